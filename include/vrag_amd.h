@@ -1,0 +1,151 @@
+/* vrag_amd.h -- C ABI of the MI355X (gfx950) hot-path library `libvrag_amd.so`.
+ *
+ * The reference (KRLabsOrg/verbatim-rag) is pure Python and has no FFI of its own; these
+ * entry points are what a Python binding (ctypes) calls in place of the
+ * third-party arithmetic the reference delegates to:
+ *
+ *   vrag_encoder_*         <- transformers ModernBertModel.forward, called from
+ *                             packages/core/verbatim_core/extractor_models/model.py:75
+ *                             (QAModel.forward) and extractors.py:260-268 (legacy qa_model path)
+ *   vrag_encoder_*qa*      <- QAModel sentence head, extractor_models/model.py:82-113
+ *   vrag_encoder_*token*   <- ModernBertForTokenClassification head used by the v2 highlighter
+ *                             `.process()` (extractors.py:213-221)
+ *   vrag_encoder_*splade*  <- SparseEncoder.encode (MLM logits -> max_s log1p(relu))
+ *                             verbatim_rag/embedding_providers.py:127-166
+ *   vrag_encoder_*pool*    <- SentenceTransformer.encode (pool + L2 normalise)
+ *                             verbatim_rag/embedding_providers.py:73-77
+ *
+ * Conventions: every function returns 0 (VRAG_OK) or a negative status; the message for the
+ * last failure on the calling thread is vrag_last_error().  Handles are thread-safe (one
+ * internal mutex per handle; callers may hit one handle from asyncio.to_thread workers like
+ * extractors.py:48-54 does).  `stream` arguments are a hipStream_t passed as void* (NULL = the
+ * handle's own stream).  load_* = host->device upload, run_* = device kernels only,
+ * read_* = device->host (synchronises the stream).  No callbacks, no global state.
+ */
+#ifndef VRAG_AMD_H
+#define VRAG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRAG_OK 0
+#define VRAG_ERR_INVALID (-1) /* bad argument / shape / state */
+#define VRAG_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define VRAG_ERR_CAPACITY (-3)/* batch does not fit the workspace the handle was created with */
+#define VRAG_ERR_NO_DEVICE (-4)
+
+#define VRAG_ABI_VERSION 1
+
+typedef struct vrag_encoder vrag_encoder;
+
+typedef struct vrag_encoder_config {
+  int32_t vocab_size;
+  int32_t hidden_size;         /* multiple of 128, <= 1024; head_dim is fixed at 64 */
+  int32_t num_layers;
+  int32_t num_heads;           /* hidden_size / 64 */
+  int32_t intermediate_size;   /* multiple of 64 */
+  int32_t global_every;        /* layer l is global attention iff l % global_every == 0 */
+  int32_t sliding_window;      /* local layers keep |i-j| <= sliding_window (ModernBERT: 64) */
+  float rope_theta_global;     /* 160000 */
+  float rope_theta_local;      /* 10000 */
+  float norm_eps;              /* 1e-5 */
+  int32_t pad_token_id;
+  int32_t max_seq_len;         /* longest sequence (RoPE table rows) */
+  int32_t max_tokens;          /* workspace capacity: packed tokens per batch */
+  int32_t max_seqs;            /* sequences per batch */
+  int32_t max_ranges;          /* sentence / pooling ranges per batch */
+  int32_t micro_batch_tokens;  /* 0 = whole batch per kernel; else split (cache blocking) */
+  int32_t device;              /* HIP device ordinal */
+} vrag_encoder_config;
+
+/* Host fp32 arrays, HF layouts ([out,in] row-major for nn.Linear weights). Per-layer arrays
+ * have num_layers entries; attn_norm[0] is ignored (layer 0 has no attn_norm). */
+typedef struct vrag_encoder_weights {
+  const float* tok_embeddings;   /* [V, H]   embeddings.tok_embeddings.weight */
+  const float* emb_norm;         /* [H]      embeddings.norm.weight */
+  const float* const* attn_norm; /* [L][H]   layers.i.attn_norm.weight */
+  const float* const* wqkv;      /* [L][3H,H] layers.i.attn.Wqkv.weight */
+  const float* const* wo;        /* [L][H,H] layers.i.attn.Wo.weight */
+  const float* const* mlp_norm;  /* [L][H]   layers.i.mlp_norm.weight */
+  const float* const* wi;        /* [L][2I,H] layers.i.mlp.Wi.weight */
+  const float* const* wo_mlp;    /* [L][H,I] layers.i.mlp.Wo.weight */
+  const float* final_norm;       /* [H]      final_norm.weight */
+} vrag_encoder_weights;
+
+const char* vrag_last_error(void);
+int vrag_abi_version(void);
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int vrag_device_count(void);
+
+int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weights* w, vrag_encoder** out);
+void vrag_encoder_destroy(vrag_encoder* enc);
+
+/* Heads (host fp32, HF layouts). */
+int vrag_encoder_set_qa_head(vrag_encoder* enc, const float* w /*[labels,H]*/, const float* b /*[labels]*/,
+                             int32_t num_labels);
+int vrag_encoder_set_token_head(vrag_encoder* enc, const float* dense_w /*[H,H]*/, const float* norm_w /*[H]*/,
+                                const float* cls_w /*[labels,H]*/, const float* cls_b /*[labels]*/,
+                                int32_t num_labels);
+/* decoder_w == NULL ties the decoder to tok_embeddings (ModernBertForMaskedLM). */
+int vrag_encoder_set_mlm_head(vrag_encoder* enc, const float* dense_w /*[H,H]*/, const float* norm_w /*[H]*/,
+                              const float* decoder_w /*[V,H] or NULL*/, const float* decoder_b /*[V]*/);
+
+/* Packed batch: `ids` is the plain concatenation of n_seqs unpadded sequences of lengths
+ * seq_lens[i] (positions restart at 0 per sequence, like the reference's B=1 forward). */
+int vrag_encoder_load_batch(vrag_encoder* enc, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
+                            void* stream);
+/* Embedding + all encoder layers; leaves the fp32 residual stream on the device. */
+int vrag_encoder_run(vrag_encoder* enc, void* stream);
+/* Same, stopping after `n_layers` layers (debug / per-layer parity). */
+int vrag_encoder_run_layers(vrag_encoder* enc, int32_t n_layers, void* stream);
+
+/* Inclusive token ranges inside sequences (sentence boundaries or pooling spans). */
+int vrag_encoder_load_ranges(vrag_encoder* enc, const int32_t* seq_idx, const int32_t* start, const int32_t* end,
+                             int32_t n_ranges, void* stream);
+/* final LayerNorm + mean over each range + Linear(H, labels)  -> device logits [n_ranges, labels] */
+int vrag_encoder_run_qa_head(vrag_encoder* enc, void* stream);
+int vrag_encoder_read_qa_logits(vrag_encoder* enc, float* logits /*[n_ranges, labels]*/, void* stream);
+/* final LayerNorm + mean over each range (+ L2 normalise) -> [n_ranges, H] */
+int vrag_encoder_run_pool(vrag_encoder* enc, int32_t normalize, void* stream);
+int vrag_encoder_read_pool(vrag_encoder* enc, float* out /*[n_ranges, H]*/, void* stream);
+
+/* Token-classification head: logits for every packed token, in the caller's concatenation order. */
+int vrag_encoder_run_token_head(vrag_encoder* enc, void* stream);
+int vrag_encoder_read_token_logits(vrag_encoder* enc, float* logits /*[n_tokens, labels]*/, void* stream);
+
+/* SPLADE head: rows[s][v] = max over the tokens of sequence s of log1p(relu(mlm_logit)). */
+int vrag_encoder_run_splade(vrag_encoder* enc, void* stream);
+int vrag_encoder_read_splade(vrag_encoder* enc, float* rows /*[n_seqs, V]*/, void* stream);
+
+/* Debug / parity: final-LayerNorm hidden states (or the raw residual stream), caller order. */
+int vrag_encoder_read_hidden(vrag_encoder* enc, int32_t apply_final_norm, float* out /*[n_tokens, H]*/,
+                             void* stream);
+
+/* One-call convenience for the extractor path: load_batch + load_ranges + run + run_qa_head + read. */
+int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
+                            const int32_t* rng_seq, const int32_t* rng_start, const int32_t* rng_end,
+                            int32_t n_ranges, float* logits);
+
+/* Per-kernel-class timing with HIP events recorded on the launch stream.
+ * classes: see VRAG_PROF_* ; ms[i] = summed event time, launches[i] = launch count since reset. */
+#define VRAG_PROF_EMBED 0
+#define VRAG_PROF_LAYERNORM 1
+#define VRAG_PROF_GEMM_QKV 2
+#define VRAG_PROF_ATTN_GLOBAL 3
+#define VRAG_PROF_ATTN_LOCAL 4
+#define VRAG_PROF_GEMM_WO 5
+#define VRAG_PROF_GEMM_WI 6
+#define VRAG_PROF_GEMM_WO_MLP 7
+#define VRAG_PROF_HEAD 8
+#define VRAG_PROF_COUNT 9
+int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
+int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/,
+                              int64_t* launches /*[VRAG_PROF_COUNT]*/, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRAG_AMD_H */

@@ -1,0 +1,124 @@
+"""ctypes binding of libvrag_amd.so (include/vrag_amd.h). Fails loudly: there is no
+Python/CPU fallback for any entry point."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LOCK = threading.Lock()
+_LIB = None
+
+VRAG_OK = 0
+PROF_CLASSES = (
+    "embed", "layernorm", "gemm_qkv", "attn_global", "attn_local",
+    "gemm_wo", "gemm_wi", "gemm_wo_mlp", "head",
+)
+
+
+class VragError(RuntimeError):
+    """A libvrag_amd call returned a non-zero status."""
+
+    def __init__(self, fn: str, status: int, message: str):
+        super().__init__(f"{fn} failed (status {status}): {message}")
+        self.status = status
+
+
+class EncoderConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32), ("intermediate_size", C.c_int32), ("global_every", C.c_int32),
+        ("sliding_window", C.c_int32), ("rope_theta_global", C.c_float), ("rope_theta_local", C.c_float),
+        ("norm_eps", C.c_float), ("pad_token_id", C.c_int32), ("max_seq_len", C.c_int32),
+        ("max_tokens", C.c_int32), ("max_seqs", C.c_int32), ("max_ranges", C.c_int32),
+        ("micro_batch_tokens", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+_FP = C.POINTER(C.c_float)
+_FPP = C.POINTER(_FP)
+_IP = C.POINTER(C.c_int32)
+_LP = C.POINTER(C.c_int64)
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [
+        ("tok_embeddings", _FP), ("emb_norm", _FP), ("attn_norm", _FPP), ("wqkv", _FPP), ("wo", _FPP),
+        ("mlp_norm", _FPP), ("wi", _FPP), ("wo_mlp", _FPP), ("final_norm", _FP),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/vrag_amd.h declares.
+_H = C.c_void_p
+SIGNATURES = {
+    "vrag_last_error": (C.c_char_p, []),
+    "vrag_abi_version": (C.c_int, []),
+    "vrag_device_count": (C.c_int, []),
+    "vrag_encoder_create": (C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), C.POINTER(_H)]),
+    "vrag_encoder_destroy": (None, [_H]),
+    "vrag_encoder_set_qa_head": (C.c_int, [_H, _FP, _FP, C.c_int32]),
+    "vrag_encoder_set_token_head": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int32]),
+    "vrag_encoder_set_mlm_head": (C.c_int, [_H, _FP, _FP, _FP, _FP]),
+    "vrag_encoder_load_batch": (C.c_int, [_H, _IP, _IP, C.c_int32, C.c_void_p]),
+    "vrag_encoder_run": (C.c_int, [_H, C.c_void_p]),
+    "vrag_encoder_run_layers": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "vrag_encoder_load_ranges": (C.c_int, [_H, _IP, _IP, _IP, C.c_int32, C.c_void_p]),
+    "vrag_encoder_run_qa_head": (C.c_int, [_H, C.c_void_p]),
+    "vrag_encoder_read_qa_logits": (C.c_int, [_H, _FP, C.c_void_p]),
+    "vrag_encoder_run_pool": (C.c_int, [_H, C.c_int32, C.c_void_p]),
+    "vrag_encoder_read_pool": (C.c_int, [_H, _FP, C.c_void_p]),
+    "vrag_encoder_run_token_head": (C.c_int, [_H, C.c_void_p]),
+    "vrag_encoder_read_token_logits": (C.c_int, [_H, _FP, C.c_void_p]),
+    "vrag_encoder_run_splade": (C.c_int, [_H, C.c_void_p]),
+    "vrag_encoder_read_splade": (C.c_int, [_H, _FP, C.c_void_p]),
+    "vrag_encoder_read_hidden": (C.c_int, [_H, C.c_int32, _FP, C.c_void_p]),
+    "vrag_encoder_extract_qa": (C.c_int, [_H, _IP, _IP, C.c_int32, _IP, _IP, _IP, C.c_int32, _FP]),
+    "vrag_encoder_set_profiling": (C.c_int, [_H, C.c_int32]),
+    "vrag_encoder_read_profile": (C.c_int, [_H, _FP, _LP, C.c_int32]),
+}
+
+
+def library_path() -> str:
+    return os.environ.get("VRAG_AMD_LIB", os.path.join(_HERE, "libvrag_amd.so"))
+
+
+def load() -> C.CDLL:
+    """Loads the shared library and binds every declared symbol (raises if anything is missing)."""
+    global _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). verbatim_rag_amd has no CPU fallback."
+            )
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.vrag_abi_version() != 1:
+            raise ImportError(f"{path}: ABI version {lib.vrag_abi_version()} != 1")
+        _LIB = lib
+        return lib
+
+
+def last_error() -> str:
+    msg = load().vrag_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(fn: str, status: int) -> None:
+    if status != VRAG_OK:
+        raise VragError(fn, status, last_error())
+
+
+def require_gpu() -> None:
+    if load().vrag_device_count() <= 0:
+        raise RuntimeError(
+            "verbatim_rag_amd: no HIP device visible. The MI355X hot path has no CPU fallback; "
+            "use the reference's own providers on machines without a GPU."
+        )

@@ -1,0 +1,61 @@
+"""Builds libvrag_amd.so (gfx950) in-tree with hipcc. No JIT cache, no torch extension:
+the library is a plain C-ABI shared object (include/vrag_amd.h)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libvrag_amd.so")
+SOURCES = ["gemm_bf16.hip", "attention.hip", "norm_heads.hip", "topk.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libvrag_amd.so)")
+
+
+def _newer(src: str, dst: str) -> bool:
+    return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "vrag_amd.h"))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src: str) -> str:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _newer(sp, obj) or os.path.getmtime(obj) < hdr_time:
+            cmd = [hipcc, *FLAGS, "-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    if force or any(_newer(o, LIB_PATH) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,939 @@
+// C ABI (include/vrag_amd.h) over the gfx950 kernels: handle lifetime, weight packing,
+// batch layout, the encoder schedule and the heads.  No torch types cross this boundary.
+#include "../../include/vrag_amd.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+#include "gemm_bf16.h"
+#include "norm_heads.h"
+
+namespace vrag {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- weight packing kernels
+__global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows_dst,
+                                     int rows_src, int cols, int interleave_I) {
+  // dst row r <- src row perm(r); rows beyond rows_src are zero. interleave_I > 0 applies the
+  // GeGLU interleave: each 64-row group = 32 input rows (x1) then the 32 matching gate rows (x2).
+  const int r = blockIdx.x;
+  int s = r;
+  if (interleave_I > 0) {
+    const int g = r >> 6, w = r & 63;
+    s = w < 32 ? g * 32 + w : interleave_I + g * 32 + (w - 32);
+  }
+  for (int c = threadIdx.x; c < cols; c += blockDim.x)
+    dst[(size_t)r * cols + c] = (r < rows_dst && s < rows_src) ? (bf16_t)src[(size_t)s * cols + c] : (bf16_t)0.f;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Layer {
+  float* attn_norm = nullptr;
+  bf16_t* wqkv = nullptr;
+  bf16_t* wo = nullptr;
+  float* mlp_norm = nullptr;
+  bf16_t* wi = nullptr;  // interleaved rows
+  bf16_t* wo_mlp = nullptr;
+};
+
+struct MicroBatch {
+  int row0, row1;  // row1 is a multiple of 128
+  int blk0, blk1;
+};
+
+struct ProfRec {
+  int cls;
+  hipEvent_t a, b;
+};
+
+}  // namespace vrag
+
+using namespace vrag;
+
+struct vrag_encoder {
+  vrag_encoder_config cfg{};
+  std::mutex mu;
+  hipStream_t own_stream = nullptr;
+  std::vector<void*> dev_allocs;
+  std::vector<void*> host_allocs;
+
+  // weights
+  float* tok_emb = nullptr;
+  float* emb_norm = nullptr;
+  float* final_norm = nullptr;
+  std::vector<Layer> layers;
+  float *cos_g = nullptr, *sin_g = nullptr, *cos_l = nullptr, *sin_l = nullptr;
+  // heads
+  float *qa_w = nullptr, *qa_b = nullptr;
+  int qa_labels = 0;
+  bf16_t* tk_dense = nullptr;
+  float *tk_norm = nullptr, *tk_w = nullptr, *tk_b = nullptr;
+  int tk_labels = 0;
+  bf16_t *mlm_dense = nullptr, *mlm_dec = nullptr;
+  float *mlm_norm = nullptr, *mlm_bias = nullptr;
+  int vpad = 0;
+
+  // workspace
+  int cap_rows = 0;
+  int *d_ids = nullptr, *d_pos = nullptr, *d_tokseq = nullptr;
+  float* h = nullptr;
+  bf16_t *a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr, *act = nullptr;
+  float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
+  int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;
+  int cap_blocks = 0;
+  int *d_rng_start = nullptr, *d_rng_end = nullptr;
+  float* d_rng_out = nullptr;  // [max_ranges, max(H, labels)]
+  float* d_tok_logits = nullptr;
+  unsigned* d_splade = nullptr;  // allocated with the MLM head
+
+  // pinned staging
+  int *h_ids = nullptr, *h_pos = nullptr, *h_tokseq = nullptr;
+  int *h_blk_start = nullptr, *h_blk_len = nullptr, *h_blk_q0 = nullptr;
+  int *h_rng_start = nullptr, *h_rng_end = nullptr;
+  float* h_out = nullptr;  // generic read-back staging
+  size_t h_out_bytes = 0;
+
+  // current batch
+  int n_seqs = 0, n_tokens = 0, rows = 0, n_blocks = 0, n_ranges = 0;
+  std::vector<int> seq_start, seq_len;
+  std::vector<MicroBatch> mbs;
+  bool ran = false;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+  float prof_ms[VRAG_PROF_COUNT] = {0};
+  int64_t prof_n[VRAG_PROF_COUNT] = {0};
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));          \
+      return VRAG_ERR_HIP;                                                                     \
+    }                                                                                          \
+  } while (0)
+
+#define ARG_CHECK(cond, ...)      \
+  do {                            \
+    if (!(cond)) {                \
+      set_error(__VA_ARGS__);     \
+      return VRAG_ERR_INVALID;    \
+    }                             \
+  } while (0)
+
+template <typename T>
+int dev_alloc(vrag_encoder* e, T** out, size_t count, bool zero = true) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+  HIP_TRY(hipMalloc(&p, bytes));
+  e->dev_allocs.push_back(p);
+  if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+  *out = reinterpret_cast<T*>(p);
+  return VRAG_OK;
+}
+
+template <typename T>
+int host_alloc(vrag_encoder* e, T** out, size_t count) {
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, std::max<size_t>(count * sizeof(T), 256), hipHostMallocDefault));
+  e->host_allocs.push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return VRAG_OK;
+}
+
+int upload_f32(vrag_encoder* e, float** out, const float* src, size_t count) {
+  int rc = dev_alloc(e, out, count, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*out, src, count * sizeof(float), hipMemcpyHostToDevice));
+  return VRAG_OK;
+}
+
+// fp32 host matrix [rows_src, cols] -> bf16 device matrix [rows_dst, cols] (zero padded rows).
+int upload_bf16(vrag_encoder* e, bf16_t** out, const float* src, int rows_src, int cols, int rows_dst,
+                int interleave_I, float* stage, size_t stage_elems) {
+  int rc = dev_alloc(e, out, (size_t)rows_dst * cols, false);
+  if (rc) return rc;
+  // stream the fp32 source through the staging buffer in row chunks
+  const int chunk_rows_max = (int)std::max<size_t>(1, stage_elems / cols);
+  if (interleave_I > 0 || rows_src <= chunk_rows_max) {
+    ARG_CHECK((size_t)rows_src * cols <= stage_elems, "internal: staging buffer too small");
+    HIP_TRY(hipMemcpy(stage, src, (size_t)rows_src * cols * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(rows_dst), dim3(256), 0, 0, stage, *out, rows_dst, rows_src, cols,
+                       interleave_I);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return VRAG_OK;
+  }
+  for (int r0 = 0; r0 < rows_dst; r0 += chunk_rows_max) {
+    const int nr_dst = std::min(chunk_rows_max, rows_dst - r0);
+    const int nr_src = std::max(0, std::min(chunk_rows_max, rows_src - r0));
+    if (nr_src > 0)
+      HIP_TRY(hipMemcpy(stage, src + (size_t)r0 * cols, (size_t)nr_src * cols * sizeof(float),
+                        hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(nr_dst), dim3(256), 0, 0, stage, *out + (size_t)r0 * cols, nr_dst,
+                       nr_src, cols, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  return VRAG_OK;
+}
+
+void rope_table(int max_pos, float theta, std::vector<float>& cs, std::vector<float>& sn) {
+  // inv_freq_j = 1 / theta^(2j/64), j = 0..31; fp32 like the reference (TF:141,150-163)
+  cs.resize((size_t)max_pos * 32);
+  sn.resize((size_t)max_pos * 32);
+  for (int j = 0; j < 32; ++j) {
+    const float inv = 1.0f / powf(theta, (float)(2 * j) / 64.0f);
+    for (int p = 0; p < max_pos; ++p) {
+      const float f = (float)p * inv;
+      cs[(size_t)p * 32 + j] = cosf(f);
+      sn[(size_t)p * 32 + j] = sinf(f);
+    }
+  }
+}
+
+hipStream_t pick_stream(vrag_encoder* e, void* stream) {
+  return stream ? reinterpret_cast<hipStream_t>(stream) : e->own_stream;
+}
+
+struct ProfScope {
+  vrag_encoder* e;
+  hipStream_t st;
+  ProfRec rec{};
+  bool on;
+  ProfScope(vrag_encoder* e_, int cls, hipStream_t st_) : e(e_), st(st_), on(e_->prof_on) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t ev;
+      if (!e->prof_free.empty()) {
+        ev = e->prof_free.back();
+        e->prof_free.pop_back();
+      } else {
+        (void)hipEventCreate(&ev);
+      }
+      return ev;
+    };
+    rec.cls = cls;
+    rec.a = get();
+    rec.b = get();
+    (void)hipEventRecord(rec.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, st);
+    e->prof_pending.push_back(rec);
+  }
+};
+
+int check_ready(vrag_encoder* e) {
+  ARG_CHECK(e != nullptr, "null encoder handle");
+  ARG_CHECK(e->n_seqs > 0, "no batch loaded (call vrag_encoder_load_batch first)");
+  return VRAG_OK;
+}
+
+int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t st) {
+  const auto& c = e->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size;
+  const int Tp = e->cap_rows;
+  for (const MicroBatch& mb : e->mbs) {
+    const int r0 = mb.row0, M = mb.row1 - mb.row0;
+    {
+      ProfScope ps(e, VRAG_PROF_EMBED, st);
+      HIP_TRY(launch_embed_ln(e->d_ids + r0, e->tok_emb, e->emb_norm, c.norm_eps, H, M, e->h + (size_t)r0 * H,
+                              e->a + (size_t)r0 * H, st));
+    }
+    for (int l = 0; l < n_layers; ++l) {
+      const Layer& L = e->layers[l];
+      const bool global = (l % c.global_every) == 0;
+      if (l > 0) {
+        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, L.attn_norm, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr,
+                                 st));
+      }
+      {
+        GemmParams g{};
+        g.A = e->a + (size_t)r0 * H;
+        g.W = L.wqkv;
+        g.M = M;
+        g.N = 3 * H;
+        g.K = H;
+        g.q = e->q + (size_t)r0 * H;
+        g.k = e->k + (size_t)r0 * H;
+        g.vt = e->vt + r0;
+        g.vt_ld = Tp;
+        g.rope_cos = global ? e->cos_g : e->cos_l;
+        g.rope_sin = global ? e->sin_g : e->sin_l;
+        g.pos = e->d_pos + r0;
+        g.hidden = H;
+        g.q_scale = 0.125f;
+        ProfScope ps(e, VRAG_PROF_GEMM_QKV, st);
+        HIP_TRY(launch_gemm(EPI_QKV_ROPE, g, st));
+      }
+      {
+        AttnParams ap{};
+        ap.q = e->q;
+        ap.k = e->k;
+        ap.vt = e->vt;
+        ap.o = e->o;
+        ap.blk_seq_start = e->d_blk_start + mb.blk0;
+        ap.blk_seq_len = e->d_blk_len + mb.blk0;
+        ap.blk_q0 = e->d_blk_q0 + mb.blk0;
+        ap.n_blocks = mb.blk1 - mb.blk0;
+        ap.H = H;
+        ap.nh = c.num_heads;
+        ap.Tp = Tp;
+        ap.window = c.sliding_window;
+        ProfScope ps(e, global ? VRAG_PROF_ATTN_GLOBAL : VRAG_PROF_ATTN_LOCAL, st);
+        HIP_TRY(launch_attention(ap, !global, st));
+      }
+      {
+        GemmParams g{};
+        g.A = e->o + (size_t)r0 * H;
+        g.W = L.wo;
+        g.M = M;
+        g.N = H;
+        g.K = H;
+        g.out_f32 = e->h + (size_t)r0 * H;
+        ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
+        HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+      }
+      {
+        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, L.mlp_norm, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr,
+                                 st));
+      }
+      {
+        GemmParams g{};
+        g.A = e->a + (size_t)r0 * H;
+        g.W = L.wi;
+        g.M = M;
+        g.N = 2 * I;
+        g.K = H;
+        g.out_bf16 = e->act + (size_t)r0 * I;
+        ProfScope ps(e, VRAG_PROF_GEMM_WI, st);
+        HIP_TRY(launch_gemm(EPI_GEGLU, g, st));
+      }
+      {
+        GemmParams g{};
+        g.A = e->act + (size_t)r0 * I;
+        g.W = L.wo_mlp;
+        g.M = M;
+        g.N = H;
+        g.K = I;
+        g.out_f32 = e->h + (size_t)r0 * H;
+        ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
+        HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+      }
+    }
+  }
+  e->ran = true;
+  return VRAG_OK;
+}
+
+int ensure_h_out(vrag_encoder* e, size_t bytes) {
+  if (bytes <= e->h_out_bytes) return VRAG_OK;
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  e->host_allocs.push_back(p);
+  e->h_out = reinterpret_cast<float*>(p);
+  e->h_out_bytes = bytes;
+  return VRAG_OK;
+}
+
+// Copies a padded device matrix [rows, cols] to the host and gathers the real tokens of each
+// sequence into the caller's concatenation order.
+int read_rows(vrag_encoder* e, const float* dsrc, int cols, float* out, hipStream_t st) {
+  const size_t bytes = (size_t)e->rows * cols * sizeof(float);
+  int rc = ensure_h_out(e, bytes);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(e->h_out, dsrc, bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  size_t o = 0;
+  for (int s = 0; s < e->n_seqs; ++s) {
+    memcpy(out + o * cols, e->h_out + (size_t)e->seq_start[s] * cols, (size_t)e->seq_len[s] * cols * sizeof(float));
+    o += e->seq_len[s];
+  }
+  return VRAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vrag_last_error(void) { return g_last_error.c_str(); }
+int vrag_abi_version(void) { return VRAG_ABI_VERSION; }
+
+int vrag_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weights* w, vrag_encoder** out) {
+  ARG_CHECK(cfg && w && out, "null argument");
+  *out = nullptr;
+  const int H = cfg->hidden_size, I = cfg->intermediate_size, L = cfg->num_layers, V = cfg->vocab_size;
+  ARG_CHECK(H > 0 && H % 128 == 0 && H <= 1024, "hidden_size must be a multiple of 128 and <= 1024 (got %d)", H);
+  ARG_CHECK(cfg->num_heads * 64 == H, "head_dim must be 64: num_heads*64 != hidden_size (%d, %d)", cfg->num_heads, H);
+  ARG_CHECK(I > 0 && I % 64 == 0, "intermediate_size must be a multiple of 64 (got %d)", I);
+  ARG_CHECK(L > 0 && V > 0 && cfg->global_every > 0, "bad layer/vocab configuration");
+  ARG_CHECK(cfg->max_tokens > 0 && cfg->max_seqs > 0 && cfg->max_seq_len > 0 && cfg->max_ranges > 0,
+            "max_tokens/max_seqs/max_seq_len/max_ranges must be positive");
+  ARG_CHECK(cfg->pad_token_id >= 0 && cfg->pad_token_id < V, "pad_token_id outside the vocabulary");
+  ARG_CHECK(cfg->micro_batch_tokens >= 0, "micro_batch_tokens must be >= 0");
+  if (vrag_device_count() <= cfg->device) {
+    set_error("no HIP device %d visible (the gfx950 library has no CPU fallback)", cfg->device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  vrag_encoder* e = new vrag_encoder();
+  e->cfg = *cfg;
+  auto fail = [&](int rc) {
+    vrag_encoder_destroy(e);
+    return rc;
+  };
+  int rc;
+#define TRY(x)                 \
+  do {                         \
+    rc = (x);                  \
+    if (rc) return fail(rc);   \
+  } while (0)
+
+  {
+    hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
+      return fail(VRAG_ERR_HIP);
+    }
+  }
+
+  // ---- weights
+  const size_t stage_elems = std::max<size_t>({(size_t)3 * H * H, (size_t)2 * I * H, (size_t)1 << 22});
+  float* stage = nullptr;
+  TRY(dev_alloc(e, &stage, stage_elems, false));
+  TRY(upload_f32(e, &e->tok_emb, w->tok_embeddings, (size_t)V * H));
+  TRY(upload_f32(e, &e->emb_norm, w->emb_norm, H));
+  TRY(upload_f32(e, &e->final_norm, w->final_norm, H));
+  e->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    Layer& ly = e->layers[l];
+    if (l > 0) TRY(upload_f32(e, &ly.attn_norm, w->attn_norm[l], H));
+    TRY(upload_f32(e, &ly.mlp_norm, w->mlp_norm[l], H));
+    TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems));
+    TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
+    TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * I, I, stage, stage_elems));
+    TRY(upload_bf16(e, &ly.wo_mlp, w->wo_mlp[l], H, I, H, 0, stage, stage_elems));
+  }
+  {
+    std::vector<float> cs, sn;
+    rope_table(cfg->max_seq_len, cfg->rope_theta_global, cs, sn);
+    TRY(upload_f32(e, &e->cos_g, cs.data(), cs.size()));
+    TRY(upload_f32(e, &e->sin_g, sn.data(), sn.size()));
+    rope_table(cfg->max_seq_len, cfg->rope_theta_local, cs, sn);
+    TRY(upload_f32(e, &e->cos_l, cs.data(), cs.size()));
+    TRY(upload_f32(e, &e->sin_l, sn.data(), sn.size()));
+  }
+
+  // ---- workspace
+  int n_mb = 1;
+  if (cfg->micro_batch_tokens > 0) n_mb = cfg->max_tokens / std::max(1, cfg->micro_batch_tokens) + 2;
+  e->cap_rows = (int)align_up((int64_t)cfg->max_tokens + (int64_t)kSeqAlign * cfg->max_seqs + 128LL * (n_mb + 1),
+                              kRowPad);
+  const size_t R = e->cap_rows;
+  e->cap_blocks = cfg->max_tokens / 128 + cfg->max_seqs + 1;
+  TRY(dev_alloc(e, &e->d_ids, R));
+  TRY(dev_alloc(e, &e->d_pos, R));
+  TRY(dev_alloc(e, &e->d_tokseq, R));
+  TRY(dev_alloc(e, &e->h, R * H));
+  TRY(dev_alloc(e, &e->a, R * H));
+  TRY(dev_alloc(e, &e->q, R * H));
+  TRY(dev_alloc(e, &e->k, R * H));
+  TRY(dev_alloc(e, &e->vt, R * H));
+  TRY(dev_alloc(e, &e->o, R * H));
+  TRY(dev_alloc(e, &e->act, R * I));
+  TRY(dev_alloc(e, &e->f32tmp, R * H));
+  TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_rng_start, cfg->max_ranges));
+  TRY(dev_alloc(e, &e->d_rng_end, cfg->max_ranges));
+  TRY(dev_alloc(e, &e->d_rng_out, (size_t)cfg->max_ranges * H));
+  TRY(host_alloc(e, &e->h_ids, R));
+  TRY(host_alloc(e, &e->h_pos, R));
+  TRY(host_alloc(e, &e->h_tokseq, R));
+  TRY(host_alloc(e, &e->h_blk_start, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_blk_len, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_blk_q0, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_rng_start, cfg->max_ranges));
+  TRY(host_alloc(e, &e->h_rng_end, cfg->max_ranges));
+  // pad ids everywhere so never-loaded rows embed a valid token
+  for (size_t i = 0; i < R; ++i) e->h_ids[i] = cfg->pad_token_id;
+  {
+    hipError_t he = hipMemcpy(e->d_ids, e->h_ids, R * sizeof(int), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+      set_error("hipMemcpy(ids) failed: %s", hipGetErrorString(he));
+      return fail(VRAG_ERR_HIP);
+    }
+  }
+  {
+    hipError_t he = hipDeviceSynchronize();
+    if (he != hipSuccess) {
+      set_error("device sync after create failed: %s", hipGetErrorString(he));
+      return fail(VRAG_ERR_HIP);
+    }
+  }
+#undef TRY
+  *out = e;
+  return VRAG_OK;
+}
+
+void vrag_encoder_destroy(vrag_encoder* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& r : e->prof_pending) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
+  for (void* p : e->dev_allocs) (void)hipFree(p);
+  for (void* p : e->host_allocs) (void)hipHostFree(p);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int vrag_encoder_set_qa_head(vrag_encoder* e, const float* w, const float* b, int32_t num_labels) {
+  ARG_CHECK(e && w && b && num_labels > 0 && num_labels <= e->cfg.hidden_size, "bad qa head arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  int rc = upload_f32(e, &e->qa_w, w, (size_t)num_labels * e->cfg.hidden_size);
+  if (rc) return rc;
+  rc = upload_f32(e, &e->qa_b, b, num_labels);
+  if (rc) return rc;
+  e->qa_labels = num_labels;
+  return VRAG_OK;
+}
+
+int vrag_encoder_set_token_head(vrag_encoder* e, const float* dense_w, const float* norm_w, const float* cls_w,
+                                const float* cls_b, int32_t num_labels) {
+  ARG_CHECK(e && dense_w && norm_w && cls_w && cls_b && num_labels > 0 && num_labels <= 64,
+            "bad token head arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int H = e->cfg.hidden_size;
+  float* stage = nullptr;
+  int rc = dev_alloc(e, &stage, (size_t)H * H, false);
+  if (rc) return rc;
+  rc = upload_bf16(e, &e->tk_dense, dense_w, H, H, H, 0, stage, (size_t)H * H);
+  if (rc) return rc;
+  if ((rc = upload_f32(e, &e->tk_norm, norm_w, H))) return rc;
+  if ((rc = upload_f32(e, &e->tk_w, cls_w, (size_t)num_labels * H))) return rc;
+  if ((rc = upload_f32(e, &e->tk_b, cls_b, num_labels))) return rc;
+  if ((rc = dev_alloc(e, &e->d_tok_logits, (size_t)e->cap_rows * num_labels))) return rc;
+  e->tk_labels = num_labels;
+  return VRAG_OK;
+}
+
+int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float* norm_w, const float* decoder_w,
+                              const float* decoder_b) {
+  ARG_CHECK(e && dense_w && norm_w, "bad mlm head arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int H = e->cfg.hidden_size, V = e->cfg.vocab_size;
+  const int vpad = (int)align_up(V, 128);
+  const size_t stage_elems = std::max<size_t>((size_t)H * H, (size_t)1 << 22);
+  float* stage = nullptr;
+  int rc = dev_alloc(e, &stage, stage_elems, false);
+  if (rc) return rc;
+  if ((rc = upload_bf16(e, &e->mlm_dense, dense_w, H, H, H, 0, stage, stage_elems))) return rc;
+  if ((rc = upload_f32(e, &e->mlm_norm, norm_w, H))) return rc;
+  if (decoder_w) {
+    if ((rc = upload_bf16(e, &e->mlm_dec, decoder_w, V, H, vpad, 0, stage, stage_elems))) return rc;
+  } else {
+    // tied decoder: convert the device-resident fp32 embedding table
+    if ((rc = dev_alloc(e, &e->mlm_dec, (size_t)vpad * H, false))) return rc;
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(vpad), dim3(256), 0, 0, e->tok_emb, e->mlm_dec, vpad, V, H, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if ((rc = dev_alloc(e, &e->mlm_bias, vpad, true))) return rc;
+  if (decoder_b) HIP_TRY(hipMemcpy(e->mlm_bias, decoder_b, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(e, &e->d_splade, (size_t)e->cfg.max_seqs * vpad))) return rc;
+  e->vpad = vpad;
+  return VRAG_OK;
+}
+
+int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
+                            void* stream) {
+  ARG_CHECK(e && ids && seq_lens && n_seqs > 0, "bad batch arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  const auto& c = e->cfg;
+  if (n_seqs > c.max_seqs) {
+    set_error("batch has %d sequences, handle capacity is %d", n_seqs, c.max_seqs);
+    return VRAG_ERR_CAPACITY;
+  }
+  HIP_TRY(hipSetDevice(c.device));
+  hipStream_t st = pick_stream(e, stream);
+  // a previous batch's async uploads read the pinned staging buffers
+  HIP_TRY(hipStreamSynchronize(st));
+
+  e->seq_start.assign(n_seqs, 0);
+  e->seq_len.assign(seq_lens, seq_lens + n_seqs);
+  e->mbs.clear();
+  int64_t total = 0;
+  for (int s = 0; s < n_seqs; ++s) {
+    ARG_CHECK(seq_lens[s] > 0 && seq_lens[s] <= c.max_seq_len, "sequence %d has length %d (max_seq_len %d)", s,
+              seq_lens[s], c.max_seq_len);
+    total += seq_lens[s];
+  }
+  if (total > c.max_tokens) {
+    set_error("batch has %lld tokens, handle capacity is %d", (long long)total, c.max_tokens);
+    return VRAG_ERR_CAPACITY;
+  }
+  int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_tokens = 0;
+  size_t src = 0;
+  int prev_rows = e->rows;
+  for (int s = 0; s < n_seqs; ++s) {
+    const int Ls = seq_lens[s];
+    t = (int)align_up(t, kSeqAlign);
+    if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
+      const int row1 = (int)align_up(t, 128);
+      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk});
+      for (int r = t; r < row1; ++r) {
+        e->h_ids[r] = c.pad_token_id;
+        e->h_pos[r] = 0;
+        e->h_tokseq[r] = -1;
+      }
+      t = row1;
+      mb_row0 = row1;
+      mb_blk0 = nblk;
+      mb_tokens = 0;
+    }
+    // alignment gap before this sequence
+    for (int r = (s == 0 ? 0 : e->seq_start[s - 1] + seq_lens[s - 1]); r < t; ++r) {
+      e->h_ids[r] = c.pad_token_id;
+      e->h_pos[r] = 0;
+      e->h_tokseq[r] = -1;
+    }
+    e->seq_start[s] = t;
+    for (int i = 0; i < Ls; ++i) {
+      const int id = ids[src + i];
+      ARG_CHECK(id >= 0 && id < c.vocab_size, "token id %d outside the vocabulary (sequence %d)", id, s);
+      e->h_ids[t + i] = id;
+      e->h_pos[t + i] = i;
+      e->h_tokseq[t + i] = s;
+    }
+    for (int q0 = 0; q0 < Ls; q0 += 128) {
+      e->h_blk_start[nblk] = t;
+      e->h_blk_len[nblk] = Ls;
+      e->h_blk_q0[nblk] = q0;
+      ++nblk;
+    }
+    src += Ls;
+    t += Ls;
+    mb_tokens += Ls;
+  }
+  const int rows = (int)align_up(t, 128);
+  if (rows > e->cap_rows || nblk > e->cap_blocks) {
+    set_error("internal: packed layout (%d rows, %d blocks) exceeds the workspace (%d rows, %d blocks)", rows, nblk,
+              e->cap_rows, e->cap_blocks);
+    return VRAG_ERR_CAPACITY;
+  }
+  // rows up to max(rows, previous rows) get pad ids so stale tokens of an older batch vanish
+  const int fill_to = std::min(e->cap_rows, std::max(rows, prev_rows));
+  for (int r = t; r < fill_to; ++r) {
+    e->h_ids[r] = c.pad_token_id;
+    e->h_pos[r] = 0;
+    e->h_tokseq[r] = -1;
+  }
+  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk});
+  e->n_seqs = n_seqs;
+  e->n_tokens = (int)total;
+  e->rows = rows;
+  e->n_blocks = nblk;
+  e->n_ranges = 0;
+  e->ran = false;
+  HIP_TRY(hipMemcpyAsync(e->d_ids, e->h_ids, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_pos, e->h_pos, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_tokseq, e->h_tokseq, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_blk_start, e->h_blk_start, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_blk_len, e->h_blk_len, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_blk_q0, e->h_blk_q0, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_run_layers(vrag_encoder* e, int32_t n_layers, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(n_layers >= 0 && n_layers <= e->cfg.num_layers, "n_layers out of range");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  return run_layers_locked(e, n_layers, pick_stream(e, stream));
+}
+
+int vrag_encoder_run(vrag_encoder* e, void* stream) {
+  if (!e) {
+    set_error("null encoder handle");
+    return VRAG_ERR_INVALID;
+  }
+  return vrag_encoder_run_layers(e, e->cfg.num_layers, stream);
+}
+
+int vrag_encoder_load_ranges(vrag_encoder* e, const int32_t* seq_idx, const int32_t* start, const int32_t* end,
+                             int32_t n_ranges, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(seq_idx && start && end && n_ranges > 0, "bad range arguments");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (n_ranges > e->cfg.max_ranges) {
+    set_error("%d ranges, handle capacity is %d", n_ranges, e->cfg.max_ranges);
+    return VRAG_ERR_CAPACITY;
+  }
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n_ranges; ++i) {
+    const int s = seq_idx[i];
+    ARG_CHECK(s >= 0 && s < e->n_seqs, "range %d: sequence index %d out of range", i, s);
+    ARG_CHECK(start[i] >= 0 && end[i] >= start[i] && end[i] < e->seq_len[s],
+              "range %d: [%d, %d] is not inside sequence %d of length %d", i, start[i], end[i], s, e->seq_len[s]);
+    e->h_rng_start[i] = e->seq_start[s] + start[i];
+    e->h_rng_end[i] = e->seq_start[s] + end[i];
+  }
+  e->n_ranges = n_ranges;
+  HIP_TRY(hipMemcpyAsync(e->d_rng_start, e->h_rng_start, (size_t)n_ranges * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_rng_end, e->h_rng_end, (size_t)n_ranges * sizeof(int), hipMemcpyHostToDevice, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_run_qa_head(vrag_encoder* e, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->qa_labels > 0, "qa head not set (vrag_encoder_set_qa_head)");
+  ARG_CHECK(e->n_ranges > 0, "no ranges loaded (vrag_encoder_load_ranges)");
+  ARG_CHECK(e->ran, "encoder has not run on this batch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  ProfScope ps(e, VRAG_PROF_HEAD, st);
+  HIP_TRY(launch_range_pool(e->h, e->final_norm, e->cfg.norm_eps, e->cfg.hidden_size, e->d_rng_start, e->d_rng_end,
+                            e->n_ranges, 0, e->qa_w, e->qa_b, e->qa_labels, e->d_rng_out, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_qa_logits(vrag_encoder* e, float* logits, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(logits, "null output");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  HIP_TRY(hipMemcpyAsync(logits, e->d_rng_out, (size_t)e->n_ranges * e->qa_labels * sizeof(float),
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_run_pool(vrag_encoder* e, int32_t normalize, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->n_ranges > 0, "no ranges loaded (vrag_encoder_load_ranges)");
+  ARG_CHECK(e->ran, "encoder has not run on this batch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  ProfScope ps(e, VRAG_PROF_HEAD, st);
+  HIP_TRY(launch_range_pool(e->h, e->final_norm, e->cfg.norm_eps, e->cfg.hidden_size, e->d_rng_start, e->d_rng_end,
+                            e->n_ranges, normalize ? 1 : 2, nullptr, nullptr, 0, e->d_rng_out, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_pool(vrag_encoder* e, float* out, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(out, "null output");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  HIP_TRY(hipMemcpyAsync(out, e->d_rng_out, (size_t)e->n_ranges * e->cfg.hidden_size * sizeof(float),
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_run_token_head(vrag_encoder* e, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->tk_labels > 0, "token head not set (vrag_encoder_set_token_head)");
+  ARG_CHECK(e->ran, "encoder has not run on this batch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int H = e->cfg.hidden_size;
+  ProfScope ps(e, VRAG_PROF_HEAD, st);
+  HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+  GemmParams g{};
+  g.A = e->a;
+  g.W = e->tk_dense;
+  g.M = e->rows;
+  g.N = H;
+  g.K = H;
+  g.out_f32 = e->f32tmp;
+  HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
+  HIP_TRY(launch_ln_classifier(e->f32tmp, e->tk_norm, e->cfg.norm_eps, H, e->rows, e->tk_w, e->tk_b, e->tk_labels,
+                               e->d_tok_logits, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_token_logits(vrag_encoder* e, float* logits, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(logits, "null output");
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->tk_labels > 0, "token head not set");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  return read_rows(e, e->d_tok_logits, e->tk_labels, logits, pick_stream(e, stream));
+}
+
+int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set (vrag_encoder_set_mlm_head)");
+  ARG_CHECK(e->ran, "encoder has not run on this batch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int H = e->cfg.hidden_size;
+  ProfScope ps(e, VRAG_PROF_HEAD, st);
+  HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+  GemmParams g{};
+  g.A = e->a;
+  g.W = e->mlm_dense;
+  g.M = e->rows;
+  g.N = H;
+  g.K = H;
+  g.out_f32 = e->f32tmp;
+  HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
+  HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+  HIP_TRY(hipMemsetAsync(e->d_splade, 0, (size_t)e->n_seqs * e->vpad * sizeof(unsigned), st));
+  GemmParams d{};
+  d.A = e->a;
+  d.W = e->mlm_dec;
+  d.M = e->rows;
+  d.N = e->vpad;
+  d.K = H;
+  d.bias = e->mlm_bias;
+  d.tok_seq = e->d_tokseq;
+  d.splade_rows = e->d_splade;
+  HIP_TRY(launch_gemm(EPI_SPLADE, d, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_splade(vrag_encoder* e, float* rows, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(rows, "null output");
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int V = e->cfg.vocab_size;
+  HIP_TRY(hipMemcpy2DAsync(rows, (size_t)V * sizeof(float), e->d_splade, (size_t)e->vpad * sizeof(float),
+                           (size_t)V * sizeof(float), e->n_seqs, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_hidden(vrag_encoder* e, int32_t apply_final_norm, float* out, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(out, "null output");
+  std::lock_guard<std::mutex> lk(e->mu);
+  ARG_CHECK(e->ran, "encoder has not run on this batch");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int H = e->cfg.hidden_size;
+  const float* src = e->h;
+  if (apply_final_norm) {
+    HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, nullptr, e->f32tmp, st));
+    src = e->f32tmp;
+  }
+  return read_rows(e, src, H, out, st);
+}
+
+int vrag_encoder_extract_qa(vrag_encoder* e, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
+                            const int32_t* rng_seq, const int32_t* rng_start, const int32_t* rng_end,
+                            int32_t n_ranges, float* logits) {
+  int rc;
+  if ((rc = vrag_encoder_load_batch(e, ids, seq_lens, n_seqs, nullptr))) return rc;
+  if ((rc = vrag_encoder_load_ranges(e, rng_seq, rng_start, rng_end, n_ranges, nullptr))) return rc;
+  if ((rc = vrag_encoder_run(e, nullptr))) return rc;
+  if ((rc = vrag_encoder_run_qa_head(e, nullptr))) return rc;
+  return vrag_encoder_read_qa_logits(e, logits, nullptr);
+}
+
+int vrag_encoder_set_profiling(vrag_encoder* e, int32_t enabled) {
+  ARG_CHECK(e, "null encoder handle");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->prof_on = enabled != 0;
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_profile(vrag_encoder* e, float* ms, int64_t* launches, int32_t reset) {
+  ARG_CHECK(e && ms && launches, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  for (auto& r : e->prof_pending) {
+    HIP_TRY(hipEventSynchronize(r.b));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    e->prof_ms[r.cls] += t;
+    e->prof_n[r.cls] += 1;
+    e->prof_free.push_back(r.a);
+    e->prof_free.push_back(r.b);
+  }
+  e->prof_pending.clear();
+  for (int i = 0; i < VRAG_PROF_COUNT; ++i) {
+    ms[i] = e->prof_ms[i];
+    launches[i] = e->prof_n[i];
+    if (reset) {
+      e->prof_ms[i] = 0.f;
+      e->prof_n[i] = 0;
+    }
+  }
+  return VRAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave = 64 lanes everywhere in this tree; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrag {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+// Token rows of every activation buffer are padded to a multiple of this many
+// rows so that GEMM/attention tiles never read outside an allocation.
+constexpr int kRowPad = 256;
+// Packed sequences start at token offsets that are multiples of this (keeps the
+// key-contiguous V^T rows 16-byte aligned for vector loads).
+constexpr int kSeqAlign = 8;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// wave-uniform value the compiler can prove uniform (scalar register).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// exact (erf-form) GELU, matching torch.nn.functional.gelu default.
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// 16-byte global -> LDS DMA. LDS destination = wave-uniform `lds` + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+}  // namespace vrag

@@ -1,0 +1,45 @@
+// bf16 MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  with fused epilogues (gfx950).
+// A = token-major activations (K contiguous), W = HF nn.Linear weight [out,in].
+#pragma once
+#include "common.h"
+
+namespace vrag {
+
+enum GemmEpi {
+  EPI_F32 = 0,       // out_f32[m][n] = acc (+bias)
+  EPI_BF16 = 1,      // out_bf16[m][n] = bf16(acc (+bias))
+  EPI_F32_GELU = 2,  // out_f32[m][n] = gelu_erf(acc)                   (prediction-head dense)
+  EPI_RESIDUAL = 3,  // out_f32[m][n] += acc                             (fp32 residual stream)
+  EPI_GEGLU = 4,     // out_bf16[m][f] = bf16(gelu_erf(x1[f]) * x2[f])   (Wi rows pre-interleaved)
+  EPI_QKV_ROPE = 5,  // RoPE(q,k) in fp32, q *= d^-1/2, write Q,K [T,nh,64] and V^T [nh,64,T]
+  EPI_SPLADE = 6,    // rows[seq(m)][n] = max(rows, log1p(relu(acc+bias)))  via ordered-uint atomicMax
+  EPI_COUNT
+};
+
+struct GemmParams {
+  const bf16_t* A;     // [Mpad, K]
+  const bf16_t* W;     // [N, K]
+  int M, N, K;         // M valid rows; Mpad = roundup(M, kRowPad) rows are readable
+  float* out_f32;      // EPI_F32 / EPI_F32_GELU / EPI_RESIDUAL  [M, N]
+  bf16_t* out_bf16;    // EPI_BF16 [M, N]; EPI_GEGLU [M, N/2]
+  const float* bias;   // optional [N] (EPI_F32, EPI_BF16, EPI_SPLADE)
+  // EPI_QKV_ROPE
+  bf16_t* q;           // [Mpad, hidden]
+  bf16_t* k;           // [Mpad, hidden]
+  bf16_t* vt;          // [hidden, vt_ld]   (row = head*64+d, col = token)
+  const float* rope_cos;  // [max_pos, 32]
+  const float* rope_sin;  // [max_pos, 32]
+  const int* pos;      // [Mpad] position of each packed token inside its sequence
+  int hidden;          // H (= N/3)
+  int vt_ld;           // Mpad
+  float q_scale;       // head_dim^-0.5 (exact power of two for d=64)
+  // EPI_SPLADE
+  const int* tok_seq;  // [Mpad] sequence index of each token, -1 for padding tokens
+  unsigned* splade_rows;  // [n_seqs, N] float bits (values >= 0 so uint order == float order)
+};
+
+// Launches on `stream`. Requirements: N % 128 == 0, K % 64 == 0.
+hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream);
+const char* gemm_kernel_name(GemmEpi epi);
+
+}  // namespace vrag

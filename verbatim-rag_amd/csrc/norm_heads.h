@@ -1,0 +1,29 @@
+// HBM-bound row kernels: embedding gather + LayerNorm, LayerNorm, and the fused
+// final-LayerNorm + range-mean heads (sentence classifier / dense pooling), gfx950.
+#pragma once
+#include "common.h"
+
+namespace vrag {
+
+// h[t] = LN(E[ids[t]]) (fp32 residual stream) and a = bf16(h) (layer 0 has no attn_norm).
+hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows,
+                           float* h, bf16_t* a, hipStream_t stream);
+
+// out = LN(h) * w ; writes bf16 and/or fp32 (either pointer may be null).
+hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows,
+                            bf16_t* out_bf16, float* out_f32, hipStream_t stream);
+
+// For each range r: v = mean_{t in [start[r], end[r]]} LN(h[t]) * lnw   (inclusive token range)
+//   mode 0: out[r][c] = v . Wc[c] + bc[c]          (reference QAModel head, model.py:82-113)
+//   mode 1: out[r][:] = v / max(||v||, 1e-12)       (sentence-transformers mean/CLS pooling + Normalize)
+//   mode 2: out[r][:] = v                           (pooling without normalisation)
+hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H, const int* start,
+                             const int* end, int n_ranges, int mode, const float* Wc, const float* bc,
+                             int num_labels, float* out, hipStream_t stream);
+
+// Token-classification tail: logits[t][c] = LN(x[t]) * lnw . Wc[c] + bc[c]   (x fp32 = gelu(dense(h)))
+hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows,
+                                const float* Wc, const float* bc, int num_labels, float* logits,
+                                hipStream_t stream);
+
+}  // namespace vrag

@@ -1,0 +1,232 @@
+// Row-wise kernels (one 64-lane wave per token row, float4 accesses, wave-shuffle reductions).
+// Restates nn.LayerNorm(bias=False) (transformers modeling_modernbert.py:61,70,312,314,476),
+// the embedding gather (:64-71), the reference QAModel sentence head
+// (packages/core/verbatim_core/extractor_models/model.py:82-113) and the
+// ModernBertPredictionHead norm + classifier (modeling_modernbert.py:481-490,697-699).
+#include "norm_heads.h"
+
+namespace vrag {
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane: H <= 1024
+
+// Loads one row (fp32) into registers: lane owns elements [lane*4 + 256*i, +4).
+__device__ __forceinline__ void load_row(const float* row, int H, int lane, f32x4 (&x)[MAXV]) {
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < H) x[i] = *reinterpret_cast<const f32x4*>(row + c);
+    else x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// In-register LayerNorm (biased variance, two-pass), result overwrites x.
+__device__ __forceinline__ void ln_row(f32x4 (&x)[MAXV], const f32x4 (&w)[MAXV], int H, int lane, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+  const float mean = wave_sum(s) / (float)H;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = x[i][j] - mean;
+        x[i][j] = d;
+        v += d * d;
+      }
+    }
+  }
+  const float var = wave_sum(v) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[i][j] = x[i][j] * rstd * w[i][j];
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const float* __restrict__ E,
+                                                        const float* __restrict__ w, float eps, int H, int rows,
+                                                        float* __restrict__ h, bf16_t* __restrict__ a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 x[MAXV], wv[MAXV];
+  load_row(E + (size_t)ids[row] * H, H, lane, x);
+  load_row(w, H, lane, wv);
+  ln_row(x, wv, H, lane, eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < H) {
+      *reinterpret_cast<f32x4*>(h + (size_t)row * H + c) = x[i];
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)x[i][j];
+      *reinterpret_cast<bf16x4*>(a + (size_t)row * H + c) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                         float eps, int H, int rows, bf16_t* __restrict__ ob,
+                                                         float* __restrict__ of) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 x[MAXV], wv[MAXV];
+  load_row(h + (size_t)row * H, H, lane, x);
+  load_row(w, H, lane, wv);
+  ln_row(x, wv, H, lane, eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < H) {
+      if (of) *reinterpret_cast<f32x4*>(of + (size_t)row * H + c) = x[i];
+      if (ob) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)x[i][j];
+        *reinterpret_cast<bf16x4*>(ob + (size_t)row * H + c) = o;
+      }
+    }
+  }
+}
+
+// One workgroup (4 waves) per range; waves stride over the range's tokens.
+__global__ __launch_bounds__(256) void range_pool_kernel(const float* __restrict__ h, const float* __restrict__ lnw,
+                                                          float eps, int H, const int* __restrict__ start,
+                                                          const int* __restrict__ end, int mode,
+                                                          const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                          int num_labels, float* __restrict__ out) {
+  __shared__ float red[4][MAXV * 256];
+  __shared__ float nrm[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x;
+  const int s = start[r], e = end[r];
+  f32x4 acc[MAXV], wv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load_row(lnw, H, lane, wv);
+  for (int t = s + wave; t <= e; t += 4) {
+    f32x4 x[MAXV];
+    load_row(h + (size_t)t * H, H, lane, x);
+    ln_row(x, wv, H, lane, eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc[i] += x[i];
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    *reinterpret_cast<f32x4*>(&red[wave][lane * 4 + 256 * i]) = acc[i];
+  __syncthreads();
+  const float inv_n = 1.0f / (float)(e - s + 1);
+  // every wave rebuilds the mean vector (cheap) in registers
+  f32x4 mean[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][c]);
+    v += *reinterpret_cast<const f32x4*>(&red[1][c]);
+    v += *reinterpret_cast<const f32x4*>(&red[2][c]);
+    v += *reinterpret_cast<const f32x4*>(&red[3][c]);
+    mean[i] = v * inv_n;
+  }
+  if (mode == 0) {
+    for (int c = wave; c < num_labels; c += 4) {
+      f32x4 wc[MAXV];
+      load_row(Wc + (size_t)c * H, H, lane, wc);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d += mean[i][j] * wc[i][j];
+      d = wave_sum(d);
+      if (lane == 0) out[(size_t)r * num_labels + c] = d + bc[c];
+    }
+  } else {
+    float scale = 1.0f;
+    if (mode == 1) {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q += mean[i][j] * mean[i][j];
+      q = wave_sum(q);
+      scale = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) *reinterpret_cast<f32x4*>(out + (size_t)r * H + c) = mean[i] * scale;
+      }
+    }
+  }
+  (void)nrm;
+}
+
+__global__ __launch_bounds__(256) void ln_classifier_kernel(const float* __restrict__ x_in, const float* __restrict__ lnw,
+                                                             float eps, int H, int rows, const float* __restrict__ Wc,
+                                                             const float* __restrict__ bc, int num_labels,
+                                                             float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 x[MAXV], wv[MAXV];
+  load_row(x_in + (size_t)row * H, H, lane, x);
+  load_row(lnw, H, lane, wv);
+  ln_row(x, wv, H, lane, eps);
+  for (int c = 0; c < num_labels; ++c) {
+    f32x4 wc[MAXV];
+    load_row(Wc + (size_t)c * H, H, lane, wc);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += x[i][j] * wc[i][j];
+    d = wave_sum(d);
+    if (lane == 0) logits[(size_t)row * num_labels + c] = d + bc[c];
+  }
+}
+
+}  // namespace
+
+hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows, float* h,
+                           bf16_t* a, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows, bf16_t* ob, float* of,
+                            hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of);
+  return hipGetLastError();
+}
+
+hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H, const int* start, const int* end,
+                             int n_ranges, int mode, const float* Wc, const float* bc, int num_labels, float* out,
+                             hipStream_t stream) {
+  if (n_ranges <= 0) return hipSuccess;
+  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(range_pool_kernel, dim3(n_ranges), dim3(256), 0, stream, h, lnw, eps, H, start, end, mode, Wc,
+                     bc, num_labels, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows, const float* Wc,
+                                const float* bc, int num_labels, float* logits, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_classifier_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, lnw, eps, H, rows, Wc, bc,
+                     num_labels, logits);
+  return hipGetLastError();
+}
+
+}  // namespace vrag

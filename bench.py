@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on the hot path: query x chunk span-extractions/sec @512 tok.
+
+A "step" = one pass of the extractor hot path (ModernBERT-base encoder forward + per-sentence
+classification head) over one batch of 256 synthetic (question, chunk) sequences of exactly
+512 tokens (BASELINE.json configs[1]), inputs already resident in HBM.  N>1: one process per
+GPU (torch.distributed / RCCL only for the barrier + max-over-ranks), every rank processes its
+own 256 chunks (weak scaling, no data-path collective: the units are independent).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEQ = 512
+N_SENT = 16
+Q_TOK = 24
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_batch(shape, n_seqs: int, seed: int):
+    """[CLS] q(24) ([SEP] sentence)x16 [SEP]  == 512 tokens; sentence lengths 30x6 + 29x10."""
+    rng = np.random.default_rng(seed)
+    lens = [30] * 6 + [29] * 10
+    seqs, bounds = [], []
+    for _ in range(n_seqs):
+        ids = [shape.cls_token_id] + rng.integers(1000, 50000, size=Q_TOK).tolist()
+        b = []
+        for ln in lens:
+            ids.append(shape.sep_token_id)
+            start = len(ids)
+            ids.extend(rng.integers(1000, 50000, size=ln).tolist())
+            b.append((start, len(ids) - 1))
+        ids.append(shape.sep_token_id)
+        assert len(ids) == SEQ
+        seqs.append(np.asarray(ids, dtype=np.int32))
+        bounds.append(b)
+    return seqs, bounds
+
+
+def gemm_flops_per_step(shape, tokens: int):
+    H, I = shape.hidden_size, shape.intermediate_size
+    L = shape.num_hidden_layers
+    return {
+        "gemm_qkv": 2.0 * tokens * 3 * H * H * L,
+        "gemm_wo": 2.0 * tokens * H * H * L,
+        "gemm_wi": 2.0 * tokens * 2 * I * H * L,
+        "gemm_wo_mlp": 2.0 * tokens * H * I * L,
+    }
+
+
+def chunk_flops(shape, S: int = SEQ) -> float:
+    """SURVEY 8(d) algorithmic FLOP per 512-token chunk (1.222e11 for base)."""
+    H, I, L = shape.hidden_size, shape.intermediate_size, shape.num_hidden_layers
+    lin = L * 2.0 * S * (H * 3 * H + H * H + H * 2 * I + I * H)
+    n_glob = len([l for l in range(L) if l % shape.global_attn_every_n_layers == 0])
+    glob = n_glob * 4.0 * S * S * H
+    loc = (L - n_glob) * 4.0 * S * (2 * (shape.local_attention // 2) + 1) * H
+    return lin + glob + loc
+
+
+def cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, budget_s: float):
+    """Times the numpy oracle (oracle/ = checker, never the product path) on a bounded sample."""
+    from oracle import modernbert_np as O
+
+    cfg = O.EncoderConfig(
+        vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
+        num_attention_heads=shape.num_attention_heads, intermediate_size=shape.intermediate_size,
+        global_attn_every_n_layers=shape.global_attn_every_n_layers, local_attention=shape.local_attention,
+        global_rope_theta=shape.global_rope_theta, local_rope_theta=shape.local_rope_theta, norm_eps=shape.norm_eps,
+        pad_token_id=shape.pad_token_id, cls_token_id=shape.cls_token_id, sep_token_id=shape.sep_token_id)
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    logits, t0, n = [], time.perf_counter(), 0
+    for s, b in zip(seqs, bounds):
+        hid = O.encoder_forward(cfg, weights, s)
+        logits.append(O.qa_sentence_logits(hid, b, qa_w, qa_b))
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "chunks/s", "cores": int(cores), "kind": "port",
+        "sample": f"{n} of the 256 synthetic 512-token chunks, numpy fp32 oracle (B=1 per chunk like the reference loop)",
+    }, logits
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", type=int, default=256, help="sequences per step per GPU")
+    ap.add_argument("--micro-batch-tokens", type=int, default=int(os.environ.get("VRAG_MICRO_BATCH", "0")))
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import verbatim_rag_amd  # noqa: F401
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+    from verbatim_rag_amd.weights import random_init, random_qa_head
+
+    shape = ModernBertShape.base()
+    weights = random_init(shape, seed=1234)
+    qa_w, qa_b = random_qa_head(shape)
+    n_chunks = args.chunks
+    eng = EncoderEngine(shape, weights, max_tokens=n_chunks * SEQ, max_seqs=n_chunks, max_seq_len=SEQ,
+                        max_ranges=n_chunks * N_SENT, micro_batch_tokens=args.micro_batch_tokens, device=local_rank)
+    eng.set_qa_head(qa_w, qa_b)
+    seqs, bounds = synth_batch(shape, n_chunks, seed=1234 + rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # inputs resident in HBM before the timed region
+    eng.load_batch(seqs, stream)
+    seq_idx = np.repeat(np.arange(n_chunks, dtype=np.int32), N_SENT)
+    st = np.asarray([b[0] for bs in bounds for b in bs], dtype=np.int32)
+    en = np.asarray([b[1] for bs in bounds for b in bs], dtype=np.int32)
+    eng.load_ranges(seq_idx, st, en, stream)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.run(stream)
+        eng.run_qa_head(stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.read_profile(reset=True)
+    eng.set_profiling(not args.no_profile)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    eng.set_profiling(False)
+    prof = eng.read_profile(reset=True)
+    logits = eng.read_qa_logits(stream)
+
+    if rank == 0:
+        total_chunks = world * n_chunks * args.steps
+        value = total_chunks / elapsed
+        fl = gemm_flops_per_step(shape, n_chunks * SEQ)
+        roof = None
+        breakdown = {k: {"ms_per_step": v[0] / max(1, args.steps), "launches_per_step": v[1] / max(1, args.steps)}
+                     for k, v in prof.items() if v[1] > 0}
+        gemm_tf = {}
+        for k, f in fl.items():
+            ms, n = prof.get(k, (0.0, 0))
+            if n > 0 and ms > 0:
+                gemm_tf[k] = f * args.steps / (ms * 1e-3) / 1e12
+        if gemm_tf:
+            dom = max(fl.keys(), key=lambda k: prof.get(k, (0.0, 0))[0])
+            ms, n = prof[dom]
+            kname = {"gemm_qkv": "vrag::gemm_bf16_kernel<5> (EPI_QKV_ROPE)", "gemm_wo": "vrag::gemm_bf16_kernel<3> (EPI_RESIDUAL)",
+                     "gemm_wi": "vrag::gemm_bf16_kernel<4> (EPI_GEGLU)", "gemm_wo_mlp": "vrag::gemm_bf16_kernel<3> (EPI_RESIDUAL)"}[dom]
+            roof = {
+                "bound": "mfma", "kernel": kname, "achieved": gemm_tf[dom], "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": gemm_tf[dom] / PEAK_BF16_TFLOPS, "traffic": None,
+                "avg_launch_ms": ms / n, "flop_per_launch": fl[dom] * args.steps / n,
+                "all_gemm_tflops": gemm_tf,
+            }
+        cpu, parity = None, None
+        if world == 1 and args.cpu_budget > 0:
+            cpu, ref_logits = cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, args.cpu_budget)
+            ref = np.concatenate(ref_logits, axis=0)
+            parity = float(np.abs(logits[: ref.shape[0]] - ref).max())
+        out = {
+            "metric": "query x chunk span-extractions/sec @512tok (ModernBERT-base extractor, chunks/s)",
+            "value": value, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ModernBERT-base span extractor, batch 256 chunks x 512 tok, single query, 16 sentences/chunk",
+                       "chunks_per_gpu_per_step": n_chunks, "seq_len": SEQ, "sentences_per_chunk": N_SENT,
+                       "micro_batch_tokens": args.micro_batch_tokens, "parallelism": f"dp{world} (independent chunks, no collective)",
+                       "weights": "random-init ModernBERT-base (seed 1234), bf16 MFMA operands, fp32 accumulate/residual/LN/softmax"},
+            "sentence_classifications_per_s": value * N_SENT,
+            "model_tflops": value * chunk_flops(shape) / 1e12,
+            "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "roofline": roof, "cpu_baseline": cpu, "parity_max_abs_err_vs_oracle": parity,
+            "breakdown": breakdown,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,35 @@ int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
 int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/,
                               int64_t* launches /*[VRAG_PROF_COUNT]*/, int32_t reset);
 
+/* ------------------------------------------------------------------------------------------
+ * Exact dot-product top-k (what the reference delegates to Milvus:
+ * verbatim_rag/vector_stores/milvus_base.py:239-259, metric types milvus_local.py:109-129).
+ * Order: (score desc, id asc).  Missing hits: id = -1, score = -inf.  1 <= k <= 64.
+ * Dense rows are stored bf16 (dtype 0) or fp32 (dtype 1); COSINE == IP on rows/queries the caller
+ * L2-normalised.  ids are row numbers in insertion order (the caller adds its shard base).
+ */
+typedef struct vrag_dense_index vrag_dense_index;
+int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_t device, vrag_dense_index** out);
+void vrag_dense_index_destroy(vrag_dense_index* ix);
+int64_t vrag_dense_index_size(vrag_dense_index* ix);
+int vrag_dense_index_add(vrag_dense_index* ix, const float* rows /*[n,dim] host fp32*/, int64_t n);
+int vrag_dense_index_search(vrag_dense_index* ix, const float* queries /*[nq,dim] host*/, int32_t nq, int32_t k,
+                            float* scores /*[nq,k]*/, int64_t* ids /*[nq,k]*/, void* stream);
+/* Re-runs the kernels of the last search on the device-resident queries (no copies, no sync). */
+int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, void* stream);
+
+/* Sparse (SPLADE) rows in CSR, term ids < vocab <= 65536; only documents sharing a term with the
+ * query (score > 0) are hits, like an inverted index.  ids are CSR row numbers. */
+typedef struct vrag_sparse_index vrag_sparse_index;
+int vrag_sparse_index_create(int32_t vocab, int64_t n_docs, const int64_t* indptr, const int32_t* indices,
+                             const float* values, int32_t device, vrag_sparse_index** out);
+void vrag_sparse_index_destroy(vrag_sparse_index* ix);
+int vrag_sparse_index_stats(vrag_sparse_index* ix, int64_t* n_docs, int64_t* nnz, int64_t* padded_nnz);
+int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
+                             const float* q_values, int32_t nq, int32_t k, float* scores /*[nq,k]*/,
+                             int64_t* ids /*[nq,k]*/, void* stream);
+int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

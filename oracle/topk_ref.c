@@ -1,0 +1,69 @@
+/* oracle/topk_ref.c -- TEST INFRASTRUCTURE (see oracle/__init__.py), never linked into the product.
+ *
+ * CPU restatement of exact dot-product top-k, the search the reference delegates to Milvus
+ * (verbatim_rag/vector_stores/milvus_base.py:239-259; third-party pymilvus 2.6.17 / milvus-lite
+ * 2.5.1 absent from the reference tree -> parity unpinned at the reference level; anchored on
+ * the call sites: COSINE/IP metric (milvus_local.py:109-129), `limit=top_k`, hits ordered by
+ * distance).  Total order (score desc, id asc).  fp32 accumulation:
+ *   dense : acc = fmaf(x[c], q[c], acc) for c ascending  (exact for dyadic-grid data in any order)
+ *   sparse: acc = fmaf(value_j, q[term_j], acc) in CSR order; hits need a shared term (score > 0).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void insert_hit(float* s, int64_t* id, int k, float score, int64_t doc) {
+  /* list sorted by (score desc, id asc); empty slots have id = -1 */
+  int i = k - 1;
+  if (id[i] >= 0 && !(score > s[i] || (score == s[i] && doc < id[i]))) return;
+  while (i > 0 && (id[i - 1] < 0 || score > s[i - 1] || (score == s[i - 1] && doc < id[i - 1]))) {
+    s[i] = s[i - 1];
+    id[i] = id[i - 1];
+    --i;
+  }
+  s[i] = score;
+  id[i] = doc;
+}
+
+void dense_topk_ref(const float* rows, int64_t n, int dim, const float* queries, int nq, int k, float* scores,
+                    int64_t* ids) {
+#pragma omp parallel for schedule(static)
+  for (int q = 0; q < nq; ++q) {
+    float* s = scores + (size_t)q * k;
+    int64_t* id = ids + (size_t)q * k;
+    for (int i = 0; i < k; ++i) {
+      s[i] = -INFINITY;
+      id[i] = -1;
+    }
+    const float* qv = queries + (size_t)q * dim;
+    for (int64_t r = 0; r < n; ++r) {
+      const float* x = rows + (size_t)r * dim;
+      float acc = 0.f;
+      for (int c = 0; c < dim; ++c) acc = fmaf(x[c], qv[c], acc);
+      insert_hit(s, id, k, acc, r);
+    }
+  }
+}
+
+void sparse_topk_ref(int64_t n_docs, const int64_t* indptr, const int32_t* indices, const float* values, int vocab,
+                     const int64_t* q_indptr, const int32_t* q_indices, const float* q_values, int nq, int k,
+                     float* scores, int64_t* ids) {
+#pragma omp parallel for schedule(static)
+  for (int q = 0; q < nq; ++q) {
+    float* qd = (float*)calloc((size_t)vocab, sizeof(float));
+    for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) qd[q_indices[j]] = q_values[j];
+    float* s = scores + (size_t)q * k;
+    int64_t* id = ids + (size_t)q * k;
+    for (int i = 0; i < k; ++i) {
+      s[i] = -INFINITY;
+      id[i] = -1;
+    }
+    for (int64_t d = 0; d < n_docs; ++d) {
+      float acc = 0.f;
+      for (int64_t j = indptr[d]; j < indptr[d + 1]; ++j) acc = fmaf(values[j], qd[indices[j]], acc);
+      if (acc > 0.f) insert_hit(s, id, k, acc, d);
+    }
+    free(qd);
+  }
+}

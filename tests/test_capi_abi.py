@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/vrag_amd.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import verbatim_rag_amd  # noqa: F401
+from verbatim_rag_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "vrag_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vrag_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_lib.library_path())
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vrag_amd.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_error_string():
+    lib = _lib.load()
+    assert lib.vrag_abi_version() == 1
+    assert lib.vrag_device_count() >= 0
+    assert isinstance(_lib.last_error(), str)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Product path fails loudly when there is no device (never routes to oracle/)."""
+    lib = _lib.load()
+    if lib.vrag_device_count() > 0:
+        pytest.skip("GPU present")
+    import numpy as np
+
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+    from verbatim_rag_amd.vector_stores import DenseShard, GpuVectorStore
+
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        EncoderEngine(ModernBertShape(vocab_size=512, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                      intermediate_size=192, pad_token_id=0), {})
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        DenseShard(64, 10)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        GpuVectorStore()
+    # and the raw C entry points report VRAG_ERR_NO_DEVICE instead of computing on the host
+    h = ctypes.c_void_p()
+    assert lib.vrag_dense_index_create(64, 10, 0, 0, ctypes.byref(h)) == -4
+    assert "no HIP device" in _lib.last_error()
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "verbatim-rag_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f

@@ -1,0 +1,116 @@
+"""Token-classification head, SPLADE head, dense pooling and the provider classes on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import modernbert_np as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
+            pad_token_id=0, cls_token_id=1, sep_token_id=2)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=7)
+    z = np.load(os.path.join(G, "encoder_tiny.npz"))
+    eng = EncoderEngine(ModernBertShape(**TINY), w, max_tokens=8192, max_seqs=64, max_seq_len=2048, max_ranges=256)
+    eng.set_token_head(z["tk_head.dense.weight"], z["tk_head.norm.weight"], z["tk_classifier.weight"], z["tk_classifier.bias"])
+    eng.set_mlm_head(z["mlm_head.dense.weight"], z["mlm_head.norm.weight"], z["mlm_decoder.bias"])
+    yield cfg, w, z, eng
+    eng.close()
+
+
+def test_token_logits_vs_transformers_golden(setup):
+    cfg, w, z, eng = setup
+    eng.load_batch([z["ids_200"], z["ids_64"]])
+    eng.run()
+    eng.run_token_head()
+    lg = eng.read_token_logits()
+    assert lg.shape == (264, 2)
+    ref = z["token_logits_200"]
+    err = np.abs(lg[:200] - ref).max()
+    # per-token logits see the un-averaged bf16 activation error; probability-space bound too
+    assert err < 2e-2, err
+    p, pr = O.softmax_rows(lg[:200])[:, 1], O.softmax_rows(ref)[:, 1]
+    assert np.abs(p - pr).max() < 5e-3
+
+
+def test_splade_rows_vs_golden_and_oracle(setup):
+    cfg, w, z, eng = setup
+    rng = np.random.default_rng(4)
+    seqs = [z["ids_64"], rng.integers(3, 400, size=130).astype(np.int32), rng.integers(3, 400, size=9).astype(np.int32)]
+    eng.load_batch(seqs)
+    eng.run()
+    eng.run_splade()
+    rows = eng.read_splade()
+    assert rows.shape == (3, 512) and (rows >= 0).all()
+    assert np.abs(rows[0] - z["splade_row_64"]).max() < 2e-2
+    for s, row in zip(seqs[1:], rows[1:]):
+        hid = O.encoder_forward(cfg, w, s)
+        lg = O.mlm_logits(hid, z["mlm_head.dense.weight"], z["mlm_head.norm.weight"],
+                          w["embeddings.tok_embeddings.weight"], z["mlm_decoder.bias"], cfg.norm_eps)
+        ref = O.splade_pool(lg)
+        assert np.abs(row - ref).max() < 2e-2
+        # the support (which terms are active) agrees except within the tolerance band around 0
+        assert ((row > 0) == (ref > 0))[np.abs(ref) > 2e-2].all()
+
+
+def test_dense_pooling_vs_oracle(setup):
+    cfg, w, z, eng = setup
+    seqs = [z["ids_130"], z["ids_7"]]
+    for mode in ("cls", "mean"):
+        eng.load_batch(seqs)
+        eng.load_ranges([0, 1], [0, 0], [0, 0] if mode == "cls" else [129, 6])
+        eng.run()
+        eng.run_pool(True)
+        got = eng.read_pool()
+        for s, g in zip(seqs, got):
+            ref = O.dense_pool(O.encoder_forward(cfg, w, s), mode, True)
+            assert abs(float(np.linalg.norm(g)) - 1.0) < 1e-5
+            assert np.abs(g - ref).max() < 2e-3
+
+
+def test_providers_contract(setup):
+    from tokenizers import Tokenizer
+
+    from verbatim_rag_amd.embedding_providers import GpuDenseProvider, GpuSpladeProvider
+
+    cfg, w, z, eng = setup
+    tok = Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+    sp = GpuSpladeProvider(eng, tok)
+    texts = ["Where is the tower?", "The iron bridge over the river.", "x"]
+    one = sp.embed_text(texts[0])
+    many = sp.embed_batch(texts)
+    assert sp.get_dimension() == 512
+    assert all(isinstance(k, int) and isinstance(v, float) for k, v in one.items())
+    assert len(many) == 3 and {k for k, v in many[0].items() if abs(v) > 1e-6} == set(one)
+    assert all(abs(many[0][k] - v) < 1e-6 for k, v in one.items())       # embed_text == embed_batch row (same kernels)
+    dp = GpuDenseProvider(eng, tok, pooling="mean")
+    v = dp.embed_text(texts[1])
+    vb = dp.embed_batch(texts)
+    assert dp.get_dimension() == 128 and len(v) == 128 and isinstance(v[0], float)
+    assert np.allclose(v, vb[1], atol=1e-6) and abs(np.linalg.norm(v) - 1) < 1e-5
+
+
+def test_highlighter_windows_long_context(setup):
+    """v2 highlighter path: sliding windows + token head; spans are exact substrings."""
+    from tokenizers import Tokenizer
+
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    cfg, w, z, eng = setup
+    tok = Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+    ext = GpuModelSpanExtractor(engine=eng, tokenizer=tok, model_format="highlighter", threshold=0.5, max_length=256,
+                                doc_stride=32, min_span_chars=5, merge_gap_chars=3)
+    ctx = " ".join(["The tall iron tower in paris was built for the world fair."] * 40)
+    import types
+
+    out = ext.extract_spans("Where is the tower?", [types.SimpleNamespace(text=ctx), types.SimpleNamespace(text=" ")])
+    assert set(out) == {ctx, " "} and out[" "] == []
+    assert all(s in ctx and len(s) >= 5 for s in out[ctx])

@@ -1,0 +1,76 @@
+"""Pins the oracle (oracle/modernbert_np.py) against golden vectors produced by `transformers`
+and by the reference's own QAModel.forward (tests/golden/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import modernbert_np as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
+            pad_token_id=0, cls_token_id=1, sep_token_id=2)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = O.EncoderConfig(**TINY)
+    return cfg, O.random_weights(cfg, seed=7), np.load(os.path.join(G, "encoder_tiny.npz"))
+
+
+@pytest.mark.parametrize("S", [7, 64, 130, 200])
+def test_final_hidden_vs_transformers(tiny, S):
+    cfg, w, z = tiny
+    out = O.encoder_forward(cfg, w, z[f"ids_{S}"])
+    assert np.abs(out - z[f"hidden_{S}"]).max() < 5e-6
+
+
+def test_residual_stream_per_layer_vs_transformers(tiny):
+    cfg, w, z = tiny
+    _, hs = O.encoder_forward(cfg, w, z["ids_130"], return_all=True)
+    for l in range(4):
+        assert np.abs(hs[l] - z[f"resid_130_l{l}"]).max() < 5e-6, l
+
+
+def test_sentence_head_vs_reference_qamodel(tiny):
+    cfg, w, z = tiny
+    hid = O.encoder_forward(cfg, w, z["ids_130"])
+    bounds = [tuple(b) for b in z["qa_bounds"].tolist()]
+    lg = O.qa_sentence_logits(hid, bounds, z["qa_Wc"], z["qa_bc"])
+    assert lg.shape == z["qa_logits_130"].shape == (4, 2)  # the invalid (50,10) range is skipped, (100,400) clamped
+    assert np.abs(lg - z["qa_logits_130"]).max() < 5e-6
+
+
+def test_token_head_vs_transformers(tiny):
+    cfg, w, z = tiny
+    hid = O.encoder_forward(cfg, w, z["ids_200"])
+    lg = O.token_logits(hid, z["tk_head.dense.weight"], z["tk_head.norm.weight"], z["tk_classifier.weight"],
+                        z["tk_classifier.bias"], cfg.norm_eps)
+    assert np.abs(lg - z["token_logits_200"]).max() < 1e-5
+
+
+def test_mlm_and_splade_vs_transformers(tiny):
+    cfg, w, z = tiny
+    hid = O.encoder_forward(cfg, w, z["ids_64"])
+    lg = O.mlm_logits(hid, z["mlm_head.dense.weight"], z["mlm_head.norm.weight"],
+                      w["embeddings.tok_embeddings.weight"], z["mlm_decoder.bias"], cfg.norm_eps)
+    assert np.abs(lg - z["mlm_logits_64"]).max() < 2e-5
+    assert np.abs(O.splade_pool(lg) - z["splade_row_64"]).max() < 2e-5
+
+
+def test_base_config_logits_vs_transformers():
+    """ModernBERT-base shapes, weights from the shared seeded generator, fp32 transformers logits."""
+    import verbatim_rag_amd  # noqa: F401
+    from verbatim_rag_amd.engine import ModernBertShape
+    from verbatim_rag_amd.weights import random_init, random_qa_head
+
+    z = np.load(os.path.join(G, "encoder_base.npz"))
+    shape = ModernBertShape.base()
+    w = random_init(shape, seed=1234)
+    qa_w, qa_b = random_qa_head(shape)
+    cfg = O.EncoderConfig()
+    ids, bounds = z["ids_1"], [tuple(b) for b in z["bounds_1"].tolist()]
+    hid = O.encoder_forward(cfg, w, ids)
+    assert np.abs(hid[:4] - z["hidden_rows_1"]).max() < 2e-4
+    lg = O.qa_sentence_logits(hid, bounds, qa_w, qa_b)
+    assert np.abs(lg - z["logits_1"]).max() < 5e-5

@@ -1,0 +1,139 @@
+"""Dense / sparse exact top-k on the GPU vs the C oracle (bit-exact indices on dyadic-grid data)."""
+import numpy as np
+import pytest
+
+from oracle import topk_ref as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _dyadic(rng, shape, lim=64):
+    return rng.integers(-lim, lim + 1, size=shape).astype(np.float32) / 64.0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("n,dim,nq,k", [(10000, 768, 5, 10), (4097, 384, 1, 5), (37, 64, 3, 64), (200000, 128, 9, 7)])
+def test_dense_topk_exact_on_dyadic_grid(dtype, n, dim, nq, k):
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(n + dim)
+    X, Q = _dyadic(rng, (n, dim)), _dyadic(rng, (nq, dim))
+    X[n // 2] = X[n // 3]                        # exact score ties -> id asc must decide
+    sh = DenseShard(dim, n + 5, dtype)
+    sh.add(X[: n // 2])
+    sh.add(X[n // 2:])
+    s, i = sh.search(Q, k)
+    rs, ri = T.dense_topk(X, Q, k)
+    sh.close()
+    assert np.array_equal(i, ri)
+    assert np.array_equal(s, rs)
+
+
+def test_dense_topk_random_data_recall_and_scores():
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((50000, 768)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = X[:4] + 0.05 * rng.standard_normal((4, 768)).astype(np.float32)
+    sh = DenseShard(768, 50000, "bf16")
+    sh.add(X)
+    s, i = sh.search(Q, 10)
+    sh.close()
+    rs, ri = T.dense_topk(T.bf16_round(X), Q, 10)
+    recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(i, ri)])
+    assert recall >= 0.99
+    assert np.abs(s - rs).max() < 1e-4 and (i[:, 0] == np.arange(4)).all()
+
+
+def test_dense_fewer_rows_than_k_and_empty():
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    sh = DenseShard(64, 100, "f32")
+    s, i = sh.search(np.ones((2, 64), np.float32), 5)
+    assert (i == -1).all() and np.isinf(s).all()
+    sh.add(np.eye(3, 64, dtype=np.float32))
+    s, i = sh.search(np.eye(1, 64, dtype=np.float32), 5)
+    sh.close()
+    assert i.tolist() == [[0, 1, 2, -1, -1]] and s[0, :3].tolist() == [1.0, 0.0, 0.0]
+
+
+def _sparse_corpus(rng, n, vocab, mean_nnz, qn, q_nnz):
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    indptr, idx, val = [0], [], []
+    for _ in range(n):
+        m = max(0, int(rng.poisson(mean_nnz)))
+        t = np.unique(rng.choice(vocab, size=m, p=p)) if m else np.zeros(0, np.int64)
+        idx.append(t)
+        val.append(rng.integers(1, 193, size=len(t)).astype(np.float32) / 64)
+        indptr.append(indptr[-1] + len(t))
+    qp, qi, qv = [0], [], []
+    for _ in range(qn):
+        t = np.unique(rng.choice(vocab, size=max(1, int(rng.poisson(q_nnz))), p=p))
+        qi.append(t)
+        qv.append(rng.integers(1, 193, size=len(t)).astype(np.float32) / 64)
+        qp.append(qp[-1] + len(t))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return (np.asarray(indptr), cat(idx, np.int32), cat(val, np.float32), np.asarray(qp), cat(qi, np.int32), cat(qv, np.float32))
+
+
+@pytest.mark.parametrize("vocab", [30522, 50368])       # LDS-resident query / L2-resident query paths
+def test_sparse_topk_bit_exact(vocab):
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    rng = np.random.default_rng(vocab)
+    indptr, idx, val, qp, qi, qv = _sparse_corpus(rng, 20000, vocab, 64, 6, 24)
+    sh = SparseShard(vocab, indptr, idx, val)
+    st = sh.stats()
+    assert st["n_docs"] == 20000 and st["nnz"] == indptr[-1] and st["padded_nnz"] < 1.1 * st["nnz"] + 64 * 64
+    s, i = sh.search_csr(qp, qi, qv, 5)
+    rs, ri = T.sparse_topk(indptr, idx, val, vocab, qp, qi, qv, 5)
+    assert np.array_equal(i, ri) and np.array_equal(s, rs)
+    # arbitrary fp32 weights: same fmaf order as the oracle -> still bit-exact
+    val2 = rng.random(len(val)).astype(np.float32) * 3
+    qv2 = rng.random(len(qv)).astype(np.float32) * 3
+    sh2 = SparseShard(vocab, indptr, idx, val2)
+    s, i = sh2.search_csr(qp, qi, qv2, 10)
+    rs, ri = T.sparse_topk(indptr, idx, val2, vocab, qp, qi, qv2, 10)
+    sh.close(); sh2.close()
+    assert np.array_equal(i, ri) and np.array_equal(s, rs)
+
+
+def test_sparse_no_shared_terms_is_not_a_hit():
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    sh = SparseShard(100, [0, 2, 3, 3], [1, 2, 5], [1.0, 2.0, 3.0])     # doc 2 is empty
+    s, i = sh.search([{5: 2.0}, {7: 1.0}], 3)
+    sh.close()
+    assert i.tolist() == [[1, -1, -1], [-1, -1, -1]] and s[0, 0] == 6.0
+
+
+def test_vector_store_semantics():
+    from verbatim_rag_amd.vector_stores import GpuVectorStore
+
+    rng = np.random.default_rng(3)
+    n, dim, vocab = 300, 64, 1000
+    dense = _dyadic(rng, (n, dim)).tolist()
+    sparse = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 8, replace=False), rng.integers(1, 64, 8) / 64)} for _ in range(n)]
+    st = GpuVectorStore(dense_dim=dim, sparse_vocab=vocab, dense_dtype="f32")
+    st.add_vectors([f"id{i}" for i in range(n)], dense, sparse, [f"text {i}" for i in range(n)],
+                   [f"enh {i}" for i in range(n)], [{"document_id": f"d{i % 3}", "title": f"T{i}"} for i in range(n)])
+    q = dense[17]
+    r = st.query(dense_query=q, top_k=3, search_type="dense")
+    assert r[0].id == "id17" and abs(r[0].score - 1.0) < 1e-5 and r[0].text == "text 17" and r[0].metadata["title"] == "T17"
+    r = st.query(sparse_query=sparse[5], top_k=4, search_type="sparse")
+    assert r[0].id == "id5" and len(r) <= 4
+    r = st.query(dense_query=q, sparse_query=sparse[17], top_k=5, search_type="hybrid")
+    assert r[0].id == "id17" and abs(r[0].score - (1.0 - (0.5 / 61 + 0.5 / 61))) < 1e-12     # RRF distance, float64
+    r = st.query(dense_query=q, top_k=5, search_type="dense", filter='metadata["document_id"] == "d0"')
+    assert all(x.metadata["document_id"] == "d0" for x in r) and len(r) == 5
+    with pytest.raises(ValueError):
+        st.query(dense_query=q, top_k=5, search_type="dense", filter="a > 3")
+    with pytest.raises(ValueError):
+        st.query(dense_query=q, top_k=5, search_type="bogus")
+    st.delete(["id17"])
+    assert st.query(dense_query=q, top_k=3, search_type="dense")[0].id != "id17"
+    r = st.query(dense_query=q, sparse_query=sparse[3], top_k=4, hybrid_weights={"dense": 0.7, "sparse": 0.3, "full_text": 1})
+    assert len(r) == 4
+    assert len(st.query(top_k=7)) == 7     # filter-only browse

@@ -75,7 +75,7 @@ using namespace vrag;
 
 struct vrag_encoder {
   vrag_encoder_config cfg{};
-  std::mutex mu;
+  std::recursive_mutex mu;
   hipStream_t own_stream = nullptr;
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
@@ -536,7 +536,7 @@ void vrag_encoder_destroy(vrag_encoder* e) {
 
 int vrag_encoder_set_qa_head(vrag_encoder* e, const float* w, const float* b, int32_t num_labels) {
   ARG_CHECK(e && w && b && num_labels > 0 && num_labels <= e->cfg.hidden_size, "bad qa head arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   int rc = upload_f32(e, &e->qa_w, w, (size_t)num_labels * e->cfg.hidden_size);
   if (rc) return rc;
@@ -550,7 +550,7 @@ int vrag_encoder_set_token_head(vrag_encoder* e, const float* dense_w, const flo
                                 const float* cls_b, int32_t num_labels) {
   ARG_CHECK(e && dense_w && norm_w && cls_w && cls_b && num_labels > 0 && num_labels <= 64,
             "bad token head arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int H = e->cfg.hidden_size;
   float* stage = nullptr;
@@ -569,7 +569,7 @@ int vrag_encoder_set_token_head(vrag_encoder* e, const float* dense_w, const flo
 int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float* norm_w, const float* decoder_w,
                               const float* decoder_b) {
   ARG_CHECK(e && dense_w && norm_w, "bad mlm head arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int H = e->cfg.hidden_size, V = e->cfg.vocab_size;
   const int vpad = (int)align_up(V, 128);
@@ -598,7 +598,7 @@ int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float
 int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
                             void* stream) {
   ARG_CHECK(e && ids && seq_lens && n_seqs > 0, "bad batch arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   const auto& c = e->cfg;
   if (n_seqs > c.max_seqs) {
     set_error("batch has %d sequences, handle capacity is %d", n_seqs, c.max_seqs);
@@ -698,7 +698,7 @@ int vrag_encoder_run_layers(vrag_encoder* e, int32_t n_layers, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(n_layers >= 0 && n_layers <= e->cfg.num_layers, "n_layers out of range");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   return run_layers_locked(e, n_layers, pick_stream(e, stream));
 }
@@ -716,7 +716,7 @@ int vrag_encoder_load_ranges(vrag_encoder* e, const int32_t* seq_idx, const int3
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(seq_idx && start && end && n_ranges > 0, "bad range arguments");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   if (n_ranges > e->cfg.max_ranges) {
     set_error("%d ranges, handle capacity is %d", n_ranges, e->cfg.max_ranges);
     return VRAG_ERR_CAPACITY;
@@ -741,7 +741,7 @@ int vrag_encoder_load_ranges(vrag_encoder* e, const int32_t* seq_idx, const int3
 int vrag_encoder_run_qa_head(vrag_encoder* e, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->qa_labels > 0, "qa head not set (vrag_encoder_set_qa_head)");
   ARG_CHECK(e->n_ranges > 0, "no ranges loaded (vrag_encoder_load_ranges)");
   ARG_CHECK(e->ran, "encoder has not run on this batch");
@@ -757,7 +757,7 @@ int vrag_encoder_read_qa_logits(vrag_encoder* e, float* logits, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(logits, "null output");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
   HIP_TRY(hipMemcpyAsync(logits, e->d_rng_out, (size_t)e->n_ranges * e->qa_labels * sizeof(float),
@@ -769,7 +769,7 @@ int vrag_encoder_read_qa_logits(vrag_encoder* e, float* logits, void* stream) {
 int vrag_encoder_run_pool(vrag_encoder* e, int32_t normalize, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->n_ranges > 0, "no ranges loaded (vrag_encoder_load_ranges)");
   ARG_CHECK(e->ran, "encoder has not run on this batch");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -784,7 +784,7 @@ int vrag_encoder_read_pool(vrag_encoder* e, float* out, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(out, "null output");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
   HIP_TRY(hipMemcpyAsync(out, e->d_rng_out, (size_t)e->n_ranges * e->cfg.hidden_size * sizeof(float),
@@ -796,7 +796,7 @@ int vrag_encoder_read_pool(vrag_encoder* e, float* out, void* stream) {
 int vrag_encoder_run_token_head(vrag_encoder* e, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->tk_labels > 0, "token head not set (vrag_encoder_set_token_head)");
   ARG_CHECK(e->ran, "encoder has not run on this batch");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -821,7 +821,7 @@ int vrag_encoder_read_token_logits(vrag_encoder* e, float* logits, void* stream)
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(logits, "null output");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->tk_labels > 0, "token head not set");
   HIP_TRY(hipSetDevice(e->cfg.device));
   return read_rows(e, e->d_tok_logits, e->tk_labels, logits, pick_stream(e, stream));
@@ -830,7 +830,7 @@ int vrag_encoder_read_token_logits(vrag_encoder* e, float* logits, void* stream)
 int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set (vrag_encoder_set_mlm_head)");
   ARG_CHECK(e->ran, "encoder has not run on this batch");
   HIP_TRY(hipSetDevice(e->cfg.device));
@@ -865,7 +865,7 @@ int vrag_encoder_read_splade(vrag_encoder* e, float* rows, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(rows, "null output");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
@@ -880,7 +880,7 @@ int vrag_encoder_read_hidden(vrag_encoder* e, int32_t apply_final_norm, float* o
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(out, "null output");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->ran, "encoder has not run on this batch");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
@@ -896,6 +896,8 @@ int vrag_encoder_read_hidden(vrag_encoder* e, int32_t apply_final_norm, float* o
 int vrag_encoder_extract_qa(vrag_encoder* e, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
                             const int32_t* rng_seq, const int32_t* rng_start, const int32_t* rng_end,
                             int32_t n_ranges, float* logits) {
+  ARG_CHECK(e != nullptr, "null encoder handle");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);  // the whole sequence is one critical section
   int rc;
   if ((rc = vrag_encoder_load_batch(e, ids, seq_lens, n_seqs, nullptr))) return rc;
   if ((rc = vrag_encoder_load_ranges(e, rng_seq, rng_start, rng_end, n_ranges, nullptr))) return rc;
@@ -906,14 +908,14 @@ int vrag_encoder_extract_qa(vrag_encoder* e, const int32_t* ids, const int32_t* 
 
 int vrag_encoder_set_profiling(vrag_encoder* e, int32_t enabled) {
   ARG_CHECK(e, "null encoder handle");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   e->prof_on = enabled != 0;
   return VRAG_OK;
 }
 
 int vrag_encoder_read_profile(vrag_encoder* e, float* ms, int64_t* launches, int32_t reset) {
   ARG_CHECK(e && ms && launches, "null argument");
-  std::lock_guard<std::mutex> lk(e->mu);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   for (auto& r : e->prof_pending) {
     HIP_TRY(hipEventSynchronize(r.b));

@@ -1,0 +1,354 @@
+"""GPU drop-in for the reference's ModelSpanExtractor.
+
+Plug point kept: `SpanExtractor.extract_spans(question, search_results) -> Dict[text, List[str]]`
+(packages/core/verbatim_core/extractors.py:34-54); callers: verbatim_rag/core.py:255,351,
+verbatim_core/transform.py:94,122, verbatim_rag/streaming.py:98-100.
+
+What changes underneath: the reference runs one tokenisation + one [1,S] ModernBERT forward per
+retrieved chunk (extractors.py:233-268); here all (question, chunk) pairs of a call are packed
+into ONE padding-free token batch and run through the HIP encoder + sentence head in one go.
+The host-side rules are the reference's, unchanged: regex sentence split (:190-195), the
+`[CLS] q [SEP] s1 [SEP] ...` packer with the 510-token budget (dataset.py:109-243),
+`softmax(logits)[:,1] > threshold` (strict) selection (:270-277), dict keyed by chunk text.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import threading
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .packing import (
+    PackedSample,
+    TokenizerAdapter,
+    encode_question_and_sentences,
+    split_into_sentences,
+    valid_boundaries,
+)
+
+logger = logging.getLogger(__name__)
+
+
+class SpanExtractor(ABC):
+    """Same abstract interface as the reference (extractors.py:34-54)."""
+
+    @abstractmethod
+    def extract_spans(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
+        raise NotImplementedError
+
+    async def extract_spans_async(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
+        import asyncio
+
+        return await asyncio.to_thread(self.extract_spans, question, search_results)
+
+
+def softmax_rows(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.float32)
+    x = x - x.max(axis=-1, keepdims=True)
+    e = np.exp(x, dtype=np.float32)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+def select_sentences(logits: np.ndarray, raw_sentences: Sequence[str], threshold: float) -> List[str]:
+    """extractors.py:270-277: strict `>`, logits row i is matched with raw_sentences[i]."""
+    spans: List[str] = []
+    if logits is None or len(logits) == 0:
+        return spans
+    probs = softmax_rows(np.asarray(logits))
+    for i in range(probs.shape[0]):
+        if i < len(raw_sentences) and probs[i, 1] > threshold:
+            spans.append(raw_sentences[i])
+    return spans
+
+
+def token_spans_to_char_spans(
+    probs: Sequence[float],
+    offsets: Sequence[Tuple[int, int]],
+    context: str,
+    threshold: float,
+    min_span_chars: int,
+    merge_gap_chars: int,
+) -> List[str]:
+    """Highlighter post-processing (the hub `.process()` source is not part of the reference;
+    knobs from extractors.py:86-113, run/merge semantics after `_find_span_regions`,
+    extractors.py:438-469, applied in character space as the knob names say):
+    runs of tokens with P > threshold -> [char_start, char_end); merge runs whose gap is
+    <= merge_gap_chars; drop spans shorter than min_span_chars; spans are exact substrings."""
+    runs: List[List[int]] = []
+    cur: Optional[List[int]] = None
+    for p, (a, b) in zip(probs, offsets):
+        if b <= a:  # special / empty-offset token
+            continue
+        if p > threshold:
+            if cur is None:
+                cur = [a, b]
+            else:
+                cur[1] = max(cur[1], b)
+        elif cur is not None:
+            runs.append(cur)
+            cur = None
+    if cur is not None:
+        runs.append(cur)
+    merged: List[List[int]] = []
+    for r in runs:
+        if merged and r[0] - merged[-1][1] <= merge_gap_chars:
+            merged[-1][1] = max(merged[-1][1], r[1])
+        else:
+            merged.append(list(r))
+    out = []
+    for a, b in merged:
+        if b - a >= min_span_chars and context[a:b].strip():
+            out.append(context[a:b])
+    return out
+
+
+class GpuModelSpanExtractor(SpanExtractor):
+    """MI355X implementation of ModelSpanExtractor (extractors.py:57-279).
+
+    Construct either from a local HF checkpoint directory (`model_path`: config.json +
+    *.safetensors [+ tokenizer.json]) or from an already-built `engine` + `tokenizer`.
+    Raises at construction when the HIP library or a GPU is missing -- there is no CPU path.
+    """
+
+    DEFAULT_MODEL = "KRLabsOrg/verbatim-rag-modern-bert-v2"
+    _FORMAT_HIGHLIGHTER = "highlighter"
+    _FORMAT_QA_MODEL = "qa_model"
+
+    def __init__(
+        self,
+        model_path: Optional[str] = None,
+        device: int | str | None = None,
+        threshold: float = 0.2,
+        extraction_mode: str = "individual",
+        max_display_spans: int = 5,
+        min_span_chars: int = 30,
+        merge_gap_chars: int = 20,
+        max_length: int = 8192,
+        doc_stride: int = 256,
+        *,
+        engine: Any = None,
+        tokenizer: Any = None,
+        model_format: Optional[str] = None,
+        qa_max_length: int = 512,
+        max_batch_tokens: int = 65536,
+        max_batch_seqs: int = 512,
+    ):
+        self.model_path = model_path
+        self.threshold = threshold
+        self.min_span_chars = min_span_chars
+        self.merge_gap_chars = merge_gap_chars
+        self.max_length = max_length
+        self.doc_stride = doc_stride
+        self.qa_max_length = qa_max_length
+        self.max_batch_tokens = max_batch_tokens
+        self.max_batch_seqs = max_batch_seqs
+        self._lock = threading.Lock()  # callers arrive from asyncio.to_thread workers (extractors.py:54)
+        dev = 0 if device in (None, "cuda", "cpu", "mps") else int(str(device).replace("cuda:", ""))
+        self.device = f"cuda:{dev}"
+
+        if engine is not None:
+            if tokenizer is None:
+                raise ValueError("engine= needs tokenizer=")
+            self.engine = engine
+            self._format = model_format or (
+                self._FORMAT_HIGHLIGHTER if getattr(engine, "token_labels", 0) and not getattr(engine, "qa_labels", 0)
+                else self._FORMAT_QA_MODEL)
+        else:
+            if model_path is None or not os.path.isdir(model_path):
+                raise FileNotFoundError(
+                    f"model_path={model_path!r}: a local HF checkpoint directory is required (no network here); "
+                    "or pass engine= and tokenizer=")
+            self._format = model_format or self._detect_format(model_path)
+            self.engine = self._build_engine(model_path, dev)
+            tokenizer = tokenizer or self._load_tokenizer(model_path)
+        self.tokenizer = tokenizer
+        self._tok = TokenizerAdapter(tokenizer, sep_token_id=getattr(self.engine.shape, "sep_token_id", None)
+                                     if not hasattr(tokenizer, "sep_token_id") else None,
+                                     cls_token_id=getattr(self.engine.shape, "cls_token_id", None)
+                                     if not hasattr(tokenizer, "cls_token_id") else None)
+        logger.info("GpuModelSpanExtractor ready: format=%s device=%s", self._format, self.device)
+
+    # ------------------------------------------------------------------ loading
+    @staticmethod
+    def _detect_format(model_path: str) -> str:
+        """extractors.py:135-149 without transformers: auto_map naming a *Highlighter* class."""
+        try:
+            with open(os.path.join(model_path, "config.json")) as f:
+                cfg = json.load(f)
+            auto_map = cfg.get("auto_map") or {}
+            target = auto_map.get("AutoModel") or auto_map.get("AutoModelForTokenClassification")
+            if target and "Highlighter" in target:
+                return GpuModelSpanExtractor._FORMAT_HIGHLIGHTER
+        except Exception as exc:
+            logger.warning("Highlighter detection failed for %s: %s", model_path, exc)
+        return GpuModelSpanExtractor._FORMAT_QA_MODEL
+
+    def _build_engine(self, model_path: str, dev: int):
+        from .engine import EncoderEngine, strip_prefix
+        from .weights import load_safetensors_dir
+
+        shape, tensors, _cfg = load_safetensors_dir(model_path)
+        max_seq = self.qa_max_length if self._format == self._FORMAT_QA_MODEL else self.max_length
+        eng = EncoderEngine(shape, tensors, max_tokens=self.max_batch_tokens, max_seqs=self.max_batch_seqs,
+                            max_seq_len=max_seq, max_ranges=max(4096, self.max_batch_tokens // 8), device=dev)
+        if self._format == self._FORMAT_QA_MODEL:
+            eng.set_qa_head(tensors["classifier.weight"], tensors["classifier.bias"])
+        else:
+            eng.set_token_head(tensors["head.dense.weight"], tensors["head.norm.weight"],
+                               tensors["classifier.weight"], tensors["classifier.bias"])
+        return eng
+
+    @staticmethod
+    def _load_tokenizer(model_path: str):
+        tj = os.path.join(model_path, "tokenizer.json")
+        try:
+            from transformers import AutoTokenizer
+
+            return AutoTokenizer.from_pretrained(model_path)
+        except Exception as e:  # fall back to the raw tokenizers file
+            logger.warning("AutoTokenizer failed for %s (%s); using tokenizers.Tokenizer", model_path, e)
+            from tokenizers import Tokenizer
+
+            return Tokenizer.from_file(tj)
+
+    def _split_into_sentences(self, text: str) -> List[str]:
+        return split_into_sentences(text)
+
+    # ------------------------------------------------------------------ API
+    def extract_spans(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
+        if self._format == self._FORMAT_HIGHLIGHTER:
+            return self._extract_highlighter(question, search_results)
+        return self._extract_qa_model(question, search_results)
+
+    # ------------------------------------------------------------------ legacy qa_model path
+    def pack_qa(self, question: str, texts: Sequence[str]) -> Tuple[List[List[str]], List[Optional[PackedSample]]]:
+        """Sentence split + token packing for every chunk; one batched tokenizer call for all
+        sentences (bit-identical to the reference's per-sentence calls, dataset.py:158-167)."""
+        budget = self.qa_max_length - 2
+        q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
+        all_sents = [split_into_sentences(t) for t in texts]
+        flat = [s for sents in all_sents for s in sents]
+        flat_ids = self._tok.ids_batch(flat, max_length=budget)
+        samples: List[Optional[PackedSample]] = []
+        o = 0
+        for sents in all_sents:
+            if not sents:
+                samples.append(None)
+                continue
+            samples.append(encode_question_and_sentences(q_ids, flat_ids[o:o + len(sents)], self._tok.sep_token_id,
+                                                         max_length=self.qa_max_length))
+            o += len(sents)
+        return all_sents, samples
+
+    def _extract_qa_model(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
+        texts = [getattr(r, "text", "") for r in search_results]
+        all_sents, samples = self.pack_qa(question, texts)
+        relevant: Dict[str, List[str]] = {t: [] for t in texts}
+        todo = []
+        for i, smp in enumerate(samples):
+            if smp is None:
+                continue
+            vb = valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
+            if not vb:
+                # the reference's QAModel returns None here and `len(None)` raises; we log and return [].
+                logger.error("chunk %d: no sentence fits the %d-token budget", i, self.qa_max_length)
+                continue
+            todo.append((i, smp.input_ids, vb))
+        # sub-batches that fit the engine workspace
+        with self._lock:
+            start = 0
+            while start < len(todo):
+                tok = rng = 0
+                end = start
+                while end < len(todo) and end - start < self.engine.max_seqs and \
+                        tok + len(todo[end][1]) <= self.engine.max_tokens and rng + len(todo[end][2]) <= self.engine.max_ranges:
+                    tok += len(todo[end][1])
+                    rng += len(todo[end][2])
+                    end += 1
+                if end == start:
+                    raise ValueError("a single sample exceeds the engine workspace")
+                batch = todo[start:end]
+                try:
+                    logits = self.engine.qa_logits([b[1] for b in batch], [b[2] for b in batch])
+                    for (i, _ids, _vb), lg in zip(batch, logits):
+                        relevant[texts[i]] = select_sentences(lg, all_sents[i], self.threshold)
+                except Exception as exc:  # same contract as extractors.py:225-227: log, [] for the chunk(s)
+                    logger.error("GPU span extraction failed: %s", exc)
+                start = end
+        return relevant
+
+    # ------------------------------------------------------------------ v2 highlighter path
+    def _encode_windows(self, question: str, context: str):
+        """Pair-encode (question, context) into windows of <= max_length tokens overlapping by
+        doc_stride context tokens.  Returns [(ids, ctx_token_slice, first_ctx_pos_in_window)], offsets."""
+        tok = self.tokenizer
+        if hasattr(tok, "encode_batch") and tok.__class__.__module__.startswith("tokenizers"):
+            enc = tok.encode(context, add_special_tokens=False)
+            ctx_ids, offsets = list(enc.ids), list(enc.offsets)
+        else:
+            enc = tok(context, add_special_tokens=False, return_offsets_mapping=True)
+            ctx_ids, offsets = list(enc["input_ids"]), [tuple(o) for o in enc["offset_mapping"]]
+        q = self._tok.ids(question, add_special_tokens=True, max_length=max(8, self.max_length // 2))
+        room = self.max_length - len(q) - 1
+        if room <= 0:
+            raise ValueError("question leaves no room for context tokens")
+        step = max(1, room - self.doc_stride)
+        windows = []
+        a = 0
+        while True:
+            b = min(len(ctx_ids), a + room)
+            ids = q + ctx_ids[a:b] + [self._tok.sep_token_id]
+            windows.append((ids, (a, b), len(q)))
+            if b >= len(ctx_ids):
+                break
+            a += step
+        return windows, offsets, len(ctx_ids)
+
+    def _extract_highlighter(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
+        relevant: Dict[str, List[str]] = {}
+        jobs = []
+        for result in search_results:
+            context = getattr(result, "text", "")
+            relevant[context] = []
+            if not context.strip():
+                continue
+            try:
+                windows, offsets, n_ctx = self._encode_windows(question, context)
+                jobs.append((context, windows, offsets, n_ctx))
+            except Exception as exc:
+                logger.error("Highlighter extraction failed: %s", exc)
+        flat = [(ji, w) for ji, job in enumerate(jobs) for w in job[1]]
+        probs = [np.zeros(job[3], dtype=np.float32) for job in jobs]
+        with self._lock:
+            start = 0
+            while start < len(flat):
+                tok = 0
+                end = start
+                while end < len(flat) and end - start < self.engine.max_seqs and \
+                        tok + len(flat[end][1][0]) <= self.engine.max_tokens:
+                    tok += len(flat[end][1][0])
+                    end += 1
+                if end == start:
+                    raise ValueError("a single window exceeds the engine workspace")
+                try:
+                    self.engine.load_batch([w[0] for _ji, w in flat[start:end]])
+                    self.engine.run()
+                    self.engine.run_token_head()
+                    logits = self.engine.read_token_logits()
+                    p1 = softmax_rows(logits)[:, 1]
+                    o = 0
+                    for ji, (ids, (a, b), q_len) in flat[start:end]:
+                        seg = p1[o + q_len:o + q_len + (b - a)]
+                        probs[ji][a:b] = np.maximum(probs[ji][a:b], seg)
+                        o += len(ids)
+                except Exception as exc:
+                    logger.error("Highlighter extraction failed: %s", exc)
+                start = end
+        for (context, _w, offsets, _n), p in zip(jobs, probs):
+            relevant[context] = token_spans_to_char_spans(p, offsets, context, self.threshold, self.min_span_chars,
+                                                          self.merge_gap_chars)
+        return relevant

@@ -1,0 +1,137 @@
+"""Host-side input packing for the extractor path (stays in Python like the reference).
+
+Mirrors, behaviour for behaviour:
+  * ModelSpanExtractor._split_into_sentences          packages/core/verbatim_core/extractors.py:190-195
+  * QADataset.encode_question_and_sentences_with_offsets
+                                                       packages/core/verbatim_core/extractor_models/dataset.py:109-243
+    ([CLS] question [SEP] s1 [SEP] s2 ... [SEP]; inclusive token ranges; budget max_length-2;
+     sentences that do not fit are dropped with the reference's warning text)
+The packed ids of several (question, chunk) pairs are then handed to the GPU as ONE
+padding-free batch instead of the reference's batch-size-1 loop (extractors.py:233-268).
+"""
+from __future__ import annotations
+
+import logging
+import re
+from dataclasses import dataclass, field
+from typing import Any, List, Optional, Sequence, Tuple
+
+logger = logging.getLogger(__name__)
+
+_SENT_SPLIT = re.compile(r"(?<=[.!?])\s+")
+
+
+def split_into_sentences(text: str) -> List[str]:
+    """extractors.py:190-195 -- regex split, strip, drop empties."""
+    return [s.strip() for s in _SENT_SPLIT.split(text) if s.strip()]
+
+
+class TokenizerAdapter:
+    """Uniform `ids(text, add_special_tokens, max_length)` over a HF fast tokenizer
+    (transformers) or a raw `tokenizers.Tokenizer`; truncation like the reference's
+    `encode_plus(..., max_length=, truncation=True)` (dataset.py:131-137,161-167)."""
+
+    def __init__(self, tokenizer: Any, sep_token_id: Optional[int] = None, cls_token_id: Optional[int] = None):
+        self.tok = tokenizer
+        self._raw = hasattr(tokenizer, "encode_batch") and not hasattr(tokenizer, "batch_encode_plus") \
+            and tokenizer.__class__.__module__.startswith("tokenizers")
+        sid = getattr(tokenizer, "sep_token_id", None) if not self._raw else None
+        if sep_token_id is not None:
+            sid = sep_token_id
+        if sid is None and self._raw:
+            sid = tokenizer.token_to_id("[SEP]")
+        if sid is None:
+            raise ValueError("tokenizer has no sep_token_id; pass sep_token_id=")
+        self.sep_token_id = int(sid)
+        cid = cls_token_id
+        if cid is None:
+            cid = tokenizer.token_to_id("[CLS]") if self._raw else getattr(tokenizer, "cls_token_id", None)
+        self.cls_token_id = None if cid is None else int(cid)
+
+    def ids(self, text: str, add_special_tokens: bool, max_length: int) -> List[int]:
+        if self._raw:
+            # `[CLS] $A [SEP]` template applied here so that truncation keeps the special tokens
+            # and cuts content from the right, like HF `truncation=True` on a single sequence.
+            body = list(self.tok.encode(text, add_special_tokens=False).ids)
+            if not add_special_tokens:
+                return body[:max_length]
+            if self.cls_token_id is None:
+                raise ValueError("raw tokenizer without a [CLS] id; pass cls_token_id=")
+            return [self.cls_token_id] + body[: max(0, max_length - 2)] + [self.sep_token_id]
+        enc = self.tok(text, add_special_tokens=add_special_tokens, max_length=max_length, truncation=True)
+        return list(enc["input_ids"])
+
+    def ids_batch(self, texts: Sequence[str], max_length: int) -> List[List[int]]:
+        """Sentences are tokenised independently with add_special_tokens=False (dataset.py:161-167),
+        so one batched call is bit-identical to the reference's per-sentence calls."""
+        if not texts:
+            return []
+        if self._raw:
+            return [list(e.ids)[:max_length] for e in self.tok.encode_batch(list(texts), add_special_tokens=False)]
+        enc = self.tok(list(texts), add_special_tokens=False, max_length=max_length, truncation=True)
+        return [list(x) for x in enc["input_ids"]]
+
+
+@dataclass
+class PackedSample:
+    input_ids: List[int]
+    sentence_boundaries: List[Tuple[int, int]]  # inclusive token ranges
+    n_sentences_in: int = 0
+
+
+def encode_question_and_sentences(
+    question_ids_with_special: Sequence[int],
+    sentence_ids: Sequence[Sequence[int]],
+    sep_token_id: int,
+    max_length: int = 512,
+) -> PackedSample:
+    """dataset.py:127-243 on pre-tokenised pieces.
+
+    `question_ids_with_special` = tokenizer(question, add_special_tokens=True, truncation to
+    max_length-2); `sentence_ids[i]` = tokenizer(sentence_i, add_special_tokens=False, same truncation).
+    """
+    n_in = len(sentence_ids)
+    budget = max_length - 2                                   # dataset.py:127
+    input_ids = list(question_ids_with_special)
+    if len(input_ids) > 1 and input_ids[-1] == sep_token_id:  # dataset.py:142-145
+        input_ids.pop()
+    boundaries: List[Tuple[int, int]] = []
+    for sent in sentence_ids:
+        if len(input_ids) + len(sent) + 1 > budget:           # dataset.py:172-179
+            logger.warning(
+                "Legacy QA input exceeded the %d-token budget; dropping %d sentence(s)",
+                budget + 2,
+                n_in - len(boundaries),
+            )
+            break
+        input_ids.append(sep_token_id)                        # dataset.py:183
+        start = len(input_ids)
+        input_ids.extend(sent)
+        boundaries.append((start, len(input_ids) - 1))        # inclusive end, dataset.py:195-198
+    if len(input_ids) < budget:                               # dataset.py:202-205
+        input_ids.append(sep_token_id)
+    if len(input_ids) > budget:                               # dataset.py:210-227 (only reachable when
+        last_valid = 0                                        # the question alone exceeds the budget)
+        for i, (_s, e) in enumerate(boundaries):
+            if e < budget:
+                last_valid = i
+            else:
+                break
+        if boundaries:
+            last_tok = boundaries[last_valid][1]
+            input_ids = input_ids[: last_tok + 1]
+            boundaries = boundaries[: last_valid + 1]
+    return PackedSample(input_ids=input_ids, sentence_boundaries=boundaries, n_sentences_in=n_in)
+
+
+def valid_boundaries(boundaries: Sequence[Tuple[int, int]], seq_len: int) -> List[Tuple[int, int]]:
+    """QAModel.forward's range handling (extractor_models/model.py:88-96): clamp end to S-1,
+    skip `end < start` or `start < 0` (skipped rows shift later logits up, reproduced as-is)."""
+    out = []
+    for s, e in boundaries:
+        if e >= seq_len:
+            e = seq_len - 1
+        if e < s or s < 0:
+            continue
+        out.append((s, e))
+    return out

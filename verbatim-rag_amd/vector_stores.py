@@ -1,0 +1,423 @@
+"""GPU vector store behind the reference's `VectorStore` interface.
+
+Kept from the reference (same names, argument meaning, error behaviour):
+  * `SearchResult` / `VectorStore`            verbatim_rag/vector_stores/base.py:10-74
+  * `BaseMilvusStore.add_vectors/.query` semantics (dense = COSINE, sparse = IP, hybrid = top-2k per
+    method then weighted RRF, dense fallback on failure)      vector_stores/milvus_base.py:90-127,189-313,366-459
+  * weighted RRF + hit conversion              vector_stores/hybrid_search.py:15-175 (float64 Python semantics)
+The Milvus client is replaced by exact brute-force top-k on the GPU (include/vrag_amd.h,
+vrag_dense_index_* / vrag_sparse_index_*).  Multi-GPU: rows shard across ranks and per-shard top-k lists are
+all-gathered and merged in distributed.py (ShardedTopK).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import logging
+import re
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+_FP = C.POINTER(C.c_float)
+_LP = C.POINTER(C.c_int64)
+_IP = C.POINTER(C.c_int32)
+
+
+@dataclass
+class SearchResult:
+    """base.py:10-39."""
+
+    id: str
+    score: float
+    metadata: Dict[str, Any]
+    text: str
+    enhanced_text: str = ""
+
+    def __gt__(self, other):
+        return self.score > other.score
+
+    def __lt__(self, other):
+        return self.score < other.score
+
+    def __eq__(self, other):
+        return self.score == other.score
+
+    def __hash__(self):
+        return hash((self.id, self.score, self.text, self.enhanced_text))
+
+
+class VectorStore(ABC):
+    """base.py:42-74."""
+
+    @abstractmethod
+    def add_vectors(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
+        pass
+
+    @abstractmethod
+    def query(self, dense_query=None, sparse_query=None, text_query=None, top_k: int = 5,
+              search_type: str = "hybrid", filter: Optional[str] = None) -> List[SearchResult]:
+        pass
+
+    @abstractmethod
+    def delete(self, ids: List[str]):
+        pass
+
+
+# ---------------------------------------------------------------------------- hybrid_search.py
+def sanitize_hybrid_weights(hybrid_weights: Dict[str, float]) -> Dict[str, float]:
+    """hybrid_search.py:15-45."""
+    if not hybrid_weights:
+        raise ValueError("hybrid_weights must be a non-empty dict")
+    allowed = {"dense", "sparse", "full_text"}
+    cleaned: Dict[str, float] = {}
+    for method, weight in hybrid_weights.items():
+        if method not in allowed:
+            logger.warning("Ignoring unsupported hybrid method '%s'", method)
+            continue
+        if not isinstance(weight, (int, float)) or weight <= 0:
+            logger.warning("Ignoring non-positive weight for method '%s': %s", method, weight)
+            continue
+        cleaned[method] = float(weight)
+    if not cleaned:
+        raise ValueError("No valid hybrid_weights after validation")
+    return cleaned
+
+
+def normalize_weights(results_by_method: Dict[str, List], weights: Dict[str, float]) -> Dict[str, float]:
+    """hybrid_search.py:48-70."""
+    avail = {m: weights.get(m, 0.0) for m in results_by_method}
+    total = sum(avail.values())
+    if total == 0:
+        logger.warning("No non-zero weights for available methods; using equal weights for: %s",
+                       list(results_by_method.keys()))
+        return {k: 1.0 / len(results_by_method) for k in results_by_method}
+    return {k: v / total for k, v in avail.items()}
+
+
+def merge_hybrid_results(results_by_method: Dict[str, List[dict]], top_k: int, weights: Dict[str, float],
+                         rrf_k: int = 60, log_label: str = "") -> List[dict]:
+    """Weighted reciprocal-rank fusion, hybrid_search.py:73-129: score[id] += w_m / (rrf_k + rank + 1)
+    in method insertion order, stable sort descending, `distance = 1 - score`."""
+    nw = normalize_weights(results_by_method, weights)
+    scores: Dict[Any, float] = {}
+    hit_map: Dict[Any, dict] = {}
+    for method, results in results_by_method.items():
+        w = nw.get(method, 0.0)
+        for rank, hit in enumerate(results):
+            hid = hit.get("id")
+            if not hid:
+                continue
+            if hid not in scores:
+                scores[hid] = 0.0
+                hit_map[hid] = hit
+            scores[hid] += w * (1.0 / (rrf_k + rank + 1))
+    ordered = sorted(scores.keys(), key=lambda i: scores[i], reverse=True)
+    merged = []
+    for hid in ordered[:top_k]:
+        h = hit_map[hid].copy()
+        h["distance"] = 1.0 - scores[hid]
+        merged.append(h)
+    return merged
+
+
+def convert_hits_to_results(hits: List[dict], dynamic_fields: Optional[List[str]] = None) -> List[SearchResult]:
+    """hybrid_search.py:132-175."""
+    dynamic_fields = dynamic_fields or []
+    out: List[SearchResult] = []
+    for hit in hits:
+        entity = hit.get("entity", {})
+        metadata = entity.get("metadata", {}) or {}
+        if isinstance(metadata, str):
+            try:
+                metadata = json.loads(metadata)
+            except Exception:
+                metadata = {"raw": metadata}
+        for f in dynamic_fields:
+            val = entity.get(f)
+            if val is not None:
+                metadata[f] = val
+        out.append(SearchResult(id=hit.get("id"), score=hit.get("distance", 0.0), text=entity.get("text", ""),
+                                enhanced_text=entity.get("enhanced_text", ""), metadata=metadata))
+    return out
+
+
+# ---------------------------------------------------------------------------- device indexes
+class DenseShard:
+    """One GPU's slice of the dense corpus (rows appended in order; ids are local row numbers)."""
+
+    def __init__(self, dim: int, capacity: int, dtype: str = "bf16", device: int = 0):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.dim, self.capacity = dim, capacity
+        self._h = C.c_void_p()
+        _lib.check("vrag_dense_index_create", self._lib.vrag_dense_index_create(
+            dim, capacity, 0 if dtype == "bf16" else 1, device, C.byref(self._h)))
+
+    def add(self, rows: np.ndarray) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}]")
+        _lib.check("vrag_dense_index_add", self._lib.vrag_dense_index_add(self._h, rows.ctypes.data_as(_FP), rows.shape[0]))
+
+    def __len__(self) -> int:
+        return int(self._lib.vrag_dense_index_size(self._h))
+
+    def search(self, queries: np.ndarray, k: int, stream=None) -> Tuple[np.ndarray, np.ndarray]:
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        scores = np.empty((q.shape[0], k), np.float32)
+        ids = np.empty((q.shape[0], k), np.int64)
+        _lib.check("vrag_dense_index_search", self._lib.vrag_dense_index_search(
+            self._h, q.ctypes.data_as(_FP), q.shape[0], k, scores.ctypes.data_as(_FP), ids.ctypes.data_as(_LP), stream))
+        return scores, ids
+
+    def run_resident(self, nq: int, k: int, stream=None) -> None:
+        _lib.check("vrag_dense_index_run_resident", self._lib.vrag_dense_index_run_resident(self._h, nq, k, stream))
+
+    def close(self):
+        if self._h:
+            self._lib.vrag_dense_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dicts_to_csr(rows: Sequence[Dict[int, float]]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    indptr = np.zeros(len(rows) + 1, np.int64)
+    for i, r in enumerate(rows):
+        indptr[i + 1] = indptr[i] + len(r)
+    indices = np.empty(int(indptr[-1]), np.int32)
+    values = np.empty(int(indptr[-1]), np.float32)
+    for i, r in enumerate(rows):
+        a = int(indptr[i])
+        for j, (t, v) in enumerate(sorted(r.items())):
+            indices[a + j] = int(t)
+            values[a + j] = float(v)
+    return indptr, indices, values
+
+
+class SparseShard:
+    """One GPU's slice of the SPLADE corpus (immutable SELL-64 image built from CSR)."""
+
+    def __init__(self, vocab: int, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, device: int = 0):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.vocab = vocab
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        self.n_docs = len(indptr) - 1
+        self._h = C.c_void_p()
+        _lib.check("vrag_sparse_index_create", self._lib.vrag_sparse_index_create(
+            vocab, self.n_docs, indptr.ctypes.data_as(_LP), indices.ctypes.data_as(_IP), values.ctypes.data_as(_FP),
+            device, C.byref(self._h)))
+
+    def stats(self) -> Dict[str, int]:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check("vrag_sparse_index_stats", self._lib.vrag_sparse_index_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"n_docs": a.value, "nnz": b.value, "padded_nnz": c.value}
+
+    def search_csr(self, q_indptr, q_indices, q_values, k: int, stream=None) -> Tuple[np.ndarray, np.ndarray]:
+        q_indptr = np.ascontiguousarray(q_indptr, dtype=np.int64)
+        q_indices = np.ascontiguousarray(q_indices, dtype=np.int32)
+        q_values = np.ascontiguousarray(q_values, dtype=np.float32)
+        nq = len(q_indptr) - 1
+        scores = np.empty((nq, k), np.float32)
+        ids = np.empty((nq, k), np.int64)
+        _lib.check("vrag_sparse_index_search", self._lib.vrag_sparse_index_search(
+            self._h, q_indptr.ctypes.data_as(_LP), q_indices.ctypes.data_as(_IP), q_values.ctypes.data_as(_FP), nq, k,
+            scores.ctypes.data_as(_FP), ids.ctypes.data_as(_LP), stream))
+        return scores, ids
+
+    def search(self, queries: Sequence[Dict[int, float]], k: int, stream=None):
+        return self.search_csr(*dicts_to_csr(queries), k, stream)
+
+    def run_resident(self, nq: int, k: int, stream=None) -> None:
+        _lib.check("vrag_sparse_index_run_resident", self._lib.vrag_sparse_index_run_resident(self._h, nq, k, stream))
+
+    def close(self):
+        if self._h:
+            self._lib.vrag_sparse_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------- the store
+_FILTER_EQ = re.compile(r"""^\s*(?:metadata\[\s*["'](\w+)["']\s*\]|(\w+))\s*==\s*["']([^"']*)["']\s*$""")
+
+
+class GpuVectorStore(VectorStore):
+    """Exact GPU search store with BaseMilvusStore's behaviour (milvus_base.py:90-127,189-459).
+
+    dense = COSINE (rows and queries are L2-normalised here, so IP on the device equals cosine),
+    sparse = IP over shared terms.  Rows live on the host until the first query after an insert
+    ("flush"), then in HBM.  `filter` supports equality on one metadata key (the only form the
+    reference itself builds, index.py:735-739); anything else is rejected loudly.
+    """
+
+    enable_full_text = False
+
+    def __init__(self, dense_dim: Optional[int] = 384, sparse_vocab: Optional[int] = 30522, enable_dense: bool = True,
+                 enable_sparse: bool = True, dense_dtype: str = "bf16", device: int = 0):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.enable_dense, self.enable_sparse = enable_dense, enable_sparse
+        self.dense_dim, self.sparse_vocab, self.dense_dtype, self.device = dense_dim, sparse_vocab, dense_dtype, device
+        self._ids: List[str] = []
+        self._texts: List[str] = []
+        self._enh: List[str] = []
+        self._meta: List[Dict[str, Any]] = []
+        self._dense_rows: List[np.ndarray] = []
+        self._sparse_rows: List[Dict[int, float]] = []
+        self._alive: List[bool] = []
+        self._dense: Optional[DenseShard] = None
+        self._sparse: Optional[SparseShard] = None
+        self._dirty = False
+
+    # -------------------------------------------------------------- ingest
+    def add_vectors(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
+        if self.enable_dense and (dense_vectors is None or len(dense_vectors) == 0):
+            raise ValueError("Dense vectors required but not provided")          # milvus_base.py:101-104
+        if self.enable_sparse and (sparse_vectors is None or len(sparse_vectors) == 0):
+            raise ValueError("Sparse vectors required but not provided")
+        for i in range(len(ids)):
+            self._ids.append(ids[i])
+            self._texts.append(texts[i])
+            self._enh.append(enhanced_texts[i])
+            self._meta.append(dict(metadatas[i] or {}))
+            self._alive.append(True)
+            if self.enable_dense:
+                v = np.asarray(dense_vectors[i], dtype=np.float32)
+                n = float(np.sqrt((v * v).sum(dtype=np.float32)))
+                self._dense_rows.append(v / n if n > 0 else v)                  # COSINE == IP on unit rows
+            if self.enable_sparse:
+                self._sparse_rows.append({int(k): float(v) for k, v in sparse_vectors[i].items()})
+        self._dirty = True
+
+    def delete(self, ids: List[str]):
+        kill = set(ids)
+        for i, x in enumerate(self._ids):
+            if x in kill:
+                self._alive[i] = False
+
+    def _flush(self):
+        if not self._dirty:
+            return
+        n = len(self._ids)
+        if self.enable_dense:
+            if self._dense is not None:
+                self._dense.close()
+            self._dense = DenseShard(self.dense_dim, max(n, 1), self.dense_dtype, self.device)
+            if n:
+                self._dense.add(np.stack(self._dense_rows))
+        if self.enable_sparse:
+            if self._sparse is not None:
+                self._sparse.close()
+            self._sparse = SparseShard(self.sparse_vocab, *dicts_to_csr(self._sparse_rows), device=self.device) if n else None
+        self._dirty = False
+
+    # -------------------------------------------------------------- search
+    def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
+        alive = np.asarray(self._alive, dtype=bool)
+        if filter:
+            m = _FILTER_EQ.match(filter)
+            if not m:
+                raise ValueError(f"GpuVectorStore supports only `key == \"value\"` filters, got: {filter!r}")
+            key, val = (m.group(1) or m.group(2)), m.group(3)
+            alive = alive & np.asarray([str(md.get(key)) == val for md in self._meta], dtype=bool)
+        return None if alive.all() else alive
+
+    def _hit(self, row: int, score: float) -> dict:
+        return {"id": self._ids[row], "distance": float(score),
+                "entity": {"text": self._texts[row], "enhanced_text": self._enh[row], "metadata": dict(self._meta[row])}}
+
+    def _search(self, kind: str, query, limit: int, mask: Optional[np.ndarray]) -> List[dict]:
+        self._flush()
+        n = len(self._ids)
+        if n == 0:
+            return []
+        shard = self._dense if kind == "dense" else self._sparse
+        want = limit
+        while True:
+            k = min(64, want)
+            if kind == "dense":
+                q = np.asarray(query, dtype=np.float32)
+                nq = float(np.sqrt((q * q).sum(dtype=np.float32)))
+                scores, rows = shard.search((q / nq if nq > 0 else q)[None], k)
+            else:
+                scores, rows = shard.search([{int(t): float(v) for t, v in query.items()}], k)
+            hits = [(int(r), float(s)) for r, s in zip(rows[0], scores[0]) if r >= 0 and (mask is None or mask[r])]
+            if len(hits) >= limit or k >= min(64, n) or want >= 64:
+                return [self._hit(r, s) for r, s in hits[:limit]]
+            want = min(64, want * 4)  # filtered / deleted rows ate some slots: widen
+
+    def query(self, dense_query=None, sparse_query=None, text_query=None, top_k: int = 5, search_type: str = "hybrid",
+              filter: Optional[str] = None, search_params: Optional[Dict[str, Any]] = None,
+              hybrid_weights: Optional[Dict[str, float]] = None, rrf_k: int = 60) -> List[SearchResult]:
+        """milvus_base.py:189-313."""
+        if hybrid_weights is not None:
+            return self._hybrid_search_with_weights(dense_query, sparse_query, text_query, top_k, filter, hybrid_weights, rrf_k)
+        if not dense_query and not sparse_query:
+            return self._filter_only_query(filter, top_k)
+        mask = self._mask(filter)
+        if search_type == "dense" and dense_query:
+            hits = self._search("dense", dense_query, top_k, mask)
+        elif search_type == "sparse" and sparse_query:
+            hits = self._search("sparse", sparse_query, top_k, mask)
+        elif search_type == "hybrid" and dense_query and sparse_query:
+            try:
+                rbm = {"dense": self._search("dense", dense_query, top_k * 2, mask),
+                       "sparse": self._search("sparse", sparse_query, top_k * 2, mask)}
+                hits = merge_hybrid_results(rbm, top_k, {"dense": 0.5, "sparse": 0.5}, rrf_k=rrf_k)
+            except Exception as e:  # milvus_base.py:296-306
+                logger.warning("Hybrid search failed: %s, falling back to dense search", e)
+                hits = self._search("dense", dense_query, top_k, mask)
+        else:
+            raise ValueError(f"Invalid search configuration: type={search_type}, "
+                             f"dense={dense_query is not None}, sparse={sparse_query is not None}")
+        return convert_hits_to_results(hits)
+
+    def _filter_only_query(self, filter: Optional[str], limit: int) -> List[SearchResult]:
+        mask = self._mask(filter)
+        rows = [i for i in range(len(self._ids)) if mask is None or mask[i]][:limit]
+        return [SearchResult(id=self._ids[i], score=1.0, metadata=dict(self._meta[i]), text=self._texts[i],
+                             enhanced_text=self._enh[i]) for i in rows]
+
+    def _hybrid_search_with_weights(self, dense_query, sparse_query, text_query, top_k, filter, hybrid_weights, rrf_k):
+        """milvus_base.py:366-459."""
+        hybrid_weights = sanitize_hybrid_weights(hybrid_weights)
+        if "full_text" in hybrid_weights and not self.enable_full_text:
+            logger.warning("full_text not available on %s, removing from hybrid_weights", self.__class__.__name__)
+            hybrid_weights = {k: v for k, v in hybrid_weights.items() if k != "full_text"}
+        if not hybrid_weights:
+            raise ValueError("No valid search methods in hybrid_weights")
+        mask = self._mask(filter)
+        rbm: Dict[str, List[dict]] = {}
+        if "dense" in hybrid_weights and dense_query is not None:
+            rbm["dense"] = self._search("dense", dense_query, top_k * 2, mask)
+        if "sparse" in hybrid_weights and sparse_query is not None:
+            rbm["sparse"] = self._search("sparse", sparse_query, top_k * 2, mask)
+        if len(rbm) == 0:
+            logger.warning("Hybrid search: no valid methods executed after validation")
+            return []
+        if len(rbm) == 1:
+            return convert_hits_to_results(list(rbm.values())[0][:top_k])
+        return convert_hits_to_results(merge_hybrid_results(rbm, top_k, hybrid_weights, rrf_k))
+
+    def get_document(self, document_id: str):
+        return None

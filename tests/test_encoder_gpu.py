@@ -88,3 +88,27 @@ def test_qa_logits_within_1e3(tiny):
     for s, b, g in zip(seqs, bounds, got):
         ref = O.qa_sentence_logits(O.encoder_forward(cfg, w, s), b, Wc, bc)
         assert np.abs(g - ref).max() < 1e-3
+
+
+TINY256 = dict(vocab_size=512, hidden_size=256, num_hidden_layers=3, num_attention_heads=4,
+               intermediate_size=384, pad_token_id=0, cls_token_id=1, sep_token_id=2)
+
+
+def test_wide_tile_gemm_config(tiny):
+    """hidden 256 / intermediate 384: every GEMM N is a multiple of 256 -> the 256x256 8-wave tile."""
+    cfg = O.EncoderConfig(**TINY256)
+    w = O.random_weights(cfg, seed=11)
+    eng = _engine(cfg, w, max_tokens=4096, max_seqs=16, max_seq_len=512, max_ranges=64)
+    rng = np.random.default_rng(13)
+    seqs = _seqs(rng, [300, 64, 129, 5, 511], cfg.vocab_size)
+    for n_layers in (0, 1, 3):
+        eng.load_batch(seqs)
+        eng.run(n_layers=n_layers)
+        got = eng.read_hidden(final_norm=False)
+        o = 0
+        for s in seqs:
+            _, hs = O.encoder_forward(cfg, w, s, return_all=True)
+            err = np.abs(got[o:o + len(s)] - hs[n_layers]).max()
+            assert err < 2e-2, f"S={len(s)} layers={n_layers} max-abs {err}"
+            o += len(s)
+    eng.close()

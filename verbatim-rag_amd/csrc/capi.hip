@@ -60,7 +60,7 @@ struct Layer {
 };
 
 struct MicroBatch {
-  int row0, row1;  // row1 is a multiple of 128
+  int row0, row1;  // multiples of kRowPad (256): GEMM tiles never straddle micro-batches
   int blk0, blk1;
 };
 
@@ -469,7 +469,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   // ---- workspace
   int n_mb = 1;
   if (cfg->micro_batch_tokens > 0) n_mb = cfg->max_tokens / std::max(1, cfg->micro_batch_tokens) + 2;
-  e->cap_rows = (int)align_up((int64_t)cfg->max_tokens + (int64_t)kSeqAlign * cfg->max_seqs + 128LL * (n_mb + 1),
+  e->cap_rows = (int)align_up((int64_t)cfg->max_tokens + (int64_t)kSeqAlign * cfg->max_seqs + (int64_t)kRowPad * (n_mb + 1),
                               kRowPad);
   const size_t R = e->cap_rows;
   e->cap_blocks = cfg->max_tokens / 128 + cfg->max_seqs + 1;
@@ -629,7 +629,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     const int Ls = seq_lens[s];
     t = (int)align_up(t, kSeqAlign);
     if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
-      const int row1 = (int)align_up(t, 128);
+      const int row1 = (int)align_up(t, kRowPad);
       e->mbs.push_back({mb_row0, row1, mb_blk0, nblk});
       for (int r = t; r < row1; ++r) {
         e->h_ids[r] = c.pad_token_id;
@@ -665,7 +665,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     t += Ls;
     mb_tokens += Ls;
   }
-  const int rows = (int)align_up(t, 128);
+  const int rows = (int)align_up(t, kRowPad);
   if (rows > e->cap_rows || nblk > e->cap_blocks) {
     set_error("internal: packed layout (%d rows, %d blocks) exceeds the workspace (%d rows, %d blocks)", rows, nblk,
               e->cap_rows, e->cap_blocks);

@@ -4,8 +4,12 @@
 // (transformers modeling_modernbert.py: Wqkv :271, attn Wo :300, mlp Wi :90, mlp Wo :91,
 //  prediction-head dense :487, MLM decoder :550, token classifier :697).
 //
-// Tile: 128(M) x 128(N) x 64(K) per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
-// v_mfma_f32_32x32x16_bf16).  Operands go HBM -> LDS by 16-byte LDS-DMA (global_load_lds),
+// Two tile configurations of one template (v_mfma_f32_32x32x16_bf16, BK = 64):
+//   256(M) x 256(N): 512 threads = 8 waves as 2(M) x 4(N), 128x64 per wave (128 accumulator VGPRs),
+//                    128 KiB LDS (2 stages x (32 KiB A + 32 KiB W)), 1 workgroup / CU  -- used when N % 256 == 0
+//   128(M) x 128(N): 256 threads = 4 waves as 2x2, 64x64 per wave, 64 KiB LDS, 2 workgroups / CU
+// The larger tile halves the L2->LDS operand traffic per FLOP (M*N*K*2*(1/BM+1/BN) bytes), which is
+// the co-limiter of the small tile at these K (768/1152).  Operands go HBM -> LDS by 16-byte LDS-DMA (global_load_lds),
 // double buffered.  LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with
 // ((row>>1)&7) on the *source address* (LDS-DMA writes lane-linear) and on the ds_read_b128
 // address, which makes each 16-lane read group hit 16 distinct 16-byte slots of the 256-byte
@@ -21,20 +25,27 @@
 
 namespace vrag {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
-constexpr int SMEM_BYTES = 4 * TILE_BYTES;
+constexpr int BK = 64;
 
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+// BM x BN tile, WM x WN waves; every wave owns (BM/WM) x 64 outputs (MI = BM/WM/32 row tiles, 2 column tiles).
+template <int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+  static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
+  constexpr int NT = WM * WN * 64;            // threads
+  constexpr int MI = BM / WM / 32;            // 32-row accumulator tiles per wave
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = BM / 8 / (WM * WN); // LDS-DMA instructions per wave per stage (8 rows each)
+  constexpr int W_INSTR = BN / 8 / (WM * WN);
+  static_assert(A_INSTR * 8 * WM * WN == BM && W_INSTR * 8 * WM * WN == BN, "tile rows must split over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int hi = lane >> 5, l31 = lane & 31;
+  constexpr int WROWS = BM / WM;              // rows of the A tile owned by one wave
 
   // XCD-aware, bijective block remap: consecutive logical tiles (same A row panel, n fastest)
   // land on the same XCD so the panel is served from that XCD's L2.
@@ -51,13 +62,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 
-  // LDS-DMA staging: instruction i of this wave fills tile rows wave*32 + i*8 .. +8.
-  int soff[4];
+  // LDS-DMA staging: instruction i of this wave fills tile rows wave*8*INSTR + i*8 .. +8.
+  int soffA[A_INSTR], soffW[W_INSTR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int lc = (lane & 7) ^ ((row >> 1) & 7);
-    soff[i] = row * K + lc * 8;
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = wave * (8 * A_INSTR) + i * 8 + (lane >> 3);
+    soffA[i] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < W_INSTR; ++i) {
+    const int row = wave * (8 * W_INSTR) + i * 8 + (lane >> 3);
+    soffW[i] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
   }
   // fragment read offsets (bytes inside a 32-row sub-tile)
   const int sw = (lane >> 1) & 7;
@@ -66,21 +81,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   for (int s = 0; s < 4; ++s) fo[s] = l31 * 128 + ((((2 * s + hi) ^ sw)) << 4);
 
   auto stage = [&](int kt, int buf) {
-    char* sA = smem + buf * (2 * TILE_BYTES);
-    char* sW = sA + TILE_BYTES;
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sW = sA + A_BYTES;
     const int k0 = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(Ab + soff[i] + k0, sA + (wave * 32 + i * 8) * 128);
-      glds16(Wb + soff[i] + k0, sW + (wave * 32 + i * 8) * 128);
-    }
+    for (int i = 0; i < A_INSTR; ++i) glds16(Ab + soffA[i] + k0, sA + (wave * (8 * A_INSTR) + i * 8) * 128);
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) glds16(Wb + soffW[i] + k0, sW + (wave * (8 * W_INSTR) + i * 8) * 128);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][MI];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < MI; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
@@ -92,20 +106,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
-    const char* sA = smem + buf * (2 * TILE_BYTES) + (wm * 64) * 128;
-    const char* sW = smem + buf * (2 * TILE_BYTES) + TILE_BYTES + (wn * 64) * 128;
+    const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * 128;
+    const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * 128;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 af[2], wf[2];
+      bf16x8 af[MI], wf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
-        wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
-      }
+      for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -117,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
   if constexpr (EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_RESIDUAL) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * WROWS + mi * 32 + l31;
       float* row = p.out_f32 + (size_t)m * p.N;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -142,8 +155,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
   } else if constexpr (EPI == EPI_BF16) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * WROWS + mi * 32 + l31;
       bf16_t* row = p.out_bf16 + (size_t)m * p.N;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -166,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const int NO = p.N >> 1;
     const int f0 = (nw >> 6) * 32;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * WROWS + mi * 32 + l31;
       bf16_t* row = p.out_bf16 + (size_t)m * NO + f0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -186,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       bf16_t* dst = which == 0 ? p.q : p.k;
       const float scale = which == 0 ? p.q_scale : 1.0f;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WROWS + mi * 32 + l31;
         const int pos = p.pos[m];
         const float* cs = p.rope_cos + (size_t)pos * 32;
         const float* sn = p.rope_sin + (size_t)pos * 32;
@@ -212,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     } else {
       // V^T: row = head*64 + d, column = token (key-contiguous for the PV MFMA operand)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WROWS + mi * 32 + l31;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -225,28 +238,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
   } else if constexpr (EPI == EPI_SPLADE) {
     // max over the tokens of each sequence of log1p(relu(logit + bias)).
-    int sq[2];
+    int sq[MI];
+    bool same_l = true;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) sq[mi] = p.tok_seq[m0 + wm * 64 + mi * 32 + l31];
+    for (int mi = 0; mi < MI; ++mi) sq[mi] = p.tok_seq[m0 + wm * WROWS + mi * 32 + l31];
     const int s0 = uniform(sq[0]);
-    const bool same = __all(sq[0] == s0 && sq[1] == s0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) same_l = same_l && (sq[mi] == s0);
+    const bool same = __all(same_l);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = nw + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const float bias = p.bias ? p.bias[n] : 0.f;
-        float v0 = log1pf(fmaxf(acc[ni][0][r] + bias, 0.f));
-        float v1 = log1pf(fmaxf(acc[ni][1][r] + bias, 0.f));
+        float vv[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) vv[mi] = log1pf(fmaxf(acc[ni][mi][r] + bias, 0.f));
         if (same) {
           if (s0 < 0) continue;
-          float v = fmaxf(v0, v1);
+          float v = vv[0];
+#pragma unroll
+          for (int mi = 1; mi < MI; ++mi) v = fmaxf(v, vv[mi]);
 #pragma unroll
           for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
           if (l31 == 0 && v > 0.f) atomicMax(p.splade_rows + (size_t)s0 * p.N + n, f2u(v));
         } else {
-          if (sq[0] >= 0 && v0 > 0.f) atomicMax(p.splade_rows + (size_t)sq[0] * p.N + n, f2u(v0));
-          if (sq[1] >= 0 && v1 > 0.f) atomicMax(p.splade_rows + (size_t)sq[1] * p.N + n, f2u(v1));
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            if (sq[mi] >= 0 && vv[mi] > 0.f) atomicMax(p.splade_rows + (size_t)sq[mi] * p.N + n, f2u(vv[mi]));
         }
       }
   }
@@ -254,14 +274,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
 template <int EPI>
 hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
-  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(nbm * nbn), dim3(256), SMEM_BYTES, stream, p);
+  if (p.N % 256 == 0 && p.M >= 256) {
+    constexpr int BM = 256, BN = 256, SMEM = 2 * (BM + BN) * BK * 2;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4>), dim3(nbm * nbn), dim3(512), SMEM, stream, p);
+  } else {
+    constexpr int BM = 128, BN = 128, SMEM = 2 * (BM + BN) * BK * 2;
+    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2>), dim3(nbm * nbn), dim3(256), SMEM, stream, p);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
   if (p.M <= 0) return hipSuccess;
-  if (p.N % BN != 0 || p.K % BK != 0) return hipErrorInvalidValue;
+  if (p.N % 128 != 0 || p.K % BK != 0) return hipErrorInvalidValue;
   switch (epi) {
     case EPI_F32: return launch_t<EPI_F32>(p, stream);
     case EPI_BF16: return launch_t<EPI_BF16>(p, stream);

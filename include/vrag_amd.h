@@ -142,6 +142,9 @@ int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t
 #define VRAG_PROF_HEAD 8
 #define VRAG_PROF_COUNT 9
 int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
+/* Diagnostics (kernel tuning): average ms of one GEMM instantiation (epilogue id as in
+ * csrc/gemm_bf16.h, 7 = no epilogue) on synthetic [-1,1) operands. */
+int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t device, float* ms_out);
 int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/,
                               int64_t* launches /*[VRAG_PROF_COUNT]*/, int32_t reset);
 

@@ -906,6 +906,95 @@ int vrag_encoder_extract_qa(vrag_encoder* e, const int32_t* ids, const int32_t* 
   return vrag_encoder_read_qa_logits(e, logits, nullptr);
 }
 
+// Diagnostics: times `iters` launches of one GEMM instantiation on synthetic operands (HIP events).
+int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t device, float* ms_out) {
+  ARG_CHECK(ms_out && M > 0 && N % 128 == 0 && K % 64 == 0 && iters > 0, "bad arguments");
+  ARG_CHECK(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_RESIDUAL || epi == EPI_GEGLU || epi == EPI_QKV_ROPE ||
+                epi == EPI_F32_GELU || epi == EPI_NONE,
+            "unsupported epilogue for the diagnostic");
+  if (vrag_device_count() <= device) {
+    set_error("no HIP device %d visible", device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  const size_t Mp = (size_t)align_up(M, kRowPad);
+  void *A = nullptr, *W = nullptr, *outf = nullptr, *outb = nullptr, *q = nullptr, *kk = nullptr, *vt = nullptr;
+  float *cs = nullptr, *sn = nullptr;
+  int* pos = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {A, W, outf, outb, q, kk, vt, (void*)cs, (void*)sn, (void*)pos})
+      if (p) (void)hipFree(p);
+  };
+  hipError_t e = hipMalloc(&A, Mp * K * 2);
+  if (e == hipSuccess) e = hipMalloc(&W, (size_t)N * K * 2);
+  if (e == hipSuccess) e = hipMalloc(&outf, Mp * N * 4);
+  if (e == hipSuccess) e = hipMalloc(&outb, Mp * N * 2);
+  if (e == hipSuccess) e = hipMalloc(&q, Mp * N * 2);
+  if (e == hipSuccess) e = hipMalloc(&kk, Mp * N * 2);
+  if (e == hipSuccess) e = hipMalloc(&vt, Mp * N * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&cs, 512 * 32 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&sn, 512 * 32 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&pos, Mp * 4);
+  if (e != hipSuccess) {
+    cleanup();
+    set_error("debug gemm allocation failed: %s", hipGetErrorString(e));
+    return VRAG_ERR_HIP;
+  }
+  // pseudo-random bf16 operands in [-1, 1): 0x3f80 | 7 mantissa bits = [1,2), minus 1.5, times 2
+  {
+    std::vector<unsigned short> h(std::max(Mp * K, (size_t)N * K));
+    unsigned x = 12345u;
+    for (auto& v : h) {
+      x = x * 1664525u + 1013904223u;
+      const unsigned m = (x >> 9) & 0x7f, s = (x >> 31) << 15, ex = 0x3e80u + (((x >> 20) & 1) << 7);
+      v = (unsigned short)(s | ex | m);
+    }
+    (void)hipMemcpy(A, h.data(), Mp * K * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+  }
+  (void)hipMemset(outf, 0, Mp * N * 4);
+  (void)hipMemset(pos, 0, Mp * 4);
+  (void)hipMemset(cs, 0, 512 * 32 * 4);
+  (void)hipMemset(sn, 0, 512 * 32 * 4);
+  GemmParams g{};
+  g.A = (const bf16_t*)A;
+  g.W = (const bf16_t*)W;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.out_f32 = (float*)outf;
+  g.out_bf16 = (bf16_t*)outb;
+  g.q = (bf16_t*)q;
+  g.k = (bf16_t*)kk;
+  g.vt = (bf16_t*)vt;
+  g.vt_ld = (int)Mp;
+  g.rope_cos = cs;
+  g.rope_sin = sn;
+  g.pos = pos;
+  g.hidden = N / 3;
+  g.q_scale = 0.125f;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  hipError_t le = hipSuccess;
+  for (int i = 0; i < 3 && le == hipSuccess; ++i) le = launch_gemm((GemmEpi)epi, g, 0);
+  (void)hipEventRecord(a, 0);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_gemm((GemmEpi)epi, g, 0);
+  (void)hipEventRecord(b, 0);
+  hipError_t se = hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  cleanup();
+  if (le != hipSuccess || se != hipSuccess) {
+    set_error("debug gemm failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+    return VRAG_ERR_HIP;
+  }
+  *ms_out = ms / iters;
+  return VRAG_OK;
+}
+
 int vrag_encoder_set_profiling(vrag_encoder* e, int32_t enabled) {
   ARG_CHECK(e, "null encoder handle");
   std::lock_guard<std::recursive_mutex> lk(e->mu);

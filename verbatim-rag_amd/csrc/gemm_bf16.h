@@ -13,6 +13,7 @@ enum GemmEpi {
   EPI_GEGLU = 4,     // out_bf16[m][f] = bf16(gelu_erf(x1[f]) * x2[f])   (Wi rows pre-interleaved)
   EPI_QKV_ROPE = 5,  // RoPE(q,k) in fp32, q *= d^-1/2, write Q,K [T,nh,64] and V^T [nh,64,T]
   EPI_SPLADE = 6,    // rows[seq(m)][n] = max(rows, log1p(relu(acc+bias)))  via ordered-uint atomicMax
+  EPI_NONE = 7,      // diagnostics: main loop only (accumulators kept alive, nothing stored)
   EPI_COUNT
 };
 

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -77,6 +78,9 @@ struct vrag_encoder {
   vrag_encoder_config cfg{};
   std::recursive_mutex mu;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_streams[2] = {nullptr, nullptr};  // optional 2-way micro-batch concurrency
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int n_streams = 1;
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
 
@@ -259,11 +263,21 @@ int check_ready(vrag_encoder* e) {
   return VRAG_OK;
 }
 
-int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t st) {
+int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
   const auto& c = e->cfg;
   const int H = c.hidden_size, I = c.intermediate_size;
   const int Tp = e->cap_rows;
-  for (const MicroBatch& mb : e->mbs) {
+  // Micro-batches touch disjoint rows of every buffer, so with n_streams == 2 they are issued on two
+  // internal streams: the HBM-bound kernels of one (LayerNorm, epilogue tails) overlap the MFMA-bound
+  // GEMM main loops of the other.  Fork/join with events on the caller's stream.
+  const bool fork = e->n_streams > 1 && e->mbs.size() > 1;
+  if (fork) {
+    HIP_TRY(hipEventRecord(e->ev_fork, user_st));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(e->aux_streams[i], e->ev_fork, 0));
+  }
+  for (size_t mbi = 0; mbi < e->mbs.size(); ++mbi) {
+    const MicroBatch& mb = e->mbs[mbi];
+    hipStream_t st = fork ? e->aux_streams[mbi & 1] : user_st;
     const int r0 = mb.row0, M = mb.row1 - mb.row0;
     {
       ProfScope ps(e, VRAG_PROF_EMBED, st);
@@ -354,6 +368,12 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t st) {
       }
     }
   }
+  if (fork) {
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipEventRecord(e->ev_join[i], e->aux_streams[i]));
+      HIP_TRY(hipStreamWaitEvent(user_st, e->ev_join[i], 0));
+    }
+  }
   e->ran = true;
   return VRAG_OK;
 }
@@ -435,6 +455,18 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
       set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
+      return fail(VRAG_ERR_HIP);
+    }
+  }
+
+  if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = atoi(ns) >= 2 ? 2 : 1;
+  if (e->n_streams > 1) {
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
+    if (he != hipSuccess) {
+      set_error("aux stream creation failed: %s", hipGetErrorString(he));
       return fail(VRAG_ERR_HIP);
     }
   }
@@ -530,6 +562,11 @@ void vrag_encoder_destroy(vrag_encoder* e) {
   for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
   for (void* p : e->dev_allocs) (void)hipFree(p);
   for (void* p : e->host_allocs) (void)hipHostFree(p);
+  for (int i = 0; i < 2; ++i) {
+    if (e->aux_streams[i]) (void)hipStreamDestroy(e->aux_streams[i]);
+    if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+  }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }

@@ -37,6 +37,10 @@ struct GemmParams {
   // EPI_SPLADE
   const int* tok_seq;  // [Mpad] sequence index of each token, -1 for padding tokens
   unsigned* splade_rows;  // [n_seqs, N] float bits (values >= 0 so uint order == float order)
+  // first-wave start stagger (de-synchronises the HBM-heavy epilogues of co-running workgroups)
+  int stagger_sleeps;     // max delay in units of s_sleep(127) (~8k cycles); 0 = off
+  int stagger_blocks;     // only workgroups with blockIdx < this are delayed
+  int stagger_groups;     // XCD phase groups (1, 2, 4 or 8)
 };
 
 // Launches on `stream`. Requirements: N % 128 == 0, K % 64 == 0.

@@ -105,7 +105,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chunks", type=int, default=256, help="sequences per step per GPU")
-    ap.add_argument("--micro-batch-tokens", type=int, default=int(os.environ.get("VRAG_MICRO_BATCH", "0")))
+    ap.add_argument("--micro-batch-tokens", type=int, default=int(os.environ.get("VRAG_MICRO_BATCH", "32768")))
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()

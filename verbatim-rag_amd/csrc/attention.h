@@ -5,13 +5,13 @@
 namespace vrag {
 
 struct AttnParams {
-  const bf16_t* q;   // [Tp, H]  RoPE'd and pre-scaled by head_dim^-1/2
+  const bf16_t* q;   // [Tp, H]  RoPE'd and pre-scaled by head_dim^-1/2 * log2(e)
   const bf16_t* k;   // [Tp, H]  RoPE'd
   const bf16_t* vt;  // [H, Tp]  V transposed (row = head*64+d, col = token)
   bf16_t* o;         // [Tp, H]
   const int* blk_seq_start;  // [n_blocks] first packed token of the q-block's sequence
   const int* blk_seq_len;    // [n_blocks] sequence length S
-  const int* blk_q0;         // [n_blocks] first query row of the block inside its sequence (x128)
+  const int* blk_q0;         // [n_blocks] first query row of the block inside its sequence (x attention_q_block())
   int n_blocks;
   int H;       // hidden = nh * 64
   int nh;
@@ -20,5 +20,6 @@ struct AttnParams {
 };
 
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream);
+int attention_q_block();  // query rows per work item (256)
 
 }  // namespace vrag

@@ -2,8 +2,11 @@
 // eager/SDPA attention inside ModernBertAttention.forward
 // (transformers modeling_modernbert.py:166-185,286-299; mask: masking_utils.py:141-151).
 //
-// Work item = (sequence, 128-row query block, head); 4 waves x 32 query rows.
-// Per 64-key step:
+// Work item = (sequence, 256-row query block, head); 4 waves x 64 query rows (two 32-row
+// sub-tiles per wave that SHARE every K / V^T fragment read from LDS).  64-key tiles stream
+// through a 3-slot LDS ring by 16-byte LDS-DMA (global_load_lds), two tiles in flight, one raw
+// s_barrier per tile and a counted s_waitcnt vmcnt (never a full drain in steady state).
+// Per tile and sub-tile:
 //   S^T[key][q] = K . Q^T        v_mfma_f32_32x32x16_bf16, A = K tile (LDS), B = Q (registers)
 //     -> lane (q = lane&31) holds 16 keys of ITS query row per 32-key tile, so the softmax
 //        row max / sum are in-lane + one cross-half exchange (lane ^ 32).
@@ -11,18 +14,22 @@
 //        S^T accumulators (the accumulator row map IS the B-operand k-slot order once the
 //        V^T fragment is read with the same key permutation) -> no LDS round trip for P and
 //        the per-row rescale factor lives in the lane that owns the O^T column.
-// K tile rows are 128 B, 16-byte chunks XOR-swizzled by ((key>>1)&7) (ds_read_b128 conflict free);
-// V^T tile rows are 128 B, 8-byte chunks XOR-swizzled by ((d>>1)&15) (ds_read_b64 conflict free).
-// Softmax is fp32 (exp2 domain); P and the MFMA operands are bf16, accumulation fp32.
+// LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled on the DMA source address and on
+// the read address: K by ((key>>1)&7) (ds_read_b128 conflict free), V^T by ((d>>1)&7)
+// (ds_read_b64, 2-way).  Softmax is fp32 (exp2 domain); P and the MFMA operands are bf16.
+// Banded layers (|i-j| <= window) visit only the key tiles inside the block's band and each
+// wave skips tiles outside its own 64 rows' band.
 #include "attention.h"
 
 namespace vrag {
 
+constexpr int ATT_QB = 256;      // query rows per workgroup
+constexpr int ATT_TILE = 16384;  // bytes per LDS ring slot (K 8 KiB + V^T 8 KiB)
+constexpr int ATT_SLOTS = 3;
+
 template <bool LOCAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[16384];
-  char* sK = smem;
-  char* sV = smem + 8192;
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[ATT_SLOTS * ATT_TILE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -34,161 +41,184 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int t0 = p.blk_seq_start[blk];
   const int S = p.blk_seq_len[blk];
   const int qb0 = p.blk_q0[blk];
-  const int qw0 = qb0 + wave * 32;  // first query row of this wave (inside the sequence)
-  const int qi = qw0 + l31;
+  const int qw0 = qb0 + wave * 64;  // first query row of this wave (inside the sequence)
   const int W = p.window;
 
-  // Q fragments (B operand): k-slot (8*hi + j) of step s <-> d = 16*s + 8*hi + j
-  bf16x8 qf[4];
-  {
-    const int row = min(t0 + qi, Tp - 1);
+  // Q fragments (B operand) for both sub-tiles: k-slot (8*hi + j) of step s <-> d = 16*s + 8*hi + j
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = min(t0 + qw0 + u * 32 + l31, Tp - 1);
     const bf16_t* qrow = p.q + (size_t)row * H + head * 64 + 8 * hi;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
   }
 
   int kb_lo = 0, kb_hi = (S - 1) >> 6;
   if constexpr (LOCAL) {
     kb_lo = max(0, qb0 - W) >> 6;
-    kb_hi = min(S - 1, qb0 + 127 + W) >> 6;
+    kb_hi = min(S - 1, qb0 + ATT_QB - 1 + W) >> 6;
   }
 
-  // staging roles
-  const int srow = tid >> 2;        // K: key row 0..63 ; V^T: d row 0..63
-  const int spiece = (tid & 3) * 2; // two 16-byte pieces per thread
-  const int ksw = (srow >> 1) & 7;
-  const int vsw = (srow >> 1) & 15;
-
-  f32x4 kreg[2], vreg[2];  // raw 16-byte payloads in flight
-  auto load_tile = [&](int kb) {
-    const int krow = min(t0 + kb * 64 + srow, Tp - 1);
-    const bf16_t* ksrc = p.k + (size_t)krow * H + head * 64;
-    const bf16_t* vsrc = p.vt + (size_t)(head * 64 + srow) * Tp;
+  // LDS-DMA roles: instruction i (0,1) of this wave covers tile rows wave*16 + i*8 + (lane>>3)
+  const int drow0 = wave * 16 + (lane >> 3);
+  const int dchunk = lane & 7;
+  auto stage = [&](int kb) {
+    char* slot = smem + (kb % ATT_SLOTS) * ATT_TILE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      kreg[i] = *reinterpret_cast<const f32x4*>(ksrc + (spiece + i) * 8);
-      const int col = min(t0 + kb * 64 + (spiece + i) * 8, Tp - 8);
-      vreg[i] = *reinterpret_cast<const f32x4*>(vsrc + col);
-    }
-  };
-  auto write_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = spiece + i;
-      *reinterpret_cast<f32x4*>(sK + srow * 128 + ((c ^ ksw) << 4)) = kreg[i];
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      f32x2 lo, hi2;
-      lo[0] = vreg[i][0]; lo[1] = vreg[i][1];
-      hi2[0] = vreg[i][2]; hi2[1] = vreg[i][3];
-      *reinterpret_cast<f32x2*>(sV + srow * 128 + (((2 * c) ^ vsw) << 3)) = lo;
-      *reinterpret_cast<f32x2*>(sV + srow * 128 + (((2 * c + 1) ^ vsw) << 3)) = hi2;
+      const int row = drow0 + i * 8;  // K: key row, V^T: d row
+      const int lc = dchunk ^ ((row >> 1) & 7);
+      const int krow = min(t0 + kb * 64 + row, Tp - 1);
+      glds16(p.k + (size_t)krow * H + head * 64 + lc * 8, slot + (wave * 16 + i * 8) * 128);
+      const int col = min(t0 + kb * 64 + lc * 8, Tp - 8);
+      glds16(p.vt + (size_t)(head * 64 + row) * Tp + col, slot + 8192 + (wave * 16 + i * 8) * 128);
     }
   };
 
-  f32x16 ot[2];
+  f32x16 ot[2][2];
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float LOG2E = 1.4426950408889634f;
-
-  const int fsw = (l31 >> 1) & 7;   // K fragment swizzle
-  const int vfs = (l31 >> 1) & 15;  // V^T fragment swizzle
-
-  load_tile(kb_lo);
-  for (int kb = kb_lo; kb <= kb_hi; ++kb) {
-    __syncthreads();  // everyone finished reading the previous tile
-    write_tile();
-    __syncthreads();
-    if (kb < kb_hi) load_tile(kb + 1);  // in flight during the MFMA work below
-
-    bool active = qw0 < S;
-    if constexpr (LOCAL) {
-      active = active && (kb * 64 + 63 >= qw0 - W) && (kb * 64 <= qw0 + 31 + W);
-    }
-    if (!active) continue;  // wave-uniform
-
-    // ---- S^T = K . Q^T
-    f32x16 st[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * 128 + (((2 * s + hi) ^ fsw) << 4));
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
-      }
-    }
-    // ---- mask + online softmax (exp2 domain)
-    float mx = -1e30f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kb * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        bool ok = kk < S;
-        if constexpr (LOCAL) ok = ok && (kk - qi <= W) && (qi - kk <= W);
-        const float x = ok ? st[t][r] * LOG2E : -INFINITY;
-        st[t][r] = x;
-        mx = fmaxf(mx, x);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(st[t][r] - m_new);
-        psum += pv;
-        pf[t][r >> 3][r & 7] = (bf16_t)pv;
-      }
-    l_run = l_run * alpha + psum;
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
+      for (int r = 0; r < 16; ++r) ot[u][n][r] = 0.f;
+  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+  const int fsw = (l31 >> 1) & 7;  // fragment swizzle (same for K rows and V^T rows)
 
-    // ---- O^T += V^T . P^T
+  stage(kb_lo);
+  if (kb_lo + 1 <= kb_hi) stage(kb_lo + 1);
+  for (int kb = kb_lo; kb <= kb_hi; ++kb) {
+    // tile kb landed (this wave's part); the next tile (4 DMA instructions) may stay in flight
+    if (kb < kb_hi) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kb + 2 <= kb_hi) stage(kb + 2);  // slot of tile kb-1: every wave finished it before the barrier
+
+    bool active = qw0 < S;
+    if constexpr (LOCAL) active = active && (kb * 64 + 63 >= qw0 - W) && (kb * 64 <= qw0 + 63 + W);
+    if (!active) continue;  // wave-uniform
+
+    const char* sK = smem + (kb % ATT_SLOTS) * ATT_TILE;
+    const char* sV = sK + 8192;
+
+    // ---- S^T = K . Q^T for both sub-tiles (K fragments read once)
+    f32x16 st[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[u][t][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * 128 + (((2 * s + hi) ^ fsw) << 4));
+        st[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], st[0][t], 0, 0, 0);
+        st[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], st[1][t], 0, 0, 0);
+      }
+
+    // ---- mask + online softmax (scores arrive in log2 units: q was pre-scaled by d^-1/2 * log2 e),
+    //      P -> bf16 B-operand fragments.  Interior tiles (every key valid and inside every row's
+    //      band) take the mask-free path: the VALU, not the MFMA, is the busier pipe at head_dim 64.
+    bf16x8 pf[2][2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q_lo = qw0 + u * 32;
+      bool need_mask = kb * 64 + 63 >= S;
+      if constexpr (LOCAL) need_mask = need_mask || (kb * 64 < q_lo + 31 - W) || (kb * 64 + 63 > q_lo + W);
+      float mx = -1e30f;
+      if (need_mask) {  // wave-uniform
+        const int qi = q_lo + l31;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kk = kb * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            bool ok = kk < S;
+            if constexpr (LOCAL) ok = ok && (kk - qi <= W) && (qi - kk <= W);
+            const float x = ok ? st[u][t][r] : -INFINITY;
+            st[u][t][r] = x;
+            mx = fmaxf(mx, x);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][t][r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx);
+      const bool grew = !__all(m_new == m_run[u]);  // wave-uniform
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[u][t][r] - m_new);
+          psum += pv;
+          pf[u][t][r >> 3][r & 7] = (bf16_t)pv;
+        }
+      if (grew) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+        m_run[u] = m_new;
+        l_run[u] = l_run[u] * alpha + psum;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[u][n][r] *= alpha;
+      } else {
+        l_run[u] += psum;
+      }
+    }
+
+    // ---- O^T += V^T . P^T (V^T fragments read once for both sub-tiles)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const int c8 = 8 * t + 4 * hf + hi;
+        const int c16 = 4 * t + 2 * hf;  // 16-byte chunk of keys t*32 + hf*16 .. ; +1 = the next 8 keys
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          const char* vrow = sV + (n * 32 + l31) * 128;
-          bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vrow + ((c8 ^ vfs) << 3));
-          bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vrow + (((c8 + 2) ^ vfs) << 3));
+          const char* vrow = sV + (n * 32 + l31) * 128 + (hi << 3);
+          const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vrow + ((c16 ^ fsw) << 4));
+          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vrow + (((c16 + 1) ^ fsw) << 4));
           bf16x8 vf;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { vf[j] = a0[j]; vf[4 + j] = a1[j]; }
-          ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][hf], ot[n], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = a0[j];
+            vf[4 + j] = a1[j];
+          }
+          ot[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][t][hf], ot[0][n], 0, 0, 0);
+          ot[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][t][hf], ot[1][n], 0, 0, 0);
         }
       }
   }
 
   // ---- normalise and store O[q][head*64 + d]
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (qi < S) {
-    const float inv = 1.0f / l_tot;
-    bf16_t* orow = p.o + (size_t)(t0 + qi) * H + head * 64;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+  for (int u = 0; u < 2; ++u) {
+    const int qi = qw0 + u * 32 + l31;
+    const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+    if (qi < S) {
+      const float inv = 1.0f / l_tot;
+      bf16_t* orow = p.o + (size_t)(t0 + qi) * H + head * 64;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(ot[n][4 * g + j] * inv);
-        *reinterpret_cast<bf16x4*>(orow + n * 32 + 8 * g + 4 * hi) = o;
-      }
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(ot[u][n][4 * g + j] * inv);
+          *reinterpret_cast<bf16x4*>(orow + n * 32 + 8 * g + 4 * hi) = o;
+        }
+    }
   }
 }
+
+int attention_q_block() { return ATT_QB; }
 
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream) {
   if (p.n_blocks <= 0) return hipSuccess;

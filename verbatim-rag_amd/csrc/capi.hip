@@ -307,7 +307,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.rope_sin = global ? e->sin_g : e->sin_l;
         g.pos = e->d_pos + r0;
         g.hidden = H;
-        g.q_scale = 0.125f;
+        g.q_scale = 0.125f * 1.4426950408889634f;  // head_dim^-1/2 * log2(e): attention softmax runs in exp2 units
         ProfScope ps(e, VRAG_PROF_GEMM_QKV, st);
         HIP_TRY(launch_gemm(EPI_QKV_ROPE, g, st));
       }
@@ -459,6 +459,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     }
   }
 
+  e->n_streams = 2;  // micro-batches alternate between two internal streams (VRAG_STREAMS=1 disables)
   if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = atoi(ns) >= 2 ? 2 : 1;
   if (e->n_streams > 1) {
     hipError_t he = hipSuccess;
@@ -692,7 +693,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
       e->h_pos[t + i] = i;
       e->h_tokseq[t + i] = s;
     }
-    for (int q0 = 0; q0 < Ls; q0 += 128) {
+    for (int q0 = 0; q0 < Ls; q0 += attention_q_block()) {
       e->h_blk_start[nblk] = t;
       e->h_blk_len[nblk] = Ls;
       e->h_blk_q0[nblk] = q0;

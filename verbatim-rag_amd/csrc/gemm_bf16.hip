@@ -177,7 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       for (int g = 0; g < 4; ++g) {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(gelu_erf(acc[0][mi][4 * g + j]) * acc[1][mi][4 * g + j]);
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(gelu_fast(acc[0][mi][4 * g + j]) * acc[1][mi][4 * g + j]);
         put_bf16(mi * 32 + l31, 8 * g + 4 * hi, o, 64);
       }
 #pragma unroll
@@ -544,6 +544,86 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p)
   gemm_epilogue<EPI, MI, WROWS>(p, acc, smem, wave, lane, mw, nw, n0, v_block);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Experimental (tuning probe, EPI_NONE only): 256x256 tile, FOUR waves as 2x2, 128x128 per wave
+// (256 accumulator registers -> AGPRs, one wave per SIMD): 16 KiB of LDS fragment reads per 32 MFMAs
+// instead of 12 KiB per 16.
+__global__ __launch_bounds__(256) void gemm_bf16_big_probe_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, MI = 4, NI = 4;
+  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int nbn = p.N / BN, nblk = gridDim.x;
+  int b = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN, K = p.K;
+  const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
+  const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
+  int soff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wave * 64 + i * 8 + (lane >> 3);
+    soff[i] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+  const int sw = (lane >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) fo[s] = l31 * 128 + ((((2 * s + hi) ^ sw)) << 4);
+  auto stage = [&](int kt, int buf) {
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sW = sA + A_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16(Ab + soff[i] + k0, sA + (wave * 64 + i * 8) * 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) glds16(Wb + soff[i] + k0, sW + (wave * 64 + i * 8) * 128);
+  };
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int c = 0; c < MI; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  const int KT = K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+    const char* sA = smem + buf * STAGE_BYTES + (wm * 128) * 128;
+    const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 128) * 128;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[ni][mi][r]));
+}
+
 template <int EPI>
 hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
@@ -563,7 +643,19 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
     p.stagger_blocks = 256;   // 1 workgroup per CU
-    static const bool noring = getenv("VRAG_GEMM_NORING") != nullptr;  // tuning knob
+    static const bool bigprobe = getenv("VRAG_GEMM_BIGPROBE") != nullptr;  // tuning probe
+    if (bigprobe && EPI == EPI_NONE) {
+      static bool attr3 = false;
+      if (!attr3) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_probe_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr3 = true;
+      }
+      hipLaunchKernelGGL(gemm_bf16_big_probe_kernel, dim3(nbm * nbn), dim3(256), SMEM, stream, p);
+      return hipGetLastError();
+    }
+    static const bool noring = getenv("VRAG_GEMM_RING") == nullptr;  // ring variant is opt-in (measured ~3% slower)
     if (!noring && p.K % 32 == 0) {
       static bool attr2 = false;
       if (!attr2) {

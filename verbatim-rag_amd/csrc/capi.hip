@@ -33,17 +33,49 @@ static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * 
 
 // ---------------------------------------------------------------- weight packing kernels
 __global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows_dst,
-                                     int rows_src, int cols, int interleave_I) {
-  // dst row r <- src row perm(r); rows beyond rows_src are zero. interleave_I > 0 applies the
-  // GeGLU interleave: each 64-row group = 32 input rows (x1) then the 32 matching gate rows (x2).
+                                     int rows_src, int cols, int interleave_I,
+                                     const float* __restrict__ col_scale, float* __restrict__ row_sum) {
+  // dst row r <- src row perm(r) (* col_scale per input column: a LayerNorm gain folded into the
+  // weight); rows beyond rows_src are zero.  interleave_I > 0 applies the GeGLU interleave: each
+  // 64-row group = 32 input rows (x1) then the 32 matching gate rows (x2).  row_sum[r] = sum over
+  // the bf16-ROUNDED row (what the MFMA will actually multiply), fp32.
+  __shared__ float red[4];
   const int r = blockIdx.x;
   int s = r;
   if (interleave_I > 0) {
     const int g = r >> 6, w = r & 63;
     s = w < 32 ? g * 32 + w : interleave_I + g * 32 + (w - 32);
   }
-  for (int c = threadIdx.x; c < cols; c += blockDim.x)
-    dst[(size_t)r * cols + c] = (r < rows_dst && s < rows_src) ? (bf16_t)src[(size_t)s * cols + c] : (bf16_t)0.f;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float v = (r < rows_dst && s < rows_src) ? src[(size_t)s * cols + c] : 0.f;
+    if (col_scale) v *= col_scale[c];
+    const bf16_t b = (bf16_t)v;
+    dst[(size_t)r * cols + c] = b;
+    acc += (float)b;
+  }
+  if (row_sum) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) row_sum[r] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// (mu, rstd) per token row from the per-segment partial sums left by the residual GEMM epilogue.
+__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np, int H, float eps, int rows,
+                                         float* __restrict__ mu, float* __restrict__ rstd) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < np; ++i) {  // fixed order: deterministic
+    s1 += part[((size_t)r * np + i) * 2];
+    s2 += part[((size_t)r * np + i) * 2 + 1];
+  }
+  const float m = s1 / (float)H;
+  const float var = fmaxf(s2 / (float)H - m * m, 0.f);
+  mu[r] = m;
+  rstd[r] = 1.0f / sqrtf(var + eps);
 }
 
 struct DevBuf {
@@ -58,6 +90,9 @@ struct Layer {
   float* mlp_norm = nullptr;
   bf16_t* wi = nullptr;  // interleaved rows
   bf16_t* wo_mlp = nullptr;
+  // LayerNorm gains are folded into wqkv (attn_norm, layers > 0) and wi (mlp_norm); s_* = row sums
+  float* s_qkv = nullptr;
+  float* s_wi = nullptr;
 };
 
 struct MicroBatch {
@@ -81,6 +116,7 @@ struct vrag_encoder {
   hipStream_t aux_streams[2] = {nullptr, nullptr};  // optional 2-way micro-batch concurrency
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   int n_streams = 1;
+  bool ln_fold = false;  // LayerNorm folded into the consumer GEMM epilogues (VRAG_LN_FOLD=1; measured 3% slower)
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
 
@@ -106,6 +142,7 @@ struct vrag_encoder {
   float* h = nullptr;
   bf16_t *a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr, *act = nullptr;
   float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
+  float *st_part = nullptr, *ln_mu = nullptr, *ln_rstd = nullptr;  // folded-LayerNorm row statistics
   int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;
   int cap_blocks = 0;
   int *d_rng_start = nullptr, *d_rng_end = nullptr;
@@ -182,16 +219,22 @@ int upload_f32(vrag_encoder* e, float** out, const float* src, size_t count) {
 
 // fp32 host matrix [rows_src, cols] -> bf16 device matrix [rows_dst, cols] (zero padded rows).
 int upload_bf16(vrag_encoder* e, bf16_t** out, const float* src, int rows_src, int cols, int rows_dst,
-                int interleave_I, float* stage, size_t stage_elems) {
+                int interleave_I, float* stage, size_t stage_elems, const float* d_col_scale = nullptr,
+                float** row_sum_out = nullptr) {
   int rc = dev_alloc(e, out, (size_t)rows_dst * cols, false);
   if (rc) return rc;
+  float* d_row_sum = nullptr;
+  if (row_sum_out) {
+    if ((rc = dev_alloc(e, &d_row_sum, rows_dst, true))) return rc;
+    *row_sum_out = d_row_sum;
+  }
   // stream the fp32 source through the staging buffer in row chunks
   const int chunk_rows_max = (int)std::max<size_t>(1, stage_elems / cols);
-  if (interleave_I > 0 || rows_src <= chunk_rows_max) {
+  if (interleave_I > 0 || d_col_scale || row_sum_out || rows_src <= chunk_rows_max) {
     ARG_CHECK((size_t)rows_src * cols <= stage_elems, "internal: staging buffer too small");
     HIP_TRY(hipMemcpy(stage, src, (size_t)rows_src * cols * sizeof(float), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(rows_dst), dim3(256), 0, 0, stage, *out, rows_dst, rows_src, cols,
-                       interleave_I);
+                       interleave_I, d_col_scale, d_row_sum);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return VRAG_OK;
@@ -203,7 +246,7 @@ int upload_bf16(vrag_encoder* e, bf16_t** out, const float* src, int rows_src, i
       HIP_TRY(hipMemcpy(stage, src + (size_t)r0 * cols, (size_t)nr_src * cols * sizeof(float),
                         hipMemcpyHostToDevice));
     hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(nr_dst), dim3(256), 0, 0, stage, *out + (size_t)r0 * cols, nr_dst,
-                       nr_src, cols, 0);
+                       nr_src, cols, 0, (const float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }
@@ -287,15 +330,37 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
     for (int l = 0; l < n_layers; ++l) {
       const Layer& L = e->layers[l];
       const bool global = (l % c.global_every) == 0;
-      if (l > 0) {
+      // Default: LayerNorm is its own HBM-streaming kernel (it overlaps the other stream's GEMM main
+      // loops).  With ln_fold the residual GEMM epilogues leave bf16(h) in `a` plus per-row partial sums,
+      // a tiny kernel turns those into (mu, rstd) and the consumer GEMM (gain folded into its weight)
+      // normalises in its epilogue -- fewer bytes, but epilogue work is not overlapped (measured slower).
+      const bool fold = e->ln_fold;
+      auto layer_norm = [&](const float* gain) -> int {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, L.attn_norm, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr,
-                                 st));
+        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, gain, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st));
+        return VRAG_OK;
+      };
+      if (!fold && l > 0) {
+        int rc = layer_norm(L.attn_norm);
+        if (rc) return rc;
       }
+      auto finalize_stats = [&]() -> int {
+        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+        hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st,
+                           e->st_part + (size_t)r0 * (H / 64) * 2, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
+                           e->ln_rstd + r0);
+        HIP_TRY(hipGetLastError());
+        return VRAG_OK;
+      };
       {
         GemmParams g{};
         g.A = e->a + (size_t)r0 * H;
         g.W = L.wqkv;
+        if (fold && l > 0) {  // layer 0 consumes the embedding LayerNorm output directly (no attn_norm)
+          g.ln_mu = e->ln_mu + r0;
+          g.ln_rstd = e->ln_rstd + r0;
+          g.ln_s = L.s_qkv;
+        }
         g.M = M;
         g.N = 3 * H;
         g.K = H;
@@ -336,18 +401,26 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.N = H;
         g.K = H;
         g.out_f32 = e->h + (size_t)r0 * H;
+        if (fold) {
+          g.resid_bf16 = e->a + (size_t)r0 * H;
+          g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+        }
         ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
       {
-        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, L.mlp_norm, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr,
-                                 st));
+        int rc = fold ? finalize_stats() : layer_norm(L.mlp_norm);
+        if (rc) return rc;
       }
       {
         GemmParams g{};
         g.A = e->a + (size_t)r0 * H;
         g.W = L.wi;
+        if (fold) {
+          g.ln_mu = e->ln_mu + r0;
+          g.ln_rstd = e->ln_rstd + r0;
+          g.ln_s = L.s_wi;
+        }
         g.M = M;
         g.N = 2 * I;
         g.K = H;
@@ -363,8 +436,16 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.N = H;
         g.K = I;
         g.out_f32 = e->h + (size_t)r0 * H;
+        if (fold && l + 1 < c.num_layers) {  // the next layer's attn_norm is folded into its QKV GEMM
+          g.resid_bf16 = e->a + (size_t)r0 * H;
+          g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+        }
         ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+      }
+      if (fold && l + 1 < c.num_layers) {
+        int rc = finalize_stats();
+        if (rc) return rc;
       }
     }
   }
@@ -472,6 +553,8 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     }
   }
 
+  if (const char* lf = getenv("VRAG_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
+
   // ---- weights
   const size_t stage_elems = std::max<size_t>({(size_t)3 * H * H, (size_t)2 * I * H, (size_t)1 << 22});
   float* stage = nullptr;
@@ -484,9 +567,13 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     Layer& ly = e->layers[l];
     if (l > 0) TRY(upload_f32(e, &ly.attn_norm, w->attn_norm[l], H));
     TRY(upload_f32(e, &ly.mlp_norm, w->mlp_norm[l], H));
-    TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems));
+    // LayerNorm folded into the consumer GEMMs: W' = W * gain, s = row sums of bf16(W')
+    const bool fold = e->ln_fold;
+    TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems,
+                    fold && l > 0 ? ly.attn_norm : nullptr, fold && l > 0 ? &ly.s_qkv : nullptr));
     TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
-    TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * I, I, stage, stage_elems));
+    TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * I, I, stage, stage_elems, fold ? ly.mlp_norm : nullptr,
+                    fold ? &ly.s_wi : nullptr));
     TRY(upload_bf16(e, &ly.wo_mlp, w->wo_mlp[l], H, I, H, 0, stage, stage_elems));
   }
   {
@@ -517,6 +604,9 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   TRY(dev_alloc(e, &e->o, R * H));
   TRY(dev_alloc(e, &e->act, R * I));
   TRY(dev_alloc(e, &e->f32tmp, R * H));
+  TRY(dev_alloc(e, &e->st_part, R * (H / 64) * 2));
+  TRY(dev_alloc(e, &e->ln_mu, R));
+  TRY(dev_alloc(e, &e->ln_rstd, R));
   TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
@@ -622,7 +712,8 @@ int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float
   } else {
     // tied decoder: convert the device-resident fp32 embedding table
     if ((rc = dev_alloc(e, &e->mlm_dec, (size_t)vpad * H, false))) return rc;
-    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(vpad), dim3(256), 0, 0, e->tok_emb, e->mlm_dec, vpad, V, H, 0);
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(vpad), dim3(256), 0, 0, e->tok_emb, e->mlm_dec, vpad, V, H, 0,
+                       (const float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }

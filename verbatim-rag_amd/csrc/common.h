@@ -57,6 +57,19 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + erf_x);
 }
 
+// Streaming (non-temporal) 16/8-byte accesses for data that is written once and consumed by a LATER
+// kernel (GEMM / attention outputs, the residual read-modify-write): keeps the XCD's 4 MiB L2 for
+// the operand panels that co-running tiles share.  Measured on the bf16-out GEMM: 594 -> 548 us.
+__device__ __forceinline__ void store16_nt(void* dst, const f32x4& v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+}
+__device__ __forceinline__ void store8_nt(void* dst, const bf16x4& v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(dst));
+}
+__device__ __forceinline__ f32x4 load16_nt(const void* src) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+}
+
 // 16-byte global -> LDS DMA. LDS destination = wave-uniform `lds` + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -37,6 +37,16 @@ struct GemmParams {
   // EPI_SPLADE
   const int* tok_seq;  // [Mpad] sequence index of each token, -1 for padding tokens
   unsigned* splade_rows;  // [n_seqs, N] float bits (values >= 0 so uint order == float order)
+  // LayerNorm folded into the GEMM (EPI_QKV_ROPE, EPI_GEGLU): A = bf16(h) (un-normalised residual),
+  // W' = W * ln_weight (per input column), ln_s[n] = sum_k W'[n][k]; the epilogue applies
+  //   out[m][n] = ln_rstd[m] * (acc[m][n] - ln_mu[m] * ln_s[n])  ==  (LayerNorm(h) . W^T)[m][n].
+  const float* ln_mu;     // [Mpad] row means of h (null = no fold)
+  const float* ln_rstd;   // [Mpad] 1/sqrt(var + eps)
+  const float* ln_s;      // [N]
+  // EPI_RESIDUAL extras: bf16 copy of the updated residual rows (the next GEMM's A operand) and the
+  // per-row partial sums (sum x, sum x^2) over each 64-column segment, for the next fold.
+  bf16_t* resid_bf16;     // [Mpad, N] or null
+  float* stats_part;      // [Mpad, N/64, 2] or null
   // first-wave start stagger (de-synchronises the HBM-heavy epilogues of co-running workgroups)
   int stagger_sleeps;     // max delay in units of s_sleep(127) (~8k cycles); 0 = off
   int stagger_blocks;     // only workgroups with blockIdx < this are delayed

@@ -72,7 +72,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = it * 4 + (lane >> 4), c16 = lane & 15;
-        hv[it] = *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)(mw + row) * p.N + nw + c16 * 4);
+        hv[it] = load16_nt(p.out_f32 + (size_t)(mw + row) * p.N + nw + c16 * 4);
       }
     }
 #pragma unroll
@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
           for (int it = 0; it < 16; ++it) {
             const int row = it * 4 + (lane >> 4), c16 = lane & 15;
-            hn[it] = *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)(mw + (ps + 1) * 64 + row) * p.N + nw + c16 * 4);
+            hn[it] = load16_nt(p.out_f32 + (size_t)(mw + (ps + 1) * 64 + row) * p.N + nw + c16 * 4);
           }
         }
       }
@@ -119,7 +119,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         } else if constexpr (EPI == EPI_F32) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);
         }
-        *reinterpret_cast<f32x4*>(dst) = v;
+        store16_nt(dst, v);
+        if constexpr (EPI == EPI_RESIDUAL) {
+          if (p.resid_bf16) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+            store8_nt(p.resid_bf16 + (size_t)(mw + ps * 64 + row) * p.N + nw + c16 * 4, o);
+          }
+          if (p.stats_part) {
+            // the 16 lanes of a row segment reduce (sum, sum of squares) of the UPDATED residual
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+              s1 += __shfl_xor(s1, o, 64);
+              s2 += __shfl_xor(s2, o, 64);
+            }
+            if (c16 == 0) {
+              float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
+              sp[0] = s1;
+              sp[1] = s2;
+            }
+          }
+        }
       }
       if constexpr (EPI == EPI_RESIDUAL) {
         if (ps + 1 < MI / 2) {
@@ -161,10 +184,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       }
     } else {
 #pragma unroll
-    for (int it = 0; it < MI * 4; ++it) {
-      const int row = it * 8 + (lane >> 3), c16 = lane & 7;
-      *reinterpret_cast<f32x4*>(p.out_bf16 + (size_t)(mw + row) * p.N + nw + c16 * 8) = get16(row, c16, 128);
-    }
+      for (int it = 0; it < MI * 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+        store16_nt(p.out_bf16 + (size_t)(mw + row) * p.N + nw + c16 * 8, get16(row, c16, 128));
+      }
     }
   } else if constexpr (EPI == EPI_GEGLU) {
     // Wi rows were interleaved at load time: each 64-row group = 32 "input" rows (x1)
@@ -172,18 +195,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const int NO = p.N >> 1;
     const int f0 = (nw >> 6) * 32;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+      float mu = 0.f, rs = 1.f;
+      if (p.ln_mu) {
+        mu = p.ln_mu[mw + mi * 32 + l31];
+        rs = p.ln_rstd[mw + mi * 32 + l31];
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_mu) {
+          s1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 8 * g + 4 * hi);
+          s2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + 8 * g + 4 * hi);
+        }
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(gelu_fast(acc[0][mi][4 * g + j]) * acc[1][mi][4 * g + j]);
+        for (int j = 0; j < 4; ++j) {
+          const float x1 = rs * (acc[0][mi][4 * g + j] - mu * s1[j]);
+          const float x2 = rs * (acc[1][mi][4 * g + j] - mu * s2[j]);
+          o[j] = (bf16_t)(gelu_fast(x1) * x2);
+        }
         put_bf16(mi * 32 + l31, 8 * g + 4 * hi, o, 64);
       }
+    }
 #pragma unroll
     for (int it = 0; it < MI * 2; ++it) {
       const int row = it * 16 + (lane >> 2), c16 = lane & 3;
-      *reinterpret_cast<f32x4*>(p.out_bf16 + (size_t)(mw + row) * NO + f0 + c16 * 8) = get16(row, c16, 64);
+      store16_nt(p.out_bf16 + (size_t)(mw + row) * NO + f0 + c16 * 8, get16(row, c16, 64));
     }
   } else if constexpr (EPI == EPI_QKV_ROPE) {
     const int H = p.hidden;
@@ -197,15 +235,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const int pos = p.pos[mw + mi * 32 + l31];
         const float* cs = p.rope_cos + (size_t)pos * 32;
         const float* sn = p.rope_sin + (size_t)pos * 32;
+        float mu = 0.f, rs = 1.f;
+        if (p.ln_mu) {
+          mu = p.ln_mu[mw + mi * 32 + l31];
+          rs = p.ln_rstd[mw + mi * 32 + l31];
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int dd = 8 * g + 4 * hi;
           const f32x4 c = *reinterpret_cast<const f32x4*>(cs + dd);
           const f32x4 sv = *reinterpret_cast<const f32x4*>(sn + dd);
+          f32x4 ls1 = {0.f, 0.f, 0.f, 0.f}, ls2 = {0.f, 0.f, 0.f, 0.f};
+          if (p.ln_mu) {
+            ls1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + dd);
+            ls2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + dd);
+          }
           bf16x4 o1, o2;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float x1 = acc[0][mi][4 * g + j], x2 = acc[1][mi][4 * g + j];
+            const float x1 = rs * (acc[0][mi][4 * g + j] - mu * ls1[j]);
+            const float x2 = rs * (acc[1][mi][4 * g + j] - mu * ls2[j]);
             // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
             o1[j] = (bf16_t)((x1 * c[j] - x2 * sv[j]) * scale);
             o2[j] = (bf16_t)((x2 * c[j] + x1 * sv[j]) * scale);
@@ -217,29 +266,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int it = 0; it < MI * 4; ++it) {
         const int row = it * 8 + (lane >> 3), c16 = lane & 7;
-        *reinterpret_cast<f32x4*>(dst + (size_t)(mw + row) * H + head * 64 + c16 * 8) = get16(row, c16, 128);
+        store16_nt(dst + (size_t)(mw + row) * H + head * 64 + c16 * 8, get16(row, c16, 128));
       }
     } else {
       // un-swapped accumulators: lane = feature d (ni*32 + l31), registers = tokens
       //   token = mi*32 + 8*(r>>2) + 4*hi + (r&3).   Stage V^T tile [64 d][WROWS tokens].
       constexpr int RB = WROWS * 2;  // row bytes (256 for 128 tokens, 128 for 64)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni) {
+        const float sn_ = p.ln_mu ? p.ln_s[nw + ni * 32 + l31] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+            f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
+            if (p.ln_mu) {
+              mu4 = *reinterpret_cast<const f32x4*>(p.ln_mu + mw + mi * 32 + 8 * g + 4 * hi);
+              rs4 = *reinterpret_cast<const f32x4*>(p.ln_rstd + mw + mi * 32 + 8 * g + 4 * hi);
+            }
             bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)acc[ni][mi][4 * g + j];
+            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(rs4[j] * (acc[ni][mi][4 * g + j] - mu4[j] * sn_));
             put_bf16(ni * 32 + l31, mi * 32 + 8 * g + 4 * hi, o, RB);
           }
+      }
       constexpr int LPR = RB / 16;        // lanes per row
       constexpr int RPI = 64 / LPR;       // rows per instruction
 #pragma unroll
       for (int it = 0; it < 64 / RPI; ++it) {
         const int row = it * RPI + lane / LPR, c16 = lane % LPR;
-        *reinterpret_cast<f32x4*>(p.vt + (size_t)(head * 64 + row) * p.vt_ld + mw + c16 * 8) = get16(row, c16, RB);
+        store16_nt(p.vt + (size_t)(head * 64 + row) * p.vt_ld + mw + c16 * 8, get16(row, c16, RB));
       }
     }
   } else if constexpr (EPI == EPI_SPLADE) {

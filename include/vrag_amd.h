@@ -141,6 +141,9 @@ int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t
 #define VRAG_PROF_GEMM_WO_MLP 7
 #define VRAG_PROF_HEAD 8
 #define VRAG_PROF_COUNT 9
+/* Micro-batches (cfg.micro_batch_tokens) are issued on 2 internal streams by default so that the
+ * HBM-bound kernels of one overlap the MFMA-bound kernels of the other; 1 serialises them. */
+int vrag_encoder_set_concurrency(vrag_encoder* enc, int32_t n_streams);
 int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
 /* Diagnostics (kernel tuning): average ms of one GEMM instantiation (epilogue id as in
  * csrc/gemm_bf16.h, 7 = no epilogue) on synthetic [-1,1) operands. */

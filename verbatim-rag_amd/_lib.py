@@ -74,6 +74,7 @@ SIGNATURES = {
     "vrag_encoder_read_splade": (C.c_int, [_H, _FP, C.c_void_p]),
     "vrag_encoder_read_hidden": (C.c_int, [_H, C.c_int32, _FP, C.c_void_p]),
     "vrag_encoder_extract_qa": (C.c_int, [_H, _IP, _IP, C.c_int32, _IP, _IP, _IP, C.c_int32, _FP]),
+    "vrag_encoder_set_concurrency": (C.c_int, [_H, C.c_int32]),
     "vrag_encoder_set_profiling": (C.c_int, [_H, C.c_int32]),
     "vrag_encoder_read_profile": (C.c_int, [_H, _FP, _LP, C.c_int32]),
     "vrag_debug_gemm_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),

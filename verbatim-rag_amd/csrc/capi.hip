@@ -542,7 +542,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
 
   e->n_streams = 2;  // micro-batches alternate between two internal streams (VRAG_STREAMS=1 disables)
   if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = atoi(ns) >= 2 ? 2 : 1;
-  if (e->n_streams > 1) {
+  {
     hipError_t he = hipSuccess;
     for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
@@ -1121,6 +1121,13 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
     return VRAG_ERR_HIP;
   }
   *ms_out = ms / iters;
+  return VRAG_OK;
+}
+
+int vrag_encoder_set_concurrency(vrag_encoder* e, int32_t n_streams) {
+  ARG_CHECK(e && (n_streams == 1 || n_streams == 2), "n_streams must be 1 or 2");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  e->n_streams = n_streams;
   return VRAG_OK;
 }
 

@@ -275,6 +275,9 @@ class EncoderEngine:
         return res
 
     # ------------------------------------------------------------------ profiling
+    def set_concurrency(self, n_streams: int) -> None:
+        _lib.check("vrag_encoder_set_concurrency", self._lib.vrag_encoder_set_concurrency(self._h, int(n_streams)))
+
     def set_profiling(self, enabled: bool) -> None:
         _lib.check("vrag_encoder_set_profiling", self._lib.vrag_encoder_set_profiling(self._h, int(enabled)))
 

@@ -112,3 +112,41 @@ def test_wide_tile_gemm_config(tiny):
             assert err < 2e-2, f"S={len(s)} layers={n_layers} max-abs {err}"
             o += len(s)
     eng.close()
+
+
+def test_large_shapes_two_layers():
+    """ModernBERT-large geometry (H=1024, I=2624: N=5248 is not a multiple of 256 -> 128x128 tiles;
+    K=2624 = 41 x 64), 2 layers, random weights, vs the oracle."""
+    cfg = O.EncoderConfig(vocab_size=1024, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
+                          intermediate_size=2624, pad_token_id=0, cls_token_id=1, sep_token_id=2)
+    w = O.random_weights(cfg, seed=21)
+    eng = _engine(cfg, w, max_tokens=2048, max_seqs=8, max_seq_len=512, max_ranges=16)
+    rng = np.random.default_rng(22)
+    seqs = _seqs(rng, [300, 257, 31], cfg.vocab_size)
+    eng.load_batch(seqs)
+    eng.run()
+    got = eng.read_hidden(final_norm=True)
+    eng.close()
+    o = 0
+    for s in seqs:
+        ref = O.encoder_forward(cfg, w, s)
+        assert np.abs(got[o:o + len(s)] - ref).max() < 3e-2
+        o += len(s)
+
+
+def test_long_sequence_global_and_banded_attention():
+    """S = 1500 > 512: many key tiles on global layers, interior/edge tiles on banded layers."""
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=7)
+    eng = _engine(cfg, w, max_tokens=4096, max_seqs=4, max_seq_len=2048, max_ranges=16)
+    rng = np.random.default_rng(31)
+    seqs = _seqs(rng, [1500, 700], cfg.vocab_size)
+    eng.load_batch(seqs)
+    eng.run()
+    got = eng.read_hidden(final_norm=True)
+    eng.close()
+    o = 0
+    for s in seqs:
+        ref = O.encoder_forward(cfg, w, s)
+        assert np.abs(got[o:o + len(s)] - ref).max() < 3e-2
+        o += len(s)

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Top-k roofline probe (HBM-bound): dense bf16 rows and SELL-64 sparse rows, device-resident queries.
+Prints one JSON object per index kind: rows/s, algorithmic GB/s, fraction of the 8 TB/s HBM peak."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402  (device sync only)
+
+import verbatim_rag_amd  # noqa: E402,F401
+from verbatim_rag_amd.vector_stores import DenseShard, SparseShard  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def dense(n=1_250_000, dim=768, k=10):
+    rng = np.random.default_rng(0)
+    sh = DenseShard(dim, n, "bf16")
+    chunk = 125_000
+    for _ in range(n // chunk):
+        sh.add((rng.integers(-64, 65, size=(chunk, dim)) / 64.0).astype(np.float32))
+    out = []
+    for nq in (1, 4, 16):
+        q = (rng.integers(-64, 65, size=(nq, dim)) / 64.0).astype(np.float32)
+        sh.search(q, k)
+        dt = timeit(lambda: sh.run_resident(nq, k), 10)
+        passes = (nq + 3) // 4
+        bytes_ = n * dim * 2 * passes
+        out.append({"kind": "dense_bf16", "rows": n, "dim": dim, "nq": nq, "k": k, "ms": dt * 1e3,
+                    "queries_per_s": nq / dt, "algorithmic_GBps": bytes_ / dt / 1e9, "frac_of_8TBps": bytes_ / dt / HBM_PEAK,
+                    "bytes_per_pass": n * dim * 2, "passes": passes})
+    sh.close()
+    return out
+
+
+def sparse(n=1_000_000, vocab=30522, mean_nnz=128, k=5):
+    rng = np.random.default_rng(1)
+    nnz = np.maximum(1, rng.poisson(mean_nnz, size=n))
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(nnz, out=indptr[1:])
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    idx = rng.choice(vocab, size=int(indptr[-1]), p=p).astype(np.int32)   # duplicates inside a doc are harmless here
+    val = (rng.integers(1, 193, size=int(indptr[-1])) / 64.0).astype(np.float32)
+    sh = SparseShard(vocab, indptr, idx, val)
+    st = sh.stats()
+    out = []
+    for nq in (1, 8):
+        qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(nq)]
+        sh.search(qs, k)
+        dt = timeit(lambda: sh.run_resident(nq, k), 5)
+        bytes_ = (st["padded_nnz"] * 6 + (st["n_docs"] // 64 + 1) * 12) * nq
+        out.append({"kind": "sparse_sell64", "docs": n, "nnz": st["nnz"], "padded_nnz": st["padded_nnz"], "nq": nq, "k": k,
+                    "ms": dt * 1e3, "queries_per_s": nq / dt, "algorithmic_GBps": bytes_ / dt / 1e9,
+                    "frac_of_8TBps": bytes_ / dt / HBM_PEAK, "bytes_per_query_pass": bytes_ // nq})
+    sh.close()
+    return out
+
+
+if __name__ == "__main__":
+    for row in dense() + sparse():
+        print(json.dumps(row))

@@ -11,7 +11,7 @@ struct AttnParams {
   bf16_t* o;         // [Tp, H]
   const int* blk_seq_start;  // [n_blocks] first packed token of the q-block's sequence
   const int* blk_seq_len;    // [n_blocks] sequence length S
-  const int* blk_q0;         // [n_blocks] first query row of the block inside its sequence (x attention_q_block())
+  const int* blk_q0;         // [n_blocks] first query row of the block inside its sequence (x attention_q_block(local))
   int n_blocks;
   int H;       // hidden = nh * 64
   int nh;
@@ -20,6 +20,6 @@ struct AttnParams {
 };
 
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream);
-int attention_q_block();  // query rows per work item (256)
+int attention_q_block(bool local);  // query rows per work item (256 global / 128 banded)
 
 }  // namespace vrag

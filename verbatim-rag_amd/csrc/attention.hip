@@ -2,8 +2,9 @@
 // eager/SDPA attention inside ModernBertAttention.forward
 // (transformers modeling_modernbert.py:166-185,286-299; mask: masking_utils.py:141-151).
 //
-// Work item = (sequence, 256-row query block, head); 4 waves x 64 query rows (two 32-row
-// sub-tiles per wave that SHARE every K / V^T fragment read from LDS).  64-key tiles stream
+// Work item = (sequence, query block, head): 256 rows / 4 waves on global layers, 128 rows / 2 waves
+// on banded layers; every wave owns 64 query rows (two 32-row sub-tiles that SHARE every K / V^T
+// fragment read from LDS).  64-key tiles stream
 // through a 3-slot LDS ring by 16-byte LDS-DMA (global_load_lds), two tiles in flight, one raw
 // s_barrier per tile and a counted s_waitcnt vmcnt (never a full drain in steady state).
 // Per tile and sub-tile:
@@ -23,12 +24,15 @@
 
 namespace vrag {
 
-constexpr int ATT_QB = 256;      // query rows per workgroup
+constexpr int ATT_QB_GLOBAL = 256;  // query rows per workgroup, global layers (4 waves)
+constexpr int ATT_QB_LOCAL = 128;   // banded layers (2 waves): fewer loaded-but-unused key tiles per wave
 constexpr int ATT_TILE = 16384;  // bytes per LDS ring slot (K 8 KiB + V^T 8 KiB)
 constexpr int ATT_SLOTS = 3;
 
-template <bool LOCAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+template <bool LOCAL, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int ATT_QB = NW * 64;
+  constexpr int NI = 8 / NW;  // LDS-DMA instructions per wave per operand per tile (8 rows each)
   __shared__ __attribute__((aligned(16))) char smem[ATT_SLOTS * ATT_TILE];
 
   const int tid = threadIdx.x;
@@ -53,6 +57,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
   }
+  // Retire the Q loads HERE: an ordinary load still pending when the loop starts makes hipcc wait
+  // vmcnt(0) at its first use inside the loop on every iteration, which drains the LDS-DMA
+  // prefetch ring (two tiles ahead) each tile.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[u][s]));
 
   int kb_lo = 0, kb_hi = (S - 1) >> 6;
   if constexpr (LOCAL) {
@@ -60,19 +72,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     kb_hi = min(S - 1, qb0 + ATT_QB - 1 + W) >> 6;
   }
 
-  // LDS-DMA roles: instruction i (0,1) of this wave covers tile rows wave*16 + i*8 + (lane>>3)
-  const int drow0 = wave * 16 + (lane >> 3);
+  // LDS-DMA roles: instruction i of this wave covers tile rows wave*(64/NW) + i*8 + (lane>>3)
+  const int drow0 = wave * (64 / NW) + (lane >> 3);
   const int dchunk = lane & 7;
   auto stage = [&](int kb) {
     char* slot = smem + (kb % ATT_SLOTS) * ATT_TILE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int row = drow0 + i * 8;  // K: key row, V^T: d row
       const int lc = dchunk ^ ((row >> 1) & 7);
       const int krow = min(t0 + kb * 64 + row, Tp - 1);
-      glds16(p.k + (size_t)krow * H + head * 64 + lc * 8, slot + (wave * 16 + i * 8) * 128);
+      glds16(p.k + (size_t)krow * H + head * 64 + lc * 8, slot + (wave * (64 / NW) + i * 8) * 128);
       const int col = min(t0 + kb * 64 + lc * 8, Tp - 8);
-      glds16(p.vt + (size_t)(head * 64 + row) * Tp + col, slot + 8192 + (wave * 16 + i * 8) * 128);
+      glds16(p.vt + (size_t)(head * 64 + row) * Tp + col, slot + 8192 + (wave * (64 / NW) + i * 8) * 128);
     }
   };
 
@@ -89,9 +101,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   stage(kb_lo);
   if (kb_lo + 1 <= kb_hi) stage(kb_lo + 1);
   for (int kb = kb_lo; kb <= kb_hi; ++kb) {
-    // tile kb landed (this wave's part); the next tile (4 DMA instructions) may stay in flight
-    if (kb < kb_hi) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kb landed (this wave's part); the next tile (2*NI DMA instructions) may stay in flight
+    if (kb < kb_hi) {
+      if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kb + 2 <= kb_hi) stage(kb + 2);  // slot of tile kb-1: every wave finished it before the barrier
@@ -131,12 +147,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
       if constexpr (LOCAL) need_mask = need_mask || (kb * 64 < q_lo + 31 - W) || (kb * 64 + 63 > q_lo + W);
       float mx = -1e30f;
       if (need_mask) {  // wave-uniform
+        int kbase = kb * 64;
+        asm volatile("" : "+s"(kbase));  // keep the predicate arithmetic inside this (rare) branch
         const int qi = q_lo + l31;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int kk = kb * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int kk = kbase + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             bool ok = kk < S;
             if constexpr (LOCAL) ok = ok && (kk - qi <= W) && (qi - kk <= W);
             const float x = ok ? st[u][t][r] : -INFINITY;
@@ -218,15 +236,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
-int attention_q_block() { return ATT_QB; }
+int attention_q_block(bool local) { return local ? ATT_QB_LOCAL : ATT_QB_GLOBAL; }
 
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream) {
   if (p.n_blocks <= 0) return hipSuccess;
   dim3 grid(p.n_blocks, p.nh);
   if (local)
-    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, ATT_QB_LOCAL / 64>), grid, dim3(ATT_QB_LOCAL), 0, stream, p);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, ATT_QB_GLOBAL / 64>), grid, dim3(ATT_QB_GLOBAL), 0, stream, p);
   return hipGetLastError();
 }
 

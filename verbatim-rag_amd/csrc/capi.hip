@@ -97,7 +97,8 @@ struct Layer {
 
 struct MicroBatch {
   int row0, row1;  // multiples of kRowPad (256): GEMM tiles never straddle micro-batches
-  int blk0, blk1;
+  int blk0, blk1;    // global-layer q-block range
+  int lblk0, lblk1;  // banded-layer q-block range
 };
 
 struct ProfRec {
@@ -143,7 +144,8 @@ struct vrag_encoder {
   bf16_t *a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr, *act = nullptr;
   float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
   float *st_part = nullptr, *ln_mu = nullptr, *ln_rstd = nullptr;  // folded-LayerNorm row statistics
-  int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;
+  int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;     // global-layer q-blocks
+  int *d_lblk_start = nullptr, *d_lblk_len = nullptr, *d_lblk_q0 = nullptr;  // banded-layer q-blocks
   int cap_blocks = 0;
   int *d_rng_start = nullptr, *d_rng_end = nullptr;
   float* d_rng_out = nullptr;  // [max_ranges, max(H, labels)]
@@ -153,6 +155,7 @@ struct vrag_encoder {
   // pinned staging
   int *h_ids = nullptr, *h_pos = nullptr, *h_tokseq = nullptr;
   int *h_blk_start = nullptr, *h_blk_len = nullptr, *h_blk_q0 = nullptr;
+  int *h_lblk_start = nullptr, *h_lblk_len = nullptr, *h_lblk_q0 = nullptr;
   int *h_rng_start = nullptr, *h_rng_end = nullptr;
   float* h_out = nullptr;  // generic read-back staging
   size_t h_out_bytes = 0;
@@ -382,10 +385,10 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         ap.k = e->k;
         ap.vt = e->vt;
         ap.o = e->o;
-        ap.blk_seq_start = e->d_blk_start + mb.blk0;
-        ap.blk_seq_len = e->d_blk_len + mb.blk0;
-        ap.blk_q0 = e->d_blk_q0 + mb.blk0;
-        ap.n_blocks = mb.blk1 - mb.blk0;
+        ap.blk_seq_start = global ? e->d_blk_start + mb.blk0 : e->d_lblk_start + mb.lblk0;
+        ap.blk_seq_len = global ? e->d_blk_len + mb.blk0 : e->d_lblk_len + mb.lblk0;
+        ap.blk_q0 = global ? e->d_blk_q0 + mb.blk0 : e->d_lblk_q0 + mb.lblk0;
+        ap.n_blocks = global ? mb.blk1 - mb.blk0 : mb.lblk1 - mb.lblk0;
         ap.H = H;
         ap.nh = c.num_heads;
         ap.Tp = Tp;
@@ -592,7 +595,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   e->cap_rows = (int)align_up((int64_t)cfg->max_tokens + (int64_t)kSeqAlign * cfg->max_seqs + (int64_t)kRowPad * (n_mb + 1),
                               kRowPad);
   const size_t R = e->cap_rows;
-  e->cap_blocks = cfg->max_tokens / 128 + cfg->max_seqs + 1;
+  e->cap_blocks = cfg->max_tokens / 128 + cfg->max_seqs + 1;  // >= blocks of either granularity
   TRY(dev_alloc(e, &e->d_ids, R));
   TRY(dev_alloc(e, &e->d_pos, R));
   TRY(dev_alloc(e, &e->d_tokseq, R));
@@ -610,6 +613,9 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_lblk_start, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_lblk_len, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_lblk_q0, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_rng_start, cfg->max_ranges));
   TRY(dev_alloc(e, &e->d_rng_end, cfg->max_ranges));
   TRY(dev_alloc(e, &e->d_rng_out, (size_t)cfg->max_ranges * H));
@@ -619,6 +625,9 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   TRY(host_alloc(e, &e->h_blk_start, e->cap_blocks));
   TRY(host_alloc(e, &e->h_blk_len, e->cap_blocks));
   TRY(host_alloc(e, &e->h_blk_q0, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_lblk_start, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_lblk_len, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_lblk_q0, e->cap_blocks));
   TRY(host_alloc(e, &e->h_rng_start, cfg->max_ranges));
   TRY(host_alloc(e, &e->h_rng_end, cfg->max_ranges));
   // pad ids everywhere so never-loaded rows embed a valid token
@@ -751,7 +760,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     set_error("batch has %lld tokens, handle capacity is %d", (long long)total, c.max_tokens);
     return VRAG_ERR_CAPACITY;
   }
-  int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_tokens = 0;
+  int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_lblk0 = 0, nlblk = 0, mb_tokens = 0;
   size_t src = 0;
   int prev_rows = e->rows;
   for (int s = 0; s < n_seqs; ++s) {
@@ -759,7 +768,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     t = (int)align_up(t, kSeqAlign);
     if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
       const int row1 = (int)align_up(t, kRowPad);
-      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk});
+      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk});
       for (int r = t; r < row1; ++r) {
         e->h_ids[r] = c.pad_token_id;
         e->h_pos[r] = 0;
@@ -768,6 +777,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
       t = row1;
       mb_row0 = row1;
       mb_blk0 = nblk;
+      mb_lblk0 = nlblk;
       mb_tokens = 0;
     }
     // alignment gap before this sequence
@@ -784,18 +794,24 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
       e->h_pos[t + i] = i;
       e->h_tokseq[t + i] = s;
     }
-    for (int q0 = 0; q0 < Ls; q0 += attention_q_block()) {
+    for (int q0 = 0; q0 < Ls; q0 += attention_q_block(false)) {
       e->h_blk_start[nblk] = t;
       e->h_blk_len[nblk] = Ls;
       e->h_blk_q0[nblk] = q0;
       ++nblk;
+    }
+    for (int q0 = 0; q0 < Ls; q0 += attention_q_block(true)) {
+      e->h_lblk_start[nlblk] = t;
+      e->h_lblk_len[nlblk] = Ls;
+      e->h_lblk_q0[nlblk] = q0;
+      ++nlblk;
     }
     src += Ls;
     t += Ls;
     mb_tokens += Ls;
   }
   const int rows = (int)align_up(t, kRowPad);
-  if (rows > e->cap_rows || nblk > e->cap_blocks) {
+  if (rows > e->cap_rows || nblk > e->cap_blocks || nlblk > e->cap_blocks) {
     set_error("internal: packed layout (%d rows, %d blocks) exceeds the workspace (%d rows, %d blocks)", rows, nblk,
               e->cap_rows, e->cap_blocks);
     return VRAG_ERR_CAPACITY;
@@ -807,7 +823,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     e->h_pos[r] = 0;
     e->h_tokseq[r] = -1;
   }
-  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk});
+  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk});
   e->n_seqs = n_seqs;
   e->n_tokens = (int)total;
   e->rows = rows;
@@ -820,6 +836,9 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   HIP_TRY(hipMemcpyAsync(e->d_blk_start, e->h_blk_start, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->d_blk_len, e->h_blk_len, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->d_blk_q0, e->h_blk_q0, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_lblk_start, e->h_lblk_start, (size_t)nlblk * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_lblk_len, e->h_lblk_len, (size_t)nlblk * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_lblk_q0, e->h_lblk_q0, (size_t)nlblk * sizeof(int), hipMemcpyHostToDevice, st));
   return VRAG_OK;
 }
 

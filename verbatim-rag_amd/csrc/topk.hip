@@ -65,61 +65,109 @@ __device__ __forceinline__ void insert_key(u64* list, int k, u64 key) {
 
 // ------------------------------------------------------------------------------------ dense
 constexpr int DQT = 4;        // queries per pass
-constexpr int DROWS_WG = 4096;  // rows per workgroup
+constexpr int DROWS_WG = 512;   // rows per workgroup (>= 8 workgroups per CU on a 1M-row shard)
 
-template <bool F32>
+// QT queries per pass (1: query slice lives in registers; 4: in LDS), DIMC = dim/128 16-byte chunks per
+// lane per row when known at compile time (0 = runtime loop).  Two rows per 16-lane group are in
+// flight per iteration so every lane has 2*DIMC independent 16-byte loads outstanding.
+template <bool F32, int QT, int DIMC>
 __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict__ rows_v, long long n_rows, int dim,
                                                           const float* __restrict__ queries, int nq, int q0,
                                                           int k, u64* __restrict__ cand) {
-  // LDS: queries [DQT][dim] fp32, per 16-lane group lists [16 groups][DQT][k]
+  // LDS: queries [QT][dim] fp32, per 16-lane group lists [16 groups][QT][k]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);
-  u64* lists = reinterpret_cast<u64*>(smem + (size_t)DQT * dim * sizeof(float));
-  const int tid = threadIdx.x, lane = tid & 63;
+  u64* lists = reinterpret_cast<u64*>(smem + (size_t)QT * dim * sizeof(float));
+  const int tid = threadIdx.x;
   const int grp = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes
-  const int nqt = min(DQT, nq - q0);
-  for (int i = tid; i < DQT * dim; i += 256) {
+  const int nqt = min(QT, nq - q0);
+  for (int i = tid; i < QT * dim; i += 256) {
     const int q = i / dim;
     sq[i] = q < nqt ? queries[(size_t)(q0 + q) * dim + (i - q * dim)] : 0.f;
   }
-  for (int i = tid; i < 16 * DQT * k; i += 256) lists[i] = 0ull;
+  for (int i = tid; i < 16 * QT * k; i += 256) lists[i] = 0ull;
   __syncthreads();
+
+  constexpr int EPC = F32 ? 4 : 8;       // elements per 16-byte chunk
+  constexpr int CSTR = 16 * EPC;         // element stride between a lane's chunks
+  // QT == 1 with a compile-time dim: keep this lane's query slice in registers
+  float qreg[(QT == 1 && DIMC > 0) ? DIMC * EPC : 1];
+  if constexpr (QT == 1 && DIMC > 0) {
+#pragma unroll
+    for (int i = 0; i < DIMC; ++i)
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) qreg[i * EPC + j] = sq[gl * EPC + i * CSTR + j];
+  }
 
   const long long r_begin = (long long)blockIdx.x * DROWS_WG;
   const long long r_end = min(n_rows, r_begin + DROWS_WG);
-  u64* mylist = lists + (size_t)grp * DQT * k;
-  for (long long r = r_begin + grp; r < r_end; r += 16) {
-    float acc[DQT];
+  u64* mylist = lists + (size_t)grp * QT * k;
+  const size_t esz = F32 ? 4 : 2;
+  constexpr int RSTEP = QT == 1 ? 32 : 16;  // the LDS-query path keeps one row per group in flight (LDS-bound)
+  for (long long r = r_begin + grp; r < r_end; r += RSTEP) {
+    const bool has2 = QT == 1 && r + 16 < r_end;
+    const char* row0 = reinterpret_cast<const char*>(rows_v) + (size_t)r * dim * esz + (size_t)gl * 16;
+    const char* row1 = has2 ? row0 + (size_t)16 * dim * esz : row0;
+    float acc[2][QT];
 #pragma unroll
-    for (int q = 0; q < DQT; ++q) acc[q] = 0.f;
-    if constexpr (!F32) {
-      const bf16_t* row = reinterpret_cast<const bf16_t*>(rows_v) + (size_t)r * dim;
-      for (int c = gl * 8; c < dim; c += 128) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = (float)v[j];
+      for (int q = 0; q < QT; ++q) acc[u][q] = 0.f;
+
+    auto accumulate = [&](const f32x4& raw, int u, int i) {
+      float x[EPC];
+      if constexpr (F32) {
 #pragma unroll
-          for (int q = 0; q < DQT; ++q) acc[q] = fmaf(x, sq[q * dim + c + j], acc[q]);
+        for (int j = 0; j < 4; ++j) x[j] = raw[j];
+      } else {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (float)v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        if constexpr (QT == 1 && DIMC > 0) {
+          acc[u][0] = fmaf(x[j], qreg[i * EPC + j], acc[u][0]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < QT; ++q) acc[u][q] = fmaf(x[j], sq[q * dim + gl * EPC + i * CSTR + j], acc[u][q]);
         }
       }
+    };
+    if constexpr (DIMC > 0) {
+      f32x4 raw[2][DIMC];
+#pragma unroll
+      for (int i = 0; i < DIMC; ++i) {
+        raw[0][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row0 + (size_t)i * 256));
+        if constexpr (QT == 1) raw[1][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row1 + (size_t)i * 256));
+      }
+#pragma unroll
+      for (int i = 0; i < DIMC; ++i) {
+        accumulate(raw[0][i], 0, i);
+        if constexpr (QT == 1) accumulate(raw[1][i], 1, i);
+      }
     } else {
-      const float* row = reinterpret_cast<const float*>(rows_v) + (size_t)r * dim;
-      for (int c = gl * 4; c < dim; c += 64) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int q = 0; q < DQT; ++q) acc[q] = fmaf(v[j], sq[q * dim + c + j], acc[q]);
+      for (int i = 0; (gl + 16 * i) * EPC < dim; ++i) {  // any dim that is a multiple of 8
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(row0 + (size_t)i * 256);
+        accumulate(a0, 0, i);
+        if constexpr (QT == 1) {
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(row1 + (size_t)i * 256);
+          accumulate(a1, 1, i);
+        }
       }
     }
 #pragma unroll
-    for (int q = 0; q < DQT; ++q) {
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) acc[q] += __shfl_xor(acc[q], o, 64);
-    }
+      for (int q = 0; q < QT; ++q) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc[u][q] += __shfl_xor(acc[u][q], o, 64);
+      }
     if (gl == 0) {
-      for (int q = 0; q < nqt; ++q) insert_key(mylist + q * k, k, make_key(acc[q], (unsigned)r));
+      for (int q = 0; q < nqt; ++q) {
+        insert_key(mylist + q * k, k, make_key(acc[0][q], (unsigned)r));
+        if (has2) insert_key(mylist + q * k, k, make_key(acc[1][q], (unsigned)(r + 16)));
+      }
     }
   }
   __syncthreads();
@@ -133,7 +181,7 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict_
       int bg = -1;
       for (int g = 0; g < 16; ++g) {
         if (head[g] < k) {
-          const u64 v = lists[((size_t)g * DQT + tid) * k + head[g]];
+          const u64 v = lists[((size_t)g * QT + tid) * k + head[g]];
           if (v > best) {
             best = v;
             bg = g;
@@ -144,7 +192,43 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict_
       if (bg >= 0) ++head[bg];
     }
   }
-  (void)lane;
+}
+
+template <bool F32>
+static hipError_t dense_launch_pass(const void* rows, long long n, int dim, const float* dq, int nq, int q0, int qt, int k,
+                                    u64* cand, int n_wg, hipStream_t st) {
+  const size_t lds = (size_t)qt * dim * sizeof(float) + (size_t)16 * qt * k * sizeof(u64);
+  const int cstr = F32 ? 64 : 128;
+  const int dimc = dim % cstr == 0 ? dim / cstr : -1;
+#define VRAG_DENSE_CASE(QT_, DC_)                                                                               \
+  hipLaunchKernelGGL((dense_topk_kernel<F32, QT_, DC_>), dim3(n_wg), dim3(256), lds, st, rows, n, dim, dq, nq, q0, k, cand)
+  if (qt == 1) {
+    if (dimc == 6) VRAG_DENSE_CASE(1, 6);
+    else if (dimc == 3) VRAG_DENSE_CASE(1, 3);
+    else if (dimc == 8) VRAG_DENSE_CASE(1, 8);
+    else if (dimc == 12) VRAG_DENSE_CASE(1, 12);
+    else VRAG_DENSE_CASE(1, 0);
+  } else {
+    if (dimc == 6) VRAG_DENSE_CASE(4, 6);
+    else if (dimc == 3) VRAG_DENSE_CASE(4, 3);
+    else if (dimc == 8) VRAG_DENSE_CASE(4, 8);
+    else VRAG_DENSE_CASE(4, 0);
+  }
+#undef VRAG_DENSE_CASE
+  return hipGetLastError();
+}
+
+// all passes of one search: query tiles of 4 (a final tile of 1 query uses the register path)
+static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int dim, const float* dq, int nq, int k,
+                                   u64* cand, int n_wg, hipStream_t st) {
+  for (int q0 = 0; q0 < nq;) {
+    const int qt = (nq - q0 == 1) ? 1 : DQT;
+    hipError_t e = dtype == 0 ? dense_launch_pass<false>(rows, n, dim, dq, nq, q0, qt, k, cand, n_wg, st)
+                              : dense_launch_pass<true>(rows, n, dim, dq, nq, q0, qt, k, cand, n_wg, st);
+    if (e != hipSuccess) return e;
+    q0 += qt;
+  }
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------ sparse
@@ -448,15 +532,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
   } else {
-    for (int q0 = 0; q0 < nq; q0 += DQT) {
-      if (ix->dtype == 0)
-        hipLaunchKernelGGL((dense_topk_kernel<false>), dim3(n_wg), dim3(256), lds, st, ix->rows, (long long)ix->size,
-                           ix->dim, ix->d_q, nq, q0, k, ix->d_cand);
-      else
-        hipLaunchKernelGGL((dense_topk_kernel<true>), dim3(n_wg), dim3(256), lds, st, ix->rows, (long long)ix->size,
-                           ix->dim, ix->d_q, nq, q0, k, ix->d_cand);
-      HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st));
     hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), 0, st, ix->d_cand, n_wg, nq, k, ix->d_out);
     HIP_TRY(hipGetLastError());
   }
@@ -478,15 +554,7 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   const int n_wg = (int)((ix->size + DROWS_WG - 1) / DROWS_WG);
   ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k, "scratch too small");
   const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
-  for (int q0 = 0; q0 < nq; q0 += DQT) {
-    if (ix->dtype == 0)
-      hipLaunchKernelGGL((dense_topk_kernel<false>), dim3(n_wg), dim3(256), lds, st, ix->rows, (long long)ix->size,
-                         ix->dim, ix->d_q, nq, q0, k, ix->d_cand);
-    else
-      hipLaunchKernelGGL((dense_topk_kernel<true>), dim3(n_wg), dim3(256), lds, st, ix->rows, (long long)ix->size,
-                         ix->dim, ix->d_q, nq, q0, k, ix->d_cand);
-    HIP_TRY(hipGetLastError());
-  }
+  HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st));
   hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), 0, st, ix->d_cand, n_wg, nq, k, ix->d_out);
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
@@ -588,8 +656,17 @@ int vrag_sparse_index_stats(vrag_sparse_index* ix, int64_t* n_docs, int64_t* nnz
   return VRAG_OK;
 }
 
+static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
+  // ~2 workgroups per CU (one is resident per CU: the dense query vector fills the LDS), each a
+  // multiple of its 16 waves
+  const int target_wgs = 512;
+  int spw = (ix->n_slices + target_wgs - 1) / target_wgs;
+  spw = std::max(16, (spw + 15) / 16 * 16);
+  return spw;
+}
+
 static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out) {
-  const int slices_per_wg = 256;  // 16 waves x 16 slices
+  const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   *n_wg_out = n_wg;
   const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) <= 160 * 1024;
@@ -632,7 +709,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
       ARG_CHECK(t >= 0 && t < ix->vocab, "query %d: term id %d outside the vocabulary", q, t);
       dense[(size_t)q * ix->vocab + t] = q_values[j];
     }
-  const int slices_per_wg = 256;
+  const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   int rc;
   if ((rc = grow(&ix->d_q, &ix->d_q_elems, dense.size()))) return rc;

@@ -114,8 +114,8 @@ struct vrag_encoder {
   vrag_encoder_config cfg{};
   std::recursive_mutex mu;
   hipStream_t own_stream = nullptr;
-  hipStream_t aux_streams[2] = {nullptr, nullptr};  // optional 2-way micro-batch concurrency
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t aux_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // micro-batch concurrency (up to 4 ways)
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   int n_streams = 1;
   bool ln_fold = false;  // LayerNorm folded into the consumer GEMM epilogues (VRAG_LN_FOLD=1; measured 3% slower)
   std::vector<void*> dev_allocs;
@@ -319,11 +319,11 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
   const bool fork = e->n_streams > 1 && e->mbs.size() > 1;
   if (fork) {
     HIP_TRY(hipEventRecord(e->ev_fork, user_st));
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(e->aux_streams[i], e->ev_fork, 0));
+    for (int i = 0; i < e->n_streams; ++i) HIP_TRY(hipStreamWaitEvent(e->aux_streams[i], e->ev_fork, 0));
   }
   for (size_t mbi = 0; mbi < e->mbs.size(); ++mbi) {
     const MicroBatch& mb = e->mbs[mbi];
-    hipStream_t st = fork ? e->aux_streams[mbi & 1] : user_st;
+    hipStream_t st = fork ? e->aux_streams[mbi % e->n_streams] : user_st;
     const int r0 = mb.row0, M = mb.row1 - mb.row0;
     {
       ProfScope ps(e, VRAG_PROF_EMBED, st);
@@ -453,7 +453,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
     }
   }
   if (fork) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < e->n_streams; ++i) {
       HIP_TRY(hipEventRecord(e->ev_join[i], e->aux_streams[i]));
       HIP_TRY(hipStreamWaitEvent(user_st, e->ev_join[i], 0));
     }
@@ -544,12 +544,12 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   }
 
   e->n_streams = 2;  // micro-batches alternate between two internal streams (VRAG_STREAMS=1 disables)
-  if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = atoi(ns) >= 2 ? 2 : 1;
+  if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = std::min(4, std::max(1, atoi(ns)));
   {
     hipError_t he = hipSuccess;
-    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking);
+    for (int i = 0; i < 4 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
+    for (int i = 0; i < 4 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
     if (he != hipSuccess) {
       set_error("aux stream creation failed: %s", hipGetErrorString(he));
       return fail(VRAG_ERR_HIP);
@@ -662,7 +662,7 @@ void vrag_encoder_destroy(vrag_encoder* e) {
   for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
   for (void* p : e->dev_allocs) (void)hipFree(p);
   for (void* p : e->host_allocs) (void)hipHostFree(p);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (e->aux_streams[i]) (void)hipStreamDestroy(e->aux_streams[i]);
     if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
   }
@@ -1144,7 +1144,7 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
 }
 
 int vrag_encoder_set_concurrency(vrag_encoder* e, int32_t n_streams) {
-  ARG_CHECK(e && (n_streams == 1 || n_streams == 2), "n_streams must be 1 or 2");
+  ARG_CHECK(e && n_streams >= 1 && n_streams <= 4, "n_streams must be in [1, 4]");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   e->n_streams = n_streams;
   return VRAG_OK;

@@ -25,7 +25,7 @@
 namespace vrag {
 
 constexpr int ATT_QB_GLOBAL = 256;  // query rows per workgroup, global layers (4 waves)
-constexpr int ATT_QB_LOCAL = 128;   // banded layers (2 waves): fewer loaded-but-unused key tiles per wave
+constexpr int ATT_QB_LOCAL = 256;   // banded layers (128 rows / 2 waves measured slower: 4.8 vs 4.4 ms per step)
 constexpr int ATT_TILE = 16384;  // bytes per LDS ring slot (K 8 KiB + V^T 8 KiB)
 constexpr int ATT_SLOTS = 3;
 
@@ -147,16 +147,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
       if constexpr (LOCAL) need_mask = need_mask || (kb * 64 < q_lo + 31 - W) || (kb * 64 + 63 > q_lo + W);
       float mx = -1e30f;
       if (need_mask) {  // wave-uniform
-        int kbase = kb * 64;
-        asm volatile("" : "+s"(kbase));  // keep the predicate arithmetic inside this (rare) branch
+        // visible keys of row qi form one interval [lo, hi_]: key(r) = kbase + c_r is visible iff
+        // (unsigned)(kbase + c_r - lo) <= hi_ - lo  -> one add + one unsigned compare per element
+        int kbase = kb * 64 + 4 * hi;
+        asm volatile("" : "+v"(kbase));  // keep the predicate arithmetic inside this (rare) branch
         const int qi = q_lo + l31;
+        int lo = 0, hi_ = S - 1;
+        if constexpr (LOCAL) {
+          lo = max(0, qi - W);
+          hi_ = min(S - 1, qi + W);
+        }
+        const unsigned span = hi_ >= lo ? (unsigned)(hi_ - lo) : 0u;
+        const int d0 = hi_ >= lo ? kbase - lo : -100000;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int kk = kbase + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            bool ok = kk < S;
-            if constexpr (LOCAL) ok = ok && (kk - qi <= W) && (qi - kk <= W);
+            const bool ok = (unsigned)(d0 + (t * 32 + (r & 3) + 8 * (r >> 2))) <= span;
             const float x = ok ? st[u][t][r] : -INFINITY;
             st[u][t][r] = x;
             mx = fmaxf(mx, x);

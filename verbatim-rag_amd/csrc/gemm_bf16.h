@@ -51,6 +51,7 @@ struct GemmParams {
   int stagger_sleeps;     // max delay in units of s_sleep(127) (~8k cycles); 0 = off
   int stagger_blocks;     // only workgroups with blockIdx < this are delayed
   int stagger_groups;     // XCD phase groups (1, 2, 4 or 8)
+  int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
 };
 
 // Launches on `stream`. Requirements: N % 128 == 0, K % 64 == 0.

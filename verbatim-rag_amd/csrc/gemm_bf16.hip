@@ -23,6 +23,7 @@
 // partners sit in the same lane and register index of acc[0][mi] / acc[1][mi].
 #include "gemm_bf16.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -352,27 +353,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
   const int hi = lane >> 5, l31 = lane & 31;
   constexpr int WROWS = BM / WM;              // rows of the A tile owned by one wave
 
-  // XCD-aware, bijective block remap: consecutive logical tiles (same A row panel, n fastest)
-  // land on the same XCD so the panel is served from that XCD's L2.
+  // Persistent tile loop: the grid is at most one workgroup per CU (p.n_tiles tiles in total).  Tiles
+  // are dealt so that each XCD (workgroup w runs on XCD w % 8) walks a contiguous range of logical
+  // tiles, n fastest: the column tiles of an A row panel run together on one XCD and share its L2.
+  // Staying resident lets a tile's epilogue stores drain while the next tile's operands stream in.
   const int nbn = p.N / BN;
-  const int nblk = gridDim.x;
-  int b = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
   const int K = p.K;
-  if (p.stagger_sleeps > 0 && (int)blockIdx.x < p.stagger_blocks) {
-    // pseudo-random phase per workgroup: identical tiles would otherwise run main loop and
-    // epilogue in lockstep chip-wide (MFMA idle while every CU waits on HBM, and vice versa).
-    // phase groups of whole XCDs (block b runs on XCD b % 8): CUs sharing an L2 stay in lockstep
-    // (they share operand k-slices), different groups are offset so that one group's HBM-bound
-    // epilogue overlaps the other groups' MFMA-bound main loops.
-    const int n = (int)((blockIdx.x & 7) % p.stagger_groups) * p.stagger_sleeps;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
+  const int n_tiles = p.n_tiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_xcd_wgs = (gridDim.x + 7 - xcd) >> 3;  // workgroups of this grid that sit on my XCD
+  const int tq = n_tiles >> 3, tr = n_tiles & 7;
+  const int range_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int range_len = xcd < tr ? tq + 1 : tq;
+  for (int tix = slot; tix < range_len; tix += per_xcd_wgs) {
+  const int b = range_lo + tix;
+  const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 
@@ -455,6 +450,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
   else mainloop(std::true_type{});
 
   gemm_epilogue<EPI, MI, WROWS>(p, acc, smem, wave, lane, mw, nw, n0, v_block);
+  __syncthreads();  // staging area is reused as operand slots by the next tile
+  }  // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -698,6 +695,7 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
       attr = true;
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    p.n_tiles = nbm * nbn;
     p.stagger_blocks = 256;   // 1 workgroup per CU
     static const bool bigprobe = getenv("VRAG_GEMM_BIGPROBE") != nullptr;  // tuning probe
     if (bigprobe && EPI == EPI_NONE) {
@@ -722,13 +720,15 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
       }
       hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(nbm * nbn), dim3(512), SMEM, stream, p);
     } else {
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4>), dim3(nbm * nbn), dim3(512), SMEM, stream, p);
+      static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
     }
   } else {
     constexpr int BM = 128, BN = 128, SMEM = 2 * (BM + BN) * BK * 2;
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    p.n_tiles = nbm * nbn;
     p.stagger_blocks = 512;   // 2 workgroups per CU
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2>), dim3(nbm * nbn), dim3(256), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2>), dim3(std::min(nbm * nbn, 512)), dim3(256), SMEM, stream, p);
   }
   return hipGetLastError();
 }

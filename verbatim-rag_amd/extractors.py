@@ -136,6 +136,7 @@ class GpuModelSpanExtractor(SpanExtractor):
         qa_max_length: int = 512,
         max_batch_tokens: int = 65536,
         max_batch_seqs: int = 512,
+        chunk_cache_size: int = 65536,
     ):
         self.model_path = model_path
         self.threshold = threshold
@@ -147,6 +148,11 @@ class GpuModelSpanExtractor(SpanExtractor):
         self.max_batch_tokens = max_batch_tokens
         self.max_batch_seqs = max_batch_seqs
         self._lock = threading.Lock()  # callers arrive from asyncio.to_thread workers (extractors.py:54)
+        # chunk text -> (sentences, per-sentence token ids): chunk texts are known at ingest and recur across
+        # queries, and the reference's per-query tokenisation (2.7 ms/chunk) would cap the GPU path
+        self._chunk_cache: Dict[str, Tuple[List[str], List[List[int]]]] = {}
+        self._chunk_cache_size = chunk_cache_size
+        self._cache_lock = threading.Lock()
         dev = 0 if device in (None, "cuda", "cpu", "mps") else int(str(device).replace("cuda:", ""))
         self.device = f"cuda:{dev}"
 
@@ -225,23 +231,37 @@ class GpuModelSpanExtractor(SpanExtractor):
         return self._extract_qa_model(question, search_results)
 
     # ------------------------------------------------------------------ legacy qa_model path
+    def prepare_chunks(self, texts: Sequence[str]) -> None:
+        """Optional ingest-time hook: pre-split and pre-tokenise chunk texts (e.g. from add_vectors)."""
+        self.pack_qa("", list(texts))
+
     def pack_qa(self, question: str, texts: Sequence[str]) -> Tuple[List[List[str]], List[Optional[PackedSample]]]:
         """Sentence split + token packing for every chunk; one batched tokenizer call for all
         sentences (bit-identical to the reference's per-sentence calls, dataset.py:158-167)."""
         budget = self.qa_max_length - 2
         q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
-        all_sents = [split_into_sentences(t) for t in texts]
-        flat = [s for sents in all_sents for s in sents]
-        flat_ids = self._tok.ids_batch(flat, max_length=budget)
-        samples: List[Optional[PackedSample]] = []
-        o = 0
-        for sents in all_sents:
-            if not sents:
-                samples.append(None)
-                continue
-            samples.append(encode_question_and_sentences(q_ids, flat_ids[o:o + len(sents)], self._tok.sep_token_id,
-                                                         max_length=self.qa_max_length))
-            o += len(sents)
+        # sentence split + tokenisation per chunk, memoised (sentences are tokenised independently of the
+        # question, dataset.py:158-167, so the cached ids are exactly what the reference would produce)
+        with self._cache_lock:
+            missing = [t for t in dict.fromkeys(texts) if t not in self._chunk_cache]
+            if missing:
+                split = [split_into_sentences(t) for t in missing]
+                flat = [s for sents in split for s in sents]
+                flat_ids = self._tok.ids_batch(flat, max_length=budget)
+                o = 0
+                if len(self._chunk_cache) + len(missing) > self._chunk_cache_size:
+                    self._chunk_cache.clear()
+                for t, sents in zip(missing, split):
+                    self._chunk_cache[t] = (sents, flat_ids[o:o + len(sents)])
+                    o += len(sents)
+            all_sents, samples = [], []
+            for t in texts:
+                sents, ids = self._chunk_cache[t]
+                all_sents.append(sents)
+                if not sents:
+                    samples.append(None)
+                    continue
+                samples.append(encode_question_and_sentences(q_ids, ids, self._tok.sep_token_id, max_length=self.qa_max_length))
         return all_sents, samples
 
     def _extract_qa_model(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:

@@ -137,3 +137,22 @@ def test_vector_store_semantics():
     r = st.query(dense_query=q, sparse_query=sparse[3], top_k=4, hybrid_weights={"dense": 0.7, "sparse": 0.3, "full_text": 1})
     assert len(r) == 4
     assert len(st.query(top_k=7)) == 7     # filter-only browse
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(10000, 768, 40, 10), (5000, 128, 8, 16), (130, 256, 33, 5), (300000, 384, 64, 10)])
+def test_dense_topk_batched_mfma_path_exact(n, dim, nq, k):
+    """>= 8 queries, bf16 rows, k <= 16: 32 queries per pass on the matrix cores (queries rounded to bf16;
+    dyadic-grid queries are exact in bf16, so indices and scores must equal the oracle bit for bit)."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(n + nq)
+    X, Q = _dyadic(rng, (n, dim)), _dyadic(rng, (nq, dim))
+    X[n // 2] = X[n // 3]
+    Q[1] = Q[0]
+    sh = DenseShard(dim, n, "bf16")
+    sh.add(X)
+    s, i = sh.search(Q, k)
+    sh.close()
+    rs, ri = T.dense_topk(X, Q, k)
+    assert np.array_equal(i, ri)
+    assert np.array_equal(s, rs)

@@ -170,3 +170,15 @@ def test_base_config_logits_vs_transformers_golden():
         err = np.abs(got[n] - z[f"logits_{n}"]).max()
         assert err < 1e-3, f"seq {n}: sentence-logit max-abs error {err}"
     assert np.abs(hid[:4] - z["hidden_rows_0"]).max() < 5e-2
+
+
+def test_cross_query_batching_equals_per_query_calls(setup):
+    cfg, w, z, eng, ext, fx = setup
+    run = fx["extract_e2e"]["runs"][0]
+    ext.threshold = run["threshold"]
+    results = [types.SimpleNamespace(text=t) for t in run["texts"]]
+    qs = [run["question"], "Who built the iron bridge?", run["question"]]
+    rs = [results, results[:3], results[2:]]
+    batched = ext.extract_spans_batch(qs, rs)
+    assert batched == [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
+    assert batched[0] == run["spans"]

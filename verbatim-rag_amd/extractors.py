@@ -265,19 +265,30 @@ class GpuModelSpanExtractor(SpanExtractor):
         return all_sents, samples
 
     def _extract_qa_model(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
-        texts = [getattr(r, "text", "") for r in search_results]
-        all_sents, samples = self.pack_qa(question, texts)
-        relevant: Dict[str, List[str]] = {t: [] for t in texts}
-        todo = []
-        for i, smp in enumerate(samples):
-            if smp is None:
-                continue
-            vb = valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
-            if not vb:
-                # the reference's QAModel returns None here and `len(None)` raises; we log and return [].
-                logger.error("chunk %d: no sentence fits the %d-token budget", i, self.qa_max_length)
-                continue
-            todo.append((i, smp.input_ids, vb))
+        return self.extract_spans_batch([question], [search_results])[0]
+
+    def extract_spans_batch(self, questions: Sequence[str],
+                            results_per_question: Sequence[Sequence[Any]]) -> List[Dict[str, List[str]]]:
+        """Cross-query batching: all (question_i, chunk_ij) pairs of several concurrent
+        queries go through the GPU as shared padding-free batches.  Element i of the result equals
+        `extract_spans(questions[i], results_per_question[i])` (legacy qa_model format)."""
+        if self._format != self._FORMAT_QA_MODEL:
+            return [self.extract_spans(q, r) for q, r in zip(questions, results_per_question)]
+        out: List[Dict[str, List[str]]] = []
+        todo = []  # (query index, text, sentences, ids, boundaries)
+        for qi, (question, results) in enumerate(zip(questions, results_per_question)):
+            texts = [getattr(r, "text", "") for r in results]
+            all_sents, samples = self.pack_qa(question, texts)
+            out.append({t: [] for t in texts})
+            for i, smp in enumerate(samples):
+                if smp is None:
+                    continue
+                vb = valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
+                if not vb:
+                    # the reference's QAModel returns None here and `len(None)` raises; we log and return [].
+                    logger.error("query %d chunk %d: no sentence fits the %d-token budget", qi, i, self.qa_max_length)
+                    continue
+                todo.append((qi, texts[i], all_sents[i], smp.input_ids, vb))
         # sub-batches that fit the engine workspace
         with self._lock:
             start = 0
@@ -285,21 +296,21 @@ class GpuModelSpanExtractor(SpanExtractor):
                 tok = rng = 0
                 end = start
                 while end < len(todo) and end - start < self.engine.max_seqs and \
-                        tok + len(todo[end][1]) <= self.engine.max_tokens and rng + len(todo[end][2]) <= self.engine.max_ranges:
-                    tok += len(todo[end][1])
-                    rng += len(todo[end][2])
+                        tok + len(todo[end][3]) <= self.engine.max_tokens and rng + len(todo[end][4]) <= self.engine.max_ranges:
+                    tok += len(todo[end][3])
+                    rng += len(todo[end][4])
                     end += 1
                 if end == start:
                     raise ValueError("a single sample exceeds the engine workspace")
                 batch = todo[start:end]
                 try:
-                    logits = self.engine.qa_logits([b[1] for b in batch], [b[2] for b in batch])
-                    for (i, _ids, _vb), lg in zip(batch, logits):
-                        relevant[texts[i]] = select_sentences(lg, all_sents[i], self.threshold)
+                    logits = self.engine.qa_logits([b[3] for b in batch], [b[4] for b in batch])
+                    for (qi, text, sents, _ids, _vb), lg in zip(batch, logits):
+                        out[qi][text] = select_sentences(lg, sents, self.threshold)
                 except Exception as exc:  # same contract as extractors.py:225-227: log, [] for the chunk(s)
                     logger.error("GPU span extraction failed: %s", exc)
                 start = end
-        return relevant
+        return out
 
     # ------------------------------------------------------------------ v2 highlighter path
     def _encode_windows(self, question: str, context: str):

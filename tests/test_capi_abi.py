@@ -64,3 +64,13 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback when the shared object is absent: importing the binding raises."""
+    monkeypatch.setenv("VRAG_AMD_LIB", str(tmp_path / "nope" / "libvrag_amd.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load().vrag_abi_version() == 1

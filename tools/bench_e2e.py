@@ -69,7 +69,7 @@ def main():
     tok = Tokenizer.from_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "tokenizer.json"))
     shape = ModernBertShape.base()
     eng = EncoderEngine(shape, random_init(shape, 1234), max_tokens=131072, max_seqs=2048, max_seq_len=512,
-                        max_ranges=32768, micro_batch_tokens=32768)
+                        max_ranges=32768, micro_batch_tokens=65536)
     eng.set_qa_head(*random_qa_head(shape))
     ext = GpuModelSpanExtractor(engine=eng, tokenizer=tok, threshold=0.5)
     ext.prepare_chunks(pool)  # ingest-time tokenisation

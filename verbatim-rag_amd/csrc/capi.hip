@@ -117,7 +117,7 @@ struct vrag_encoder {
   hipStream_t aux_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // micro-batch concurrency (up to 4 ways)
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   int n_streams = 1;
-  bool ln_fold = false;  // LayerNorm folded into the consumer GEMM epilogues (VRAG_LN_FOLD=1; measured 3% slower)
+  bool ln_fold = true;   // LayerNorm folded into the producer/consumer GEMM epilogues (VRAG_LN_FOLD=0: separate LN kernels)
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
 

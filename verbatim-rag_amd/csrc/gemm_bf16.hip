@@ -336,7 +336,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 }
 
 // BM x BN tile, WM x WN waves; every wave owns (BM/WM) x 64 outputs (MI = BM/WM/32 row tiles, 2 column tiles).
-template <int EPI, int BM, int BN, int WM, int WN>
+// DBG = 1 compiles the main-loop decomposition probe (p.debug_flags), instantiated for EPI_NONE only.
+template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
   constexpr int NT = WM * WN * 64;            // threads
@@ -422,16 +423,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+      if (kt + 1 < KT && !(DBG && (p.debug_flags & 1) && kt >= 1)) stage(kt + 1, buf ^ 1);
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * 128;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * 128;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 af[MI], wf[2];
+        bf16x8 af[MI] = {}, wf[2] = {};
+        if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
+          for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
+          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -721,6 +724,21 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
       hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(nbm * nbn), dim3(512), SMEM, stream, p);
     } else {
       static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
+      static const int env_debug = getenv("VRAG_GEMM_DEBUG") ? atoi(getenv("VRAG_GEMM_DEBUG")) : 0;
+      if constexpr (EPI == EPI_NONE) {
+        if (env_debug) {   // main-loop decomposition probe: results are garbage by design
+          static bool attr5 = false;
+          if (!attr5) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            if (e != hipSuccess) return e;
+            attr5 = true;
+          }
+          p.debug_flags = env_debug;
+          hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
+          return hipGetLastError();
+        }
+      }
       hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
     }
   } else {

@@ -37,7 +37,7 @@ extern "C" {
 #define VRAG_ERR_CAPACITY (-3)/* batch does not fit the workspace the handle was created with */
 #define VRAG_ERR_NO_DEVICE (-4)
 
-#define VRAG_ABI_VERSION 1
+#define VRAG_ABI_VERSION 2
 
 typedef struct vrag_encoder vrag_encoder;
 
@@ -75,12 +75,60 @@ typedef struct vrag_encoder_weights {
   const float* final_norm;       /* [H]      final_norm.weight */
 } vrag_encoder_weights;
 
+/* BERT-family encoders (BERT, DistilBERT: post-LN, biased linears, learned absolute positions, GELU MLP) --
+ * the checkpoints the reference names for its embedding providers (`naver/splade-v3`,
+ * `opensearch-neural-sparse-encoding-doc-v2-distill`: verbatim_rag/embedding_providers.py:120, README.md:122-125;
+ * BAAI/bge-base: embedding_providers.py:55).  Replaces transformers BertModel / DistilBertModel.forward
+ * (models/bert/modeling_bert.py, models/distilbert/modeling_distilbert.py) underneath
+ * sentence-transformers' SparseEncoder / SentenceTransformer .encode.  head_dim must be 64. */
+typedef struct vrag_bert_config {
+  int32_t vocab_size;
+  int32_t hidden_size;              /* multiple of 128, <= 1024 */
+  int32_t num_layers;
+  int32_t num_heads;                /* hidden_size / 64 */
+  int32_t intermediate_size;        /* multiple of 128 */
+  int32_t max_position_embeddings;  /* rows of position_embeddings */
+  float norm_eps;                   /* 1e-12 */
+  int32_t pad_token_id;
+  int32_t max_seq_len;              /* <= max_position_embeddings */
+  int32_t max_tokens;
+  int32_t max_seqs;
+  int32_t max_ranges;
+  int32_t micro_batch_tokens;
+  int32_t device;
+} vrag_bert_config;
+
+/* Host fp32 arrays, HF layouts. wqkv/bqkv are the query, key, value matrices / biases concatenated
+ * along the output dimension ([3H,H] / [3H]).  DistilBERT: token_type_row = NULL. */
+typedef struct vrag_bert_weights {
+  const float* word_embeddings;      /* [V, H] */
+  const float* position_embeddings;  /* [P, H] */
+  const float* token_type_row;       /* [H] = token_type_embeddings[0] (single-segment inputs) or NULL */
+  const float* emb_norm_w;           /* [H] embeddings.LayerNorm.weight */
+  const float* emb_norm_b;           /* [H] */
+  const float* const* wqkv;          /* [L][3H,H] */
+  const float* const* bqkv;          /* [L][3H] */
+  const float* const* wo;            /* [L][H,H]  attention.output.dense / out_lin */
+  const float* const* bo;            /* [L][H] */
+  const float* const* attn_norm_w;   /* [L][H]    attention.output.LayerNorm / sa_layer_norm */
+  const float* const* attn_norm_b;   /* [L][H] */
+  const float* const* w1;            /* [L][I,H]  intermediate.dense / ffn.lin1 */
+  const float* const* b1;            /* [L][I] */
+  const float* const* w2;            /* [L][H,I]  output.dense / ffn.lin2 */
+  const float* const* b2;            /* [L][H] */
+  const float* const* out_norm_w;    /* [L][H]    output.LayerNorm / output_layer_norm */
+  const float* const* out_norm_b;    /* [L][H] */
+} vrag_bert_weights;
+
 const char* vrag_last_error(void);
 int vrag_abi_version(void);
 /* Number of visible HIP devices (0 when there is no GPU); never fails. */
 int vrag_device_count(void);
 
 int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weights* w, vrag_encoder** out);
+/* Same opaque handle type: load_batch / run / load_ranges / run_pool / run_splade / read_* work on it
+ * unchanged (there is no final LayerNorm to apply; pooling averages the hidden states directly). */
+int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weights* w, vrag_encoder** out);
 void vrag_encoder_destroy(vrag_encoder* enc);
 
 /* Heads (host fp32, HF layouts). */
@@ -92,6 +140,13 @@ int vrag_encoder_set_token_head(vrag_encoder* enc, const float* dense_w /*[H,H]*
 /* decoder_w == NULL ties the decoder to tok_embeddings (ModernBertForMaskedLM). */
 int vrag_encoder_set_mlm_head(vrag_encoder* enc, const float* dense_w /*[H,H]*/, const float* norm_w /*[H]*/,
                               const float* decoder_w /*[V,H] or NULL*/, const float* decoder_b /*[V]*/);
+
+/* MLM head with biases (BertForMaskedLM cls.predictions / DistilBertForMaskedLM vocab_transform,
+ * vocab_layer_norm, vocab_projector): logits = decoder(LN(gelu(dense(h) + dense_b)) * norm_w + norm_b) + decoder_b.
+ * dense_b / norm_b may be NULL (ModernBERT); decoder_w == NULL ties the decoder to the word embeddings. */
+int vrag_encoder_set_mlm_head_ex(vrag_encoder* enc, const float* dense_w /*[H,H]*/, const float* dense_b /*[H]*/,
+                                 const float* norm_w /*[H]*/, const float* norm_b /*[H]*/,
+                                 const float* decoder_w /*[V,H] or NULL*/, const float* decoder_b /*[V]*/);
 
 /* Packed batch: `ids` is the plain concatenation of n_seqs unpadded sequences of lengths
  * seq_lens[i] (positions restart at 0 per sequence, like the reference's B=1 forward). */

@@ -1,0 +1,142 @@
+"""GPU parity of the BERT-family encoder path (vrag_bert_encoder_create) through the C ABI: golden vectors
+captured from `transformers` (tiny BERT / DistilBERT), the numpy oracle at BERT-base width, and the embedding
+providers on top.  Same precision recipe as the ModernBERT path (bf16 MFMA operands, fp32 elsewhere)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bert_np as B
+from oracle import modernbert_np as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _shape(cfg, kind):
+    from verbatim_rag_amd.engine import BertShape
+
+    return BertShape(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                     num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                     max_position_embeddings=cfg.max_position_embeddings, norm_eps=cfg.layer_norm_eps,
+                     pad_token_id=0, cls_token_id=1, sep_token_id=2, model_type=kind)
+
+
+@pytest.mark.parametrize("name", ["bert_tiny", "distilbert_tiny"])
+def test_tiny_models_vs_transformers_golden(name):
+    from verbatim_rag_amd.engine import BertEncoderEngine
+    from verbatim_rag_amd.weights import bert_canonical
+
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))
+    V, H, L, NH, I, P = (int(x) for x in z["cfg"])
+    cfg = B.BertConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=NH, intermediate_size=I,
+                       max_position_embeddings=P)
+    W = bert_canonical({k[3:]: z[k] for k in z.files if k.startswith("sd:")})
+    eng = BertEncoderEngine(_shape(cfg, "bert" if name == "bert_tiny" else "distilbert"), W, max_tokens=1024,
+                            max_seqs=8, max_seq_len=64, max_ranges=16)
+    try:
+        seqs = [z["ids0"], z["ids1"]]
+        eng.load_batch(seqs)
+        eng.run()
+        got = eng.read_hidden(final_norm=True)   # no final LayerNorm in this family: flag is ignored
+        assert np.array_equal(got, eng.read_hidden(final_norm=False))
+        o = 0
+        for i, s in enumerate(seqs):
+            err = np.abs(got[o:o + len(s)] - z[f"hidden{i}"]).max()
+            assert err < 3e-2, (name, i, err)
+            o += len(s)
+        eng.run_splade()
+        rows = eng.read_splade()
+        for i in range(2):
+            ref = O.splade_pool(z[f"mlm{i}"])
+            assert np.abs(rows[i] - ref).max() < 3e-2, np.abs(rows[i] - ref).max()
+        # per-layer prefix (post-LN stream after the embedding LayerNorm and after layer 1)
+        Wo = B.canonical_from_hf({k[3:]: z[k] for k in z.files if k.startswith("sd:")})
+        for nl in (0, 1):
+            eng.run(n_layers=nl)
+            g = eng.read_hidden(final_norm=False)[: len(seqs[0])]
+            ref = B.encoder_forward(cfg, Wo, seqs[0], n_layers=nl)
+            assert np.abs(g - ref).max() < (1e-5 if nl == 0 else 2e-2), (nl, np.abs(g - ref).max())
+    finally:
+        eng.close()
+
+
+@pytest.fixture(scope="module")
+def base_width():
+    """BERT-base width (H=768, 12 heads, I=3072: the 256x256 GEMM tiles), 2 layers, small vocabulary."""
+    from verbatim_rag_amd.engine import BertEncoderEngine
+
+    cfg = B.BertConfig(vocab_size=2048, hidden_size=768, num_hidden_layers=2, num_attention_heads=12,
+                       intermediate_size=3072, max_position_embeddings=512)
+    W = B.random_weights(cfg, seed=5, kind="bert", std=0.03)
+    eng = BertEncoderEngine(_shape(cfg, "bert"), W, max_tokens=8192, max_seqs=32, max_seq_len=512, max_ranges=64,
+                            micro_batch_tokens=2048)
+    yield cfg, W, eng
+    eng.close()
+
+
+def test_base_width_hidden_pool_and_splade_vs_oracle(base_width):
+    cfg, W, eng = base_width
+    rng = np.random.default_rng(2)
+    lens = [512, 7, 130, 64, 257, 300, 1, 511, 33]
+    seqs = [rng.integers(3, cfg.vocab_size, size=n).astype(np.int32) for n in lens]
+    eng.load_batch(seqs)
+    n = len(seqs)
+    eng.load_ranges(list(range(n)), [0] * n, [len(s) - 1 for s in seqs])
+    eng.run()
+    got = eng.read_hidden(final_norm=False)
+    eng.run_pool(True)
+    pooled = eng.read_pool()
+    eng.run_splade()
+    rows = eng.read_splade()
+    o = 0
+    for i, s in enumerate(seqs):
+        ref = B.encoder_forward(cfg, W, s)
+        err = np.abs(got[o:o + len(s)] - ref).max()
+        assert err < 4e-2, (len(s), err)
+        pr = O.dense_pool(ref, "mean", True)
+        assert abs(float(np.linalg.norm(pooled[i])) - 1.0) < 1e-5
+        assert np.abs(pooled[i] - pr).max() < 2e-3
+        sr = O.splade_pool(B.mlm_logits(cfg, W, ref))
+        assert np.abs(rows[i] - sr).max() < 4e-2
+        o += len(s)
+    # micro-batching (2048-token micro-batches on two streams) must not change a sequence's rows
+    eng.load_batch([seqs[0]])
+    eng.run()
+    alone = eng.read_hidden(final_norm=False)
+    assert np.array_equal(alone, got[:512])
+
+
+def test_providers_on_bert_engine(base_width):
+    from tokenizers import Tokenizer
+
+    from verbatim_rag_amd.embedding_providers import GpuDenseProvider, GpuSpladeProvider
+
+    cfg, W, eng = base_width
+    tok = Tokenizer.from_file(os.path.join(GOLD, "tokenizer.json"))
+    texts = ["The Eiffel Tower is in Paris.", "It was built in 1889. Millions visit it.", "tower"]
+    sp = GpuSpladeProvider(eng, tok)
+    one = sp.embed_text(texts[0])
+    many = sp.embed_batch(texts)
+    assert sp.get_dimension() == cfg.vocab_size and len(many) == 3
+    assert all(isinstance(k, int) and isinstance(v, float) and v > 0 for k, v in one.items())
+    assert all(abs(many[0][k] - v) < 1e-6 for k, v in one.items())
+    dn = GpuDenseProvider(eng, tok, pooling="cls")
+    v = dn.embed_text(texts[1])
+    assert len(v) == cfg.hidden_size == dn.get_dimension() and abs(np.linalg.norm(v) - 1) < 1e-5
+    # CLS pooling == the first token's hidden state, L2-normalised
+    ids = sp._encode([texts[1]])[0]
+    ref = O.dense_pool(B.encoder_forward(cfg, W, [min(i, cfg.vocab_size - 1) for i in ids]), "cls", True)
+    if max(ids) < cfg.vocab_size:
+        assert np.abs(np.asarray(v) - ref).max() < 2e-3
+
+
+def test_rejects_unsupported_shapes():
+    from verbatim_rag_amd._lib import VragError
+    from verbatim_rag_amd.engine import BertEncoderEngine, BertShape
+    from verbatim_rag_amd.weights import random_init_bert
+
+    shp = BertShape(vocab_size=128, hidden_size=384, num_hidden_layers=1, num_attention_heads=12, intermediate_size=1536,
+                    max_position_embeddings=64)   # all-MiniLM-L6-v2 geometry: head_dim 32
+    with pytest.raises(VragError, match="head_dim must be 64"):
+        BertEncoderEngine(shp, random_init_bert(shp, mlm=False), max_tokens=256, max_seqs=2, max_seq_len=64, max_ranges=4)

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.vrag_abi_version() == 1
+    assert lib.vrag_abi_version() == _lib.ABI_VERSION == 2
     assert lib.vrag_device_count() >= 0
     assert isinstance(_lib.last_error(), str)
 
@@ -73,4 +73,4 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
     monkeypatch.undo()
-    assert _lib.load().vrag_abi_version() == 1
+    assert _lib.load().vrag_abi_version() == _lib.ABI_VERSION

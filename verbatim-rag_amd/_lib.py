@@ -11,6 +11,7 @@ _LOCK = threading.Lock()
 _LIB = None
 
 VRAG_OK = 0
+ABI_VERSION = 2
 PROF_CLASSES = (
     "embed", "layernorm", "gemm_qkv", "attn_global", "attn_local",
     "gemm_wo", "gemm_wi", "gemm_wo_mlp", "head",
@@ -49,6 +50,24 @@ class EncoderWeights(C.Structure):
     ]
 
 
+class BertConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
+        ("intermediate_size", C.c_int32), ("max_position_embeddings", C.c_int32), ("norm_eps", C.c_float),
+        ("pad_token_id", C.c_int32), ("max_seq_len", C.c_int32), ("max_tokens", C.c_int32), ("max_seqs", C.c_int32),
+        ("max_ranges", C.c_int32), ("micro_batch_tokens", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class BertWeights(C.Structure):
+    _fields_ = [
+        ("word_embeddings", _FP), ("position_embeddings", _FP), ("token_type_row", _FP), ("emb_norm_w", _FP),
+        ("emb_norm_b", _FP), ("wqkv", _FPP), ("bqkv", _FPP), ("wo", _FPP), ("bo", _FPP), ("attn_norm_w", _FPP),
+        ("attn_norm_b", _FPP), ("w1", _FPP), ("b1", _FPP), ("w2", _FPP), ("b2", _FPP), ("out_norm_w", _FPP),
+        ("out_norm_b", _FPP),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/vrag_amd.h declares.
 _H = C.c_void_p
 SIGNATURES = {
@@ -56,10 +75,12 @@ SIGNATURES = {
     "vrag_abi_version": (C.c_int, []),
     "vrag_device_count": (C.c_int, []),
     "vrag_encoder_create": (C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), C.POINTER(_H)]),
+    "vrag_bert_encoder_create": (C.c_int, [C.POINTER(BertConfig), C.POINTER(BertWeights), C.POINTER(_H)]),
     "vrag_encoder_destroy": (None, [_H]),
     "vrag_encoder_set_qa_head": (C.c_int, [_H, _FP, _FP, C.c_int32]),
     "vrag_encoder_set_token_head": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int32]),
     "vrag_encoder_set_mlm_head": (C.c_int, [_H, _FP, _FP, _FP, _FP]),
+    "vrag_encoder_set_mlm_head_ex": (C.c_int, [_H, _FP, _FP, _FP, _FP, _FP, _FP]),
     "vrag_encoder_load_batch": (C.c_int, [_H, _IP, _IP, C.c_int32, C.c_void_p]),
     "vrag_encoder_run": (C.c_int, [_H, C.c_void_p]),
     "vrag_encoder_run_layers": (C.c_int, [_H, C.c_int32, C.c_void_p]),
@@ -113,8 +134,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.vrag_abi_version() != 1:
-            raise ImportError(f"{path}: ABI version {lib.vrag_abi_version()} != 1")
+        if lib.vrag_abi_version() != ABI_VERSION:
+            raise ImportError(f"{path}: ABI version {lib.vrag_abi_version()} != {ABI_VERSION}")
         _LIB = lib
         return lib
 

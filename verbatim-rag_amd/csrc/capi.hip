@@ -95,6 +95,14 @@ struct Layer {
   float* s_wi = nullptr;
 };
 
+// BERT-family layer (post-LN, biased linears, GELU MLP): TF:models/bert/modeling_bert.py:282-286,340-344,
+// models/distilbert/modeling_distilbert.py:236-239.
+struct BertLayer {
+  bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+};
+
 struct MicroBatch {
   int row0, row1;  // multiples of kRowPad (256): GEMM tiles never straddle micro-batches
   int blk0, blk1;    // global-layer q-block range
@@ -122,10 +130,16 @@ struct vrag_encoder {
   std::vector<void*> host_allocs;
 
   // weights
+  int arch = 0;  // 0 = ModernBERT (pre-LN, RoPE, GeGLU, no biases); 1 = BERT family (post-LN, biases, learned positions)
   float* tok_emb = nullptr;
   float* emb_norm = nullptr;
-  float* final_norm = nullptr;
+  float* final_norm = nullptr;   // null for arch 1 (the stream is already normalised)
   std::vector<Layer> layers;
+  // arch 1
+  float *pos_emb = nullptr, *type_row = nullptr, *emb_norm_b = nullptr;
+  std::vector<BertLayer> blayers;
+  float *neg_ones = nullptr, *ones = nullptr;  // [cap_rows] constants: the QKV bias rides the LayerNorm-fold epilogue
+  float *mlm_dense_b = nullptr, *mlm_norm_b = nullptr;
   float *cos_g = nullptr, *sin_g = nullptr, *cos_l = nullptr, *sin_l = nullptr;
   // heads
   float *qa_w = nullptr, *qa_b = nullptr;
@@ -462,6 +476,198 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
   return VRAG_OK;
 }
 
+// BERT-family schedule (arch 1).  Post-LN: every sub-layer is  h <- LN(h + f(h) + b),  so the residual
+// GEMM (bias added in its epilogue) is followed by an in-place LayerNorm that also refreshes the bf16
+// copy the next GEMM reads.  The QKV GEMM reuses EPI_QKV_ROPE with identity rotation tables; its bias
+// rides the LayerNorm-fold slot of that epilogue: rstd*(acc - mu*s) with rstd = 1, mu = -1, s = bias.
+// TF:models/bert/modeling_bert.py:141-205 (attention), 282-286 / 340-344 (post-LN), 326-336 (GELU MLP);
+// models/distilbert/modeling_distilbert.py:131-239.
+int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
+  const auto& c = e->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size;
+  const int Tp = e->cap_rows;
+  const bool fork = e->n_streams > 1 && e->mbs.size() > 1;
+  if (fork) {
+    HIP_TRY(hipEventRecord(e->ev_fork, user_st));
+    for (int i = 0; i < e->n_streams; ++i) HIP_TRY(hipStreamWaitEvent(e->aux_streams[i], e->ev_fork, 0));
+  }
+  for (size_t mbi = 0; mbi < e->mbs.size(); ++mbi) {
+    const MicroBatch& mb = e->mbs[mbi];
+    hipStream_t st = fork ? e->aux_streams[mbi % e->n_streams] : user_st;
+    const int r0 = mb.row0, M = mb.row1 - mb.row0;
+    float* h = e->h + (size_t)r0 * H;
+    bf16_t* a = e->a + (size_t)r0 * H;
+    {
+      ProfScope ps(e, VRAG_PROF_EMBED, st);
+      HIP_TRY(launch_embed_ln(e->d_ids + r0, e->tok_emb, e->emb_norm, c.norm_eps, H, M, h, a, st, e->pos_emb,
+                              e->d_pos + r0, e->type_row, e->emb_norm_b));
+    }
+    for (int l = 0; l < n_layers; ++l) {
+      const BertLayer& L = e->blayers[l];
+      {
+        GemmParams g{};
+        g.A = a;
+        g.W = L.wqkv;
+        g.ln_mu = e->neg_ones;
+        g.ln_rstd = e->ones;
+        g.ln_s = L.bqkv;
+        g.M = M;
+        g.N = 3 * H;
+        g.K = H;
+        g.q = e->q + (size_t)r0 * H;
+        g.k = e->k + (size_t)r0 * H;
+        g.vt = e->vt + r0;
+        g.vt_ld = Tp;
+        g.rope_cos = e->cos_g;   // all ones
+        g.rope_sin = e->sin_g;   // all zeros
+        g.pos = e->d_pos + r0;
+        g.hidden = H;
+        g.q_scale = 0.125f * 1.4426950408889634f;
+        ProfScope ps(e, VRAG_PROF_GEMM_QKV, st);
+        HIP_TRY(launch_gemm(EPI_QKV_ROPE, g, st));
+      }
+      {
+        AttnParams ap{};
+        ap.q = e->q;
+        ap.k = e->k;
+        ap.vt = e->vt;
+        ap.o = e->o;
+        ap.blk_seq_start = e->d_blk_start + mb.blk0;
+        ap.blk_seq_len = e->d_blk_len + mb.blk0;
+        ap.blk_q0 = e->d_blk_q0 + mb.blk0;
+        ap.n_blocks = mb.blk1 - mb.blk0;
+        ap.H = H;
+        ap.nh = c.num_heads;
+        ap.Tp = Tp;
+        ap.window = 0;
+        ProfScope ps(e, VRAG_PROF_ATTN_GLOBAL, st);
+        HIP_TRY(launch_attention(ap, false, st));
+      }
+      {
+        GemmParams g{};
+        g.A = e->o + (size_t)r0 * H;
+        g.W = L.wo;
+        g.M = M;
+        g.N = H;
+        g.K = H;
+        g.out_f32 = h;
+        g.bias = L.bo;
+        ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
+        HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+      }
+      {
+        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(h, L.ln1_w, c.norm_eps, H, M, a, h, st, L.ln1_b));
+      }
+      {
+        GemmParams g{};
+        g.A = a;
+        g.W = L.w1;
+        g.M = M;
+        g.N = I;
+        g.K = H;
+        g.out_bf16 = e->act + (size_t)r0 * I;
+        g.bias = L.b1;
+        g.act_gelu = 1;
+        ProfScope ps(e, VRAG_PROF_GEMM_WI, st);
+        HIP_TRY(launch_gemm(EPI_BF16, g, st));
+      }
+      {
+        GemmParams g{};
+        g.A = e->act + (size_t)r0 * I;
+        g.W = L.w2;
+        g.M = M;
+        g.N = H;
+        g.K = I;
+        g.out_f32 = h;
+        g.bias = L.b2;
+        ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
+        HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+      }
+      {
+        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(h, L.ln2_w, c.norm_eps, H, M, a, h, st, L.ln2_b));
+      }
+    }
+  }
+  if (fork) {
+    for (int i = 0; i < e->n_streams; ++i) {
+      HIP_TRY(hipEventRecord(e->ev_join[i], e->aux_streams[i]));
+      HIP_TRY(hipStreamWaitEvent(user_st, e->ev_join[i], 0));
+    }
+  }
+  e->ran = true;
+  return VRAG_OK;
+}
+
+int init_streams(vrag_encoder* e) {
+  HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  e->n_streams = 2;  // micro-batches alternate between two internal streams (VRAG_STREAMS=1 disables)
+  if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = std::min(4, std::max(1, atoi(ns)));
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+  return VRAG_OK;
+}
+
+// Device workspace + pinned staging, sized from e->cfg (shared by both encoder families).
+int init_workspace(vrag_encoder* e) {
+  const vrag_encoder_config* cfg = &e->cfg;
+  const int H = cfg->hidden_size, I = cfg->intermediate_size;
+  int rc;
+#define TRY(x)            \
+  do {                    \
+    rc = (x);             \
+    if (rc) return rc;    \
+  } while (0)
+  int n_mb = 1;
+  if (cfg->micro_batch_tokens > 0) n_mb = cfg->max_tokens / std::max(1, cfg->micro_batch_tokens) + 2;
+  e->cap_rows = (int)align_up((int64_t)cfg->max_tokens + (int64_t)kSeqAlign * cfg->max_seqs + (int64_t)kRowPad * (n_mb + 1),
+                              kRowPad);
+  const size_t R = e->cap_rows;
+  e->cap_blocks = cfg->max_tokens / 128 + cfg->max_seqs + 1;  // >= blocks of either granularity
+  TRY(dev_alloc(e, &e->d_ids, R));
+  TRY(dev_alloc(e, &e->d_pos, R));
+  TRY(dev_alloc(e, &e->d_tokseq, R));
+  TRY(dev_alloc(e, &e->h, R * H));
+  TRY(dev_alloc(e, &e->a, R * H));
+  TRY(dev_alloc(e, &e->q, R * H));
+  TRY(dev_alloc(e, &e->k, R * H));
+  TRY(dev_alloc(e, &e->vt, R * H));
+  TRY(dev_alloc(e, &e->o, R * H));
+  TRY(dev_alloc(e, &e->act, R * I));
+  TRY(dev_alloc(e, &e->f32tmp, R * H));
+  TRY(dev_alloc(e, &e->st_part, R * (H / 64) * 2));
+  TRY(dev_alloc(e, &e->ln_mu, R));
+  TRY(dev_alloc(e, &e->ln_rstd, R));
+  TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_lblk_start, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_lblk_len, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_lblk_q0, e->cap_blocks));
+  TRY(dev_alloc(e, &e->d_rng_start, cfg->max_ranges));
+  TRY(dev_alloc(e, &e->d_rng_end, cfg->max_ranges));
+  TRY(dev_alloc(e, &e->d_rng_out, (size_t)cfg->max_ranges * H));
+  TRY(host_alloc(e, &e->h_ids, R));
+  TRY(host_alloc(e, &e->h_pos, R));
+  TRY(host_alloc(e, &e->h_tokseq, R));
+  TRY(host_alloc(e, &e->h_blk_start, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_blk_len, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_blk_q0, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_lblk_start, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_lblk_len, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_lblk_q0, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_rng_start, cfg->max_ranges));
+  TRY(host_alloc(e, &e->h_rng_end, cfg->max_ranges));
+  // pad ids everywhere so never-loaded rows embed a valid token
+  for (size_t i = 0; i < R; ++i) e->h_ids[i] = cfg->pad_token_id;
+  HIP_TRY(hipMemcpy(e->d_ids, e->h_ids, R * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+#undef TRY
+  return VRAG_OK;
+}
+
 int ensure_h_out(vrag_encoder* e, size_t bytes) {
   if (bytes <= e->h_out_bytes) return VRAG_OK;
   void* p = nullptr;
@@ -535,26 +741,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     if (rc) return fail(rc);   \
   } while (0)
 
-  {
-    hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
-    if (he != hipSuccess) {
-      set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
-      return fail(VRAG_ERR_HIP);
-    }
-  }
-
-  e->n_streams = 2;  // micro-batches alternate between two internal streams (VRAG_STREAMS=1 disables)
-  if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = std::min(4, std::max(1, atoi(ns)));
-  {
-    hipError_t he = hipSuccess;
-    for (int i = 0; i < 4 && he == hipSuccess; ++i) he = hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < 4 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
-    if (he != hipSuccess) {
-      set_error("aux stream creation failed: %s", hipGetErrorString(he));
-      return fail(VRAG_ERR_HIP);
-    }
-  }
+  TRY(init_streams(e));
 
   if (const char* lf = getenv("VRAG_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
 
@@ -589,62 +776,108 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     TRY(upload_f32(e, &e->sin_l, sn.data(), sn.size()));
   }
 
-  // ---- workspace
-  int n_mb = 1;
-  if (cfg->micro_batch_tokens > 0) n_mb = cfg->max_tokens / std::max(1, cfg->micro_batch_tokens) + 2;
-  e->cap_rows = (int)align_up((int64_t)cfg->max_tokens + (int64_t)kSeqAlign * cfg->max_seqs + (int64_t)kRowPad * (n_mb + 1),
-                              kRowPad);
-  const size_t R = e->cap_rows;
-  e->cap_blocks = cfg->max_tokens / 128 + cfg->max_seqs + 1;  // >= blocks of either granularity
-  TRY(dev_alloc(e, &e->d_ids, R));
-  TRY(dev_alloc(e, &e->d_pos, R));
-  TRY(dev_alloc(e, &e->d_tokseq, R));
-  TRY(dev_alloc(e, &e->h, R * H));
-  TRY(dev_alloc(e, &e->a, R * H));
-  TRY(dev_alloc(e, &e->q, R * H));
-  TRY(dev_alloc(e, &e->k, R * H));
-  TRY(dev_alloc(e, &e->vt, R * H));
-  TRY(dev_alloc(e, &e->o, R * H));
-  TRY(dev_alloc(e, &e->act, R * I));
-  TRY(dev_alloc(e, &e->f32tmp, R * H));
-  TRY(dev_alloc(e, &e->st_part, R * (H / 64) * 2));
-  TRY(dev_alloc(e, &e->ln_mu, R));
-  TRY(dev_alloc(e, &e->ln_rstd, R));
-  TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_lblk_start, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_lblk_len, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_lblk_q0, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_rng_start, cfg->max_ranges));
-  TRY(dev_alloc(e, &e->d_rng_end, cfg->max_ranges));
-  TRY(dev_alloc(e, &e->d_rng_out, (size_t)cfg->max_ranges * H));
-  TRY(host_alloc(e, &e->h_ids, R));
-  TRY(host_alloc(e, &e->h_pos, R));
-  TRY(host_alloc(e, &e->h_tokseq, R));
-  TRY(host_alloc(e, &e->h_blk_start, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_blk_len, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_blk_q0, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_lblk_start, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_lblk_len, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_lblk_q0, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_rng_start, cfg->max_ranges));
-  TRY(host_alloc(e, &e->h_rng_end, cfg->max_ranges));
-  // pad ids everywhere so never-loaded rows embed a valid token
-  for (size_t i = 0; i < R; ++i) e->h_ids[i] = cfg->pad_token_id;
+  TRY(init_workspace(e));
+#undef TRY
+  *out = e;
+  return VRAG_OK;
+}
+
+int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weights* w, vrag_encoder** out) {
+  ARG_CHECK(cfg && w && out, "null argument");
+  *out = nullptr;
+  const int H = cfg->hidden_size, I = cfg->intermediate_size, L = cfg->num_layers, V = cfg->vocab_size;
+  const int P = cfg->max_position_embeddings;
+  ARG_CHECK(H > 0 && H % 128 == 0 && H <= 1024, "hidden_size must be a multiple of 128 and <= 1024 (got %d)", H);
+  ARG_CHECK(cfg->num_heads * 64 == H, "head_dim must be 64: num_heads*64 != hidden_size (%d, %d)", cfg->num_heads, H);
+  ARG_CHECK(I > 0 && I % 128 == 0, "intermediate_size must be a multiple of 128 (got %d)", I);
+  ARG_CHECK(L > 0 && V > 0 && P > 0, "bad layer/vocab/position configuration");
+  ARG_CHECK(cfg->max_tokens > 0 && cfg->max_seqs > 0 && cfg->max_seq_len > 0 && cfg->max_ranges > 0,
+            "max_tokens/max_seqs/max_seq_len/max_ranges must be positive");
+  ARG_CHECK(cfg->max_seq_len <= P, "max_seq_len %d exceeds max_position_embeddings %d", cfg->max_seq_len, P);
+  ARG_CHECK(cfg->pad_token_id >= 0 && cfg->pad_token_id < V, "pad_token_id outside the vocabulary");
+  ARG_CHECK(cfg->micro_batch_tokens >= 0, "micro_batch_tokens must be >= 0");
+  ARG_CHECK(w->word_embeddings && w->position_embeddings && w->emb_norm_w && w->emb_norm_b && w->wqkv && w->bqkv &&
+                w->wo && w->bo && w->attn_norm_w && w->attn_norm_b && w->w1 && w->b1 && w->w2 && w->b2 &&
+                w->out_norm_w && w->out_norm_b,
+            "null weight array");
+  if (vrag_device_count() <= cfg->device) {
+    set_error("no HIP device %d visible (the gfx950 library has no CPU fallback)", cfg->device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  vrag_encoder* e = new vrag_encoder();
+  e->arch = 1;
+  e->ln_fold = false;
   {
-    hipError_t he = hipMemcpy(e->d_ids, e->h_ids, R * sizeof(int), hipMemcpyHostToDevice);
-    if (he != hipSuccess) {
-      set_error("hipMemcpy(ids) failed: %s", hipGetErrorString(he));
-      return fail(VRAG_ERR_HIP);
-    }
+    vrag_encoder_config& c = e->cfg;
+    c.vocab_size = V;
+    c.hidden_size = H;
+    c.num_layers = L;
+    c.num_heads = cfg->num_heads;
+    c.intermediate_size = I;
+    c.global_every = 1;
+    c.sliding_window = 0;
+    c.rope_theta_global = c.rope_theta_local = 0.f;
+    c.norm_eps = cfg->norm_eps;
+    c.pad_token_id = cfg->pad_token_id;
+    c.max_seq_len = cfg->max_seq_len;
+    c.max_tokens = cfg->max_tokens;
+    c.max_seqs = cfg->max_seqs;
+    c.max_ranges = cfg->max_ranges;
+    c.micro_batch_tokens = cfg->micro_batch_tokens;
+    c.device = cfg->device;
+  }
+  auto fail = [&](int rc) {
+    vrag_encoder_destroy(e);
+    return rc;
+  };
+  int rc;
+#define TRY(x)                 \
+  do {                         \
+    rc = (x);                  \
+    if (rc) return fail(rc);   \
+  } while (0)
+  TRY(init_streams(e));
+  const size_t stage_elems = std::max<size_t>({(size_t)3 * H * H, (size_t)I * H, (size_t)1 << 22});
+  float* stage = nullptr;
+  TRY(dev_alloc(e, &stage, stage_elems, false));
+  TRY(upload_f32(e, &e->tok_emb, w->word_embeddings, (size_t)V * H));
+  TRY(upload_f32(e, &e->pos_emb, w->position_embeddings, (size_t)P * H));
+  if (w->token_type_row) TRY(upload_f32(e, &e->type_row, w->token_type_row, H));
+  TRY(upload_f32(e, &e->emb_norm, w->emb_norm_w, H));
+  TRY(upload_f32(e, &e->emb_norm_b, w->emb_norm_b, H));
+  e->blayers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    BertLayer& ly = e->blayers[l];
+    ARG_CHECK(w->wqkv[l] && w->bqkv[l] && w->wo[l] && w->bo[l] && w->attn_norm_w[l] && w->attn_norm_b[l] && w->w1[l] &&
+                  w->b1[l] && w->w2[l] && w->b2[l] && w->out_norm_w[l] && w->out_norm_b[l],
+              "null weight pointer in layer %d", l);
+    TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems));
+    TRY(upload_f32(e, &ly.bqkv, w->bqkv[l], (size_t)3 * H));
+    TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
+    TRY(upload_f32(e, &ly.bo, w->bo[l], H));
+    TRY(upload_f32(e, &ly.ln1_w, w->attn_norm_w[l], H));
+    TRY(upload_f32(e, &ly.ln1_b, w->attn_norm_b[l], H));
+    TRY(upload_bf16(e, &ly.w1, w->w1[l], I, H, I, 0, stage, stage_elems));
+    TRY(upload_f32(e, &ly.b1, w->b1[l], I));
+    TRY(upload_bf16(e, &ly.w2, w->w2[l], H, I, H, 0, stage, stage_elems));
+    TRY(upload_f32(e, &ly.b2, w->b2[l], H));
+    TRY(upload_f32(e, &ly.ln2_w, w->out_norm_w[l], H));
+    TRY(upload_f32(e, &ly.ln2_b, w->out_norm_b[l], H));
   }
   {
-    hipError_t he = hipDeviceSynchronize();
-    if (he != hipSuccess) {
-      set_error("device sync after create failed: %s", hipGetErrorString(he));
-      return fail(VRAG_ERR_HIP);
-    }
+    // identity rotation: the QKV epilogue's RoPE becomes a no-op
+    std::vector<float> cs((size_t)cfg->max_seq_len * 32, 1.0f), sn((size_t)cfg->max_seq_len * 32, 0.0f);
+    TRY(upload_f32(e, &e->cos_g, cs.data(), cs.size()));
+    TRY(upload_f32(e, &e->sin_g, sn.data(), sn.size()));
+  }
+  TRY(init_workspace(e));
+  {
+    std::vector<float> v((size_t)e->cap_rows, -1.0f);
+    TRY(upload_f32(e, &e->neg_ones, v.data(), v.size()));
+    std::fill(v.begin(), v.end(), 1.0f);
+    TRY(upload_f32(e, &e->ones, v.data(), v.size()));
   }
 #undef TRY
   *out = e;
@@ -703,19 +936,21 @@ int vrag_encoder_set_token_head(vrag_encoder* e, const float* dense_w, const flo
   return VRAG_OK;
 }
 
-int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float* norm_w, const float* decoder_w,
-                              const float* decoder_b) {
+int vrag_encoder_set_mlm_head_ex(vrag_encoder* e, const float* dense_w, const float* dense_b, const float* norm_w,
+                                 const float* norm_b, const float* decoder_w, const float* decoder_b) {
   ARG_CHECK(e && dense_w && norm_w, "bad mlm head arguments");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int H = e->cfg.hidden_size, V = e->cfg.vocab_size;
-  const int vpad = (int)align_up(V, 128);
+  const int vpad = (int)align_up(V, 256);  // whole 256-wide GEMM tiles
   const size_t stage_elems = std::max<size_t>((size_t)H * H, (size_t)1 << 22);
   float* stage = nullptr;
   int rc = dev_alloc(e, &stage, stage_elems, false);
   if (rc) return rc;
   if ((rc = upload_bf16(e, &e->mlm_dense, dense_w, H, H, H, 0, stage, stage_elems))) return rc;
   if ((rc = upload_f32(e, &e->mlm_norm, norm_w, H))) return rc;
+  if (dense_b && (rc = upload_f32(e, &e->mlm_dense_b, dense_b, H))) return rc;
+  if (norm_b && (rc = upload_f32(e, &e->mlm_norm_b, norm_b, H))) return rc;
   if (decoder_w) {
     if ((rc = upload_bf16(e, &e->mlm_dec, decoder_w, V, H, vpad, 0, stage, stage_elems))) return rc;
   } else {
@@ -731,6 +966,11 @@ int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float
   if ((rc = dev_alloc(e, &e->d_splade, (size_t)e->cfg.max_seqs * vpad))) return rc;
   e->vpad = vpad;
   return VRAG_OK;
+}
+
+int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float* norm_w, const float* decoder_w,
+                              const float* decoder_b) {
+  return vrag_encoder_set_mlm_head_ex(e, dense_w, nullptr, norm_w, nullptr, decoder_w, decoder_b);
 }
 
 int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
@@ -848,7 +1088,8 @@ int vrag_encoder_run_layers(vrag_encoder* e, int32_t n_layers, void* stream) {
   ARG_CHECK(n_layers >= 0 && n_layers <= e->cfg.num_layers, "n_layers out of range");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
-  return run_layers_locked(e, n_layers, pick_stream(e, stream));
+  return e->arch == 1 ? run_layers_bert_locked(e, n_layers, pick_stream(e, stream))
+                      : run_layers_locked(e, n_layers, pick_stream(e, stream));
 }
 
 int vrag_encoder_run(vrag_encoder* e, void* stream) {
@@ -946,6 +1187,7 @@ int vrag_encoder_run_token_head(vrag_encoder* e, void* stream) {
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   ARG_CHECK(e->tk_labels > 0, "token head not set (vrag_encoder_set_token_head)");
+  ARG_CHECK(e->arch == 0, "the token-classification head is defined for the ModernBERT encoder only");
   ARG_CHECK(e->ran, "encoder has not run on this batch");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
@@ -985,7 +1227,13 @@ int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
   hipStream_t st = pick_stream(e, stream);
   const int H = e->cfg.hidden_size;
   ProfScope ps(e, VRAG_PROF_HEAD, st);
-  HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+  if (e->arch == 1) {  // post-LN stream: no final LayerNorm, just the bf16 operand copy
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(e->rows), dim3(256), 0, st, e->h, e->a, e->rows, e->rows, H, 0,
+                       (const float*)nullptr, (float*)nullptr);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+  }
   GemmParams g{};
   g.A = e->a;
   g.W = e->mlm_dense;
@@ -993,8 +1241,9 @@ int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
   g.N = H;
   g.K = H;
   g.out_f32 = e->f32tmp;
+  g.bias = e->mlm_dense_b;
   HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
-  HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+  HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, e->mlm_norm_b));
   HIP_TRY(hipMemsetAsync(e->d_splade, 0, (size_t)e->n_seqs * e->vpad * sizeof(unsigned), st));
   GemmParams d{};
   d.A = e->a;
@@ -1034,7 +1283,7 @@ int vrag_encoder_read_hidden(vrag_encoder* e, int32_t apply_final_norm, float* o
   hipStream_t st = pick_stream(e, stream);
   const int H = e->cfg.hidden_size;
   const float* src = e->h;
-  if (apply_final_norm) {
+  if (apply_final_norm && e->final_norm) {
     HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, nullptr, e->f32tmp, st));
     src = e->f32tmp;
   }

@@ -90,6 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
             if constexpr (EPI == EPI_F32_GELU) {
+              if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + ni * 32 + 8 * g + 4 * hi);
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
             }
@@ -116,6 +117,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
         float* dst = p.out_f32 + (size_t)(mw + ps * 64 + row) * p.N + nw + c16 * 4;
         if constexpr (EPI == EPI_RESIDUAL) {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);   // BERT-family linears have biases
           v += hv[it];
         } else if constexpr (EPI == EPI_F32) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);
@@ -165,6 +167,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           for (int j = 0; j < 4; ++j) {
             float v = acc[ni][mi][4 * g + j];
             if (p.bias) v += p.bias[nw + col + j];
+            if (p.act_gelu) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
             o[j] = (bf16_t)v;
           }
           put_bf16(mi * 32 + l31, col, o, 128);
@@ -300,38 +303,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       }
     }
   } else if constexpr (EPI == EPI_SPLADE) {
-    // max over the tokens of each sequence of log1p(relu(logit + bias)).
+    // rows[seq][n] = max over the tokens of `seq` of log1p(relu(logit + bias[n])).  log1p(relu(. + b)) is
+    // monotone non-decreasing, so the max is taken over the raw accumulators first and the transcendental is
+    // evaluated once per (sequence, column) -- bit-identical to transforming every element.  A wave's
+    // WROWS token rows are a few contiguous runs of sequences: one pass per distinct sequence id.
     int sq[MI];
-    bool same_l = true;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) sq[mi] = p.tok_seq[mw + mi * 32 + l31];
-    const int s0 = uniform(sq[0]);
+    int done_below = 0;   // sequence ids < done_below are finished (ids are non-negative and ascending along rows)
+    while (true) {
+      int m = 0x7fffffff;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) same_l = same_l && (sq[mi] == s0);
-    const bool same = __all(same_l);
+      for (int mi = 0; mi < MI; ++mi)
+        if (sq[mi] >= done_below) m = min(m, sq[mi]);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+      const int cur = uniform(m);
+      if (cur == 0x7fffffff) break;
+      bool mine[MI];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = nw + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        float vv[MI];
+      for (int mi = 0; mi < MI; ++mi) mine[mi] = sq[mi] == cur;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) vv[mi] = log1pf(fmaxf(acc[ni][mi][r] + bias, 0.f));
-        if (same) {
-          if (s0 < 0) continue;
-          float v = vv[0];
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int mi = 1; mi < MI; ++mi) v = fmaxf(v, vv[mi]);
+        for (int r = 0; r < 16; ++r) {
+          float v = -INFINITY;
 #pragma unroll
-          for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-          if (l31 == 0 && v > 0.f) atomicMax(p.splade_rows + (size_t)s0 * p.N + n, f2u(v));
-        } else {
+          for (int mi = 0; mi < MI; ++mi) v = mine[mi] ? fmaxf(v, acc[ni][mi][r]) : v;
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            if (sq[mi] >= 0 && vv[mi] > 0.f) atomicMax(p.splade_rows + (size_t)sq[mi] * p.N + n, f2u(vv[mi]));
+          for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));   // over the 32 token lanes of this half
+          if (l31 == 0) {
+            const int n = nw + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float w = log1pf(fmaxf(v + (p.bias ? p.bias[n] : 0.f), 0.f));
+            if (w > 0.f) atomicMax(p.splade_rows + (size_t)cur * p.N + n, f2u(w));
+          }
         }
-      }
+      done_below = cur + 1;
+    }
   }
 }
 

@@ -6,14 +6,18 @@
 namespace vrag {
 
 // h[t] = LN(E[ids[t]]) (fp32 residual stream) and a = bf16(h) (layer 0 has no attn_norm).
+// BERT family: P/pos/type_row add learned position rows and the token-type row before the LN, `bias` is
+// the LayerNorm bias (TF:models/bert/modeling_bert.py:53-62, models/distilbert/modeling_distilbert.py:82-116).
 hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows,
-                           float* h, bf16_t* a, hipStream_t stream);
+                           float* h, bf16_t* a, hipStream_t stream, const float* P = nullptr,
+                           const int* pos = nullptr, const float* type_row = nullptr, const float* bias = nullptr);
 
-// out = LN(h) * w ; writes bf16 and/or fp32 (either pointer may be null).
+// out = LN(h) * w (+ bias); writes bf16 and/or fp32 (either pointer may be null; out_f32 may be h itself).
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows,
-                            bf16_t* out_bf16, float* out_f32, hipStream_t stream);
+                            bf16_t* out_bf16, float* out_f32, hipStream_t stream, const float* bias = nullptr);
 
-// For each range r: v = mean_{t in [start[r], end[r]]} LN(h[t]) * lnw   (inclusive token range)
+// For each range r: v = mean_{t in [start[r], end[r]]} LN(h[t]) * lnw   (inclusive token range; lnw == nullptr:
+// no LayerNorm, v = mean of h -- post-LN encoders)
 //   mode 0: out[r][c] = v . Wc[c] + bc[c]          (reference QAModel head, model.py:82-113)
 //   mode 1: out[r][:] = v / max(||v||, 1e-12)       (sentence-transformers mean/CLS pooling + Normalize)
 //   mode 2: out[r][:] = v                           (pooling without normalisation)
@@ -24,6 +28,6 @@ hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H,
 // Token-classification tail: logits[t][c] = LN(x[t]) * lnw . Wc[c] + bc[c]   (x fp32 = gelu(dense(h)))
 hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows,
                                 const float* Wc, const float* bc, int num_labels, float* logits,
-                                hipStream_t stream);
+                                hipStream_t stream, const float* lnb = nullptr);
 
 }  // namespace vrag

@@ -22,7 +22,8 @@ __device__ __forceinline__ void load_row(const float* row, int H, int lane, f32x
 }
 
 // In-register LayerNorm (biased variance, two-pass), result overwrites x.
-__device__ __forceinline__ void ln_row(f32x4 (&x)[MAXV], const f32x4 (&w)[MAXV], int H, int lane, float eps) {
+__device__ __forceinline__ void ln_row(f32x4 (&x)[MAXV], const f32x4 (&w)[MAXV], int H, int lane, float eps,
+                                       const float* bias = nullptr) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
@@ -46,18 +47,38 @@ __device__ __forceinline__ void ln_row(f32x4 (&x)[MAXV], const f32x4 (&w)[MAXV],
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[i][j] = x[i][j] * rstd * w[i][j];
+  if (bias) {  // nn.LayerNorm with bias (BERT family, TF:models/bert/modeling_bert.py:62)
+    f32x4 b[MAXV];
+    load_row(bias, H, lane, b);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) x[i] += b[i];
+  }
 }
 
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const float* __restrict__ E,
                                                         const float* __restrict__ w, float eps, int H, int rows,
-                                                        float* __restrict__ h, bf16_t* __restrict__ a) {
+                                                        float* __restrict__ h, bf16_t* __restrict__ a,
+                                                        const float* __restrict__ P, const int* __restrict__ pos,
+                                                        const float* __restrict__ type_row,
+                                                        const float* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 x[MAXV], wv[MAXV];
   load_row(E + (size_t)ids[row] * H, H, lane, x);
+  if (P) {  // (word + token_type) + position, the reference's order of additions (TF:models/bert/modeling_bert.py:100-104)
+    f32x4 y[MAXV];
+    if (type_row) {
+      load_row(type_row, H, lane, y);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) x[i] += y[i];
+    }
+    load_row(P + (size_t)pos[row] * H, H, lane, y);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) x[i] += y[i];
+  }
   load_row(w, H, lane, wv);
-  ln_row(x, wv, H, lane, eps);
+  ln_row(x, wv, H, lane, eps, bias);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane * 4 + 256 * i;
@@ -71,16 +92,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
   }
 }
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ h, const float* __restrict__ w,
+// `of` may alias `h` (in place): a row is fully in registers before anything is written.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const float* __restrict__ w,
                                                          float eps, int H, int rows, bf16_t* __restrict__ ob,
-                                                         float* __restrict__ of) {
+                                                         float* of, const float* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 x[MAXV], wv[MAXV];
   load_row(h + (size_t)row * H, H, lane, x);
   load_row(w, H, lane, wv);
-  ln_row(x, wv, H, lane, eps);
+  ln_row(x, wv, H, lane, eps, bias);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane * 4 + 256 * i;
@@ -110,11 +132,11 @@ __global__ __launch_bounds__(256) void range_pool_kernel(const float* __restrict
   f32x4 acc[MAXV], wv[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  load_row(lnw, H, lane, wv);
+  if (lnw) load_row(lnw, H, lane, wv);
   for (int t = s + wave; t <= e; t += 4) {
     f32x4 x[MAXV];
     load_row(h + (size_t)t * H, H, lane, x);
-    ln_row(x, wv, H, lane, eps);
+    if (lnw) ln_row(x, wv, H, lane, eps);   // post-LN encoders (BERT family) have no final LayerNorm
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) acc[i] += x[i];
   }
@@ -171,14 +193,14 @@ __global__ __launch_bounds__(256) void range_pool_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void ln_classifier_kernel(const float* __restrict__ x_in, const float* __restrict__ lnw,
                                                              float eps, int H, int rows, const float* __restrict__ Wc,
                                                              const float* __restrict__ bc, int num_labels,
-                                                             float* __restrict__ logits) {
+                                                             float* __restrict__ logits, const float* __restrict__ lnb) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 x[MAXV], wv[MAXV];
   load_row(x_in + (size_t)row * H, H, lane, x);
   load_row(lnw, H, lane, wv);
-  ln_row(x, wv, H, lane, eps);
+  ln_row(x, wv, H, lane, eps, lnb);
   for (int c = 0; c < num_labels; ++c) {
     f32x4 wc[MAXV];
     load_row(Wc + (size_t)c * H, H, lane, wc);
@@ -195,18 +217,20 @@ __global__ __launch_bounds__(256) void ln_classifier_kernel(const float* __restr
 }  // namespace
 
 hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows, float* h,
-                           bf16_t* a, hipStream_t stream) {
+                           bf16_t* a, hipStream_t stream, const float* P, const int* pos, const float* type_row,
+                           const float* bias) {
   if (rows <= 0) return hipSuccess;
-  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a);
+  if (H > MAXV * 256 || (H & 3) || (P && !pos)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a, P, pos,
+                     type_row, bias);
   return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows, bf16_t* ob, float* of,
-                            hipStream_t stream) {
+                            hipStream_t stream, const float* bias) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias);
   return hipGetLastError();
 }
 
@@ -221,11 +245,11 @@ hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H,
 }
 
 hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows, const float* Wc,
-                                const float* bc, int num_labels, float* logits, hipStream_t stream) {
+                                const float* bc, int num_labels, float* logits, hipStream_t stream, const float* lnb) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_classifier_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, lnw, eps, H, rows, Wc, bc,
-                     num_labels, logits);
+                     num_labels, logits, lnb);
   return hipGetLastError();
 }
 

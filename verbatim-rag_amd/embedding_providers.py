@@ -5,8 +5,10 @@ Kept: `DenseEmbeddingProvider` / `SparseEmbeddingProvider` ABCs and the exact re
 |w| > 1e-6 (:138-146), `embed_batch -> List[Dict]` keeping exact non-zeros (:148-166), dense
 `List[float]` rows (:73-77).  Replaced: sentence-transformers `SparseEncoder.encode` /
 `SentenceTransformer.encode` (third-party, absent here) by the HIP encoder + fused SPLADE head
-`max_s log1p(relu(mlm_logits))` / CLS-or-mean pooling + L2 normalise, on ModernBERT-backbone
-checkpoints (the BERT-family checkpoints the reference names are a SURVEY 8f "next").
+`max_s log1p(relu(mlm_logits))` / CLS-or-mean pooling + L2 normalise.  `engine` is an
+`EncoderEngine` (ModernBERT backbone) or a `BertEncoderEngine` (BERT / DistilBERT: the checkpoints the
+reference names -- `naver/splade-v3`, `opensearch-neural-sparse-encoding-doc-v2-distill`, bge-base;
+embedding_providers.py:55,120); models with head_dim != 64 (all-MiniLM-L6-v2) are rejected at engine creation.
 """
 from __future__ import annotations
 

@@ -147,6 +147,9 @@ class EncoderEngine:
         )
         self.max_tokens, self.max_seqs, self.max_seq_len, self.max_ranges = max_tokens, max_seqs, max_seq_len, max_ranges
         _lib.check("vrag_encoder_create", self._lib.vrag_encoder_create(C.byref(cfg), C.byref(cw), C.byref(self._h)))
+        self._init_state()
+
+    def _init_state(self) -> None:
         self.qa_labels = 0
         self.token_labels = 0
         self.has_mlm = False
@@ -287,3 +290,105 @@ class EncoderEngine:
         cnt = (C.c_int64 * n)()
         _lib.check("vrag_encoder_read_profile", self._lib.vrag_encoder_read_profile(self._h, ms, cnt, int(reset)))
         return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+
+@dataclass
+class BertShape:
+    """Architecture numbers of a BERT / DistilBERT checkpoint (config.json keys in comments)."""
+
+    vocab_size: int = 30522               # vocab_size
+    hidden_size: int = 768                # hidden_size | dim
+    num_hidden_layers: int = 12           # num_hidden_layers | n_layers
+    num_attention_heads: int = 12         # num_attention_heads | n_heads
+    intermediate_size: int = 3072         # intermediate_size | hidden_dim
+    max_position_embeddings: int = 512
+    norm_eps: float = 1e-12               # layer_norm_eps (DistilBERT hard-codes 1e-12)
+    pad_token_id: int = 0
+    cls_token_id: int = 101
+    sep_token_id: int = 102
+    model_type: str = "bert"              # "bert" | "distilbert"
+
+    @classmethod
+    def bert_base(cls) -> "BertShape":
+        return cls()
+
+    @classmethod
+    def distilbert_base(cls) -> "BertShape":
+        return cls(num_hidden_layers=6, model_type="distilbert")
+
+    @classmethod
+    def from_hf_config(cls, cfg: dict) -> "BertShape":
+        g = cfg.get
+        if g("model_type") == "distilbert":
+            return cls(vocab_size=g("vocab_size", 30522), hidden_size=g("dim", 768), num_hidden_layers=g("n_layers", 6),
+                       num_attention_heads=g("n_heads", 12), intermediate_size=g("hidden_dim", 3072),
+                       max_position_embeddings=g("max_position_embeddings", 512), norm_eps=1e-12,
+                       pad_token_id=g("pad_token_id", 0), model_type="distilbert")
+        return cls(vocab_size=g("vocab_size", 30522), hidden_size=g("hidden_size", 768),
+                   num_hidden_layers=g("num_hidden_layers", 12), num_attention_heads=g("num_attention_heads", 12),
+                   intermediate_size=g("intermediate_size", 3072),
+                   max_position_embeddings=g("max_position_embeddings", 512),
+                   norm_eps=float(g("layer_norm_eps", 1e-12)), pad_token_id=g("pad_token_id", 0), model_type="bert")
+
+
+class BertEncoderEngine(EncoderEngine):
+    """Owner of a `vrag_encoder` handle built by `vrag_bert_encoder_create` (BERT / DistilBERT: post-LN, biased
+    linears, learned positions, GELU MLP).  `weights` uses the flat names produced by
+    `weights.bert_canonical(...)`; every batch entry point of `EncoderEngine` works unchanged."""
+
+    def __init__(self, shape: BertShape, weights: Dict[str, np.ndarray], max_tokens: int = 8192, max_seqs: int = 64,
+                 max_seq_len: int = 512, max_ranges: int = 4096, micro_batch_tokens: int = 0, device: int = 0):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.shape = shape
+        self._h = C.c_void_p()
+        L, H, I = shape.num_hidden_layers, shape.hidden_size, shape.intermediate_size
+        keep: List[np.ndarray] = []
+
+        def get(name, shp=None):
+            if name not in weights:
+                raise KeyError(f"weight '{name}' missing (have e.g. {list(weights)[:4]})")
+            a = _f32(weights[name])
+            if shp is not None and tuple(a.shape) != tuple(shp):
+                raise ValueError(f"{name}: expected shape {tuple(shp)}, got {tuple(a.shape)}")
+            keep.append(a)
+            return a
+
+        def arr(fmt, shp):
+            ptrs = (_FP * L)()
+            for l in range(L):
+                ptrs[l] = _fp(get(fmt.format(l), shp))
+            return ptrs
+
+        cw = _lib.BertWeights()
+        cw.word_embeddings = _fp(get("emb.word", (shape.vocab_size, H)))
+        cw.position_embeddings = _fp(get("emb.pos", (shape.max_position_embeddings, H)))
+        cw.token_type_row = _fp(get("emb.type0", (H,))) if "emb.type0" in weights else None
+        cw.emb_norm_w, cw.emb_norm_b = _fp(get("emb.ln.w", (H,))), _fp(get("emb.ln.b", (H,)))
+        cw.wqkv, cw.bqkv = arr("l{}.wqkv", (3 * H, H)), arr("l{}.bqkv", (3 * H,))
+        cw.wo, cw.bo = arr("l{}.wo", (H, H)), arr("l{}.bo", (H,))
+        cw.attn_norm_w, cw.attn_norm_b = arr("l{}.ln1.w", (H,)), arr("l{}.ln1.b", (H,))
+        cw.w1, cw.b1 = arr("l{}.w1", (I, H)), arr("l{}.b1", (I,))
+        cw.w2, cw.b2 = arr("l{}.w2", (H, I)), arr("l{}.b2", (H,))
+        cw.out_norm_w, cw.out_norm_b = arr("l{}.ln2.w", (H,)), arr("l{}.ln2.b", (H,))
+        cfg = _lib.BertConfig(
+            vocab_size=shape.vocab_size, hidden_size=H, num_layers=L, num_heads=shape.num_attention_heads,
+            intermediate_size=I, max_position_embeddings=shape.max_position_embeddings, norm_eps=shape.norm_eps,
+            pad_token_id=shape.pad_token_id, max_seq_len=min(max_seq_len, shape.max_position_embeddings),
+            max_tokens=max_tokens, max_seqs=max_seqs, max_ranges=max_ranges, micro_batch_tokens=micro_batch_tokens,
+            device=device)
+        self.max_tokens, self.max_seqs, self.max_ranges = max_tokens, max_seqs, max_ranges
+        self.max_seq_len = min(max_seq_len, shape.max_position_embeddings)
+        _lib.check("vrag_bert_encoder_create", self._lib.vrag_bert_encoder_create(C.byref(cfg), C.byref(cw), C.byref(self._h)))
+        self._init_state()
+        if "mlm.dense.w" in weights:
+            self.set_mlm_head_ex(weights["mlm.dense.w"], weights["mlm.dense.b"], weights["mlm.ln.w"], weights["mlm.ln.b"],
+                                 weights.get("mlm.dec.b"), weights.get("mlm.dec.w"))
+
+    def set_mlm_head_ex(self, dense_w, dense_b, norm_w, norm_b, decoder_b, decoder_w=None) -> None:
+        opt = lambda a: _f32(a) if a is not None else None  # noqa: E731
+        d, db, n, nb, b, dw = _f32(dense_w), opt(dense_b), _f32(norm_w), opt(norm_b), opt(decoder_b), opt(decoder_w)
+        p = lambda a: _fp(a) if a is not None else None  # noqa: E731
+        _lib.check("vrag_encoder_set_mlm_head_ex",
+                   self._lib.vrag_encoder_set_mlm_head_ex(self._h, _fp(d), p(db), _fp(n), p(nb), p(dw), p(b)))
+        self.has_mlm = True

@@ -80,12 +80,13 @@ typedef struct vrag_encoder_weights {
  * `opensearch-neural-sparse-encoding-doc-v2-distill`: verbatim_rag/embedding_providers.py:120, README.md:122-125;
  * BAAI/bge-base: embedding_providers.py:55).  Replaces transformers BertModel / DistilBertModel.forward
  * (models/bert/modeling_bert.py, models/distilbert/modeling_distilbert.py) underneath
- * sentence-transformers' SparseEncoder / SentenceTransformer .encode.  head_dim must be 64. */
+ * sentence-transformers' SparseEncoder / SentenceTransformer .encode.  head_dim must be 64 or 32 (32, e.g.
+ * all-MiniLM-L6-v2 -- embedding_providers.py:55 -- runs zero-padded on the head_dim-64 kernels). */
 typedef struct vrag_bert_config {
   int32_t vocab_size;
   int32_t hidden_size;              /* multiple of 128, <= 1024 */
   int32_t num_layers;
-  int32_t num_heads;                /* hidden_size / 64 */
+  int32_t num_heads;                /* hidden_size / 64 or hidden_size / 32 */
   int32_t intermediate_size;        /* multiple of 128 */
   int32_t max_position_embeddings;  /* rows of position_embeddings */
   float norm_eps;                   /* 1e-12 */

@@ -131,12 +131,39 @@ def test_providers_on_bert_engine(base_width):
         assert np.abs(np.asarray(v) - ref).max() < 2e-3
 
 
+def test_head_dim_32_minilm_geometry_vs_oracle():
+    """all-MiniLM-L6-v2 geometry (H=384, 12 heads x 32): heads are zero-padded to 64 inside the library."""
+    from verbatim_rag_amd.engine import BertEncoderEngine
+
+    cfg = B.BertConfig(vocab_size=1024, hidden_size=384, num_hidden_layers=3, num_attention_heads=12,
+                       intermediate_size=1536, max_position_embeddings=256)
+    W = B.random_weights(cfg, seed=9, kind="bert", mlm=False, std=0.04)
+    eng = BertEncoderEngine(_shape(cfg, "bert"), W, max_tokens=2048, max_seqs=8, max_seq_len=256, max_ranges=8)
+    try:
+        rng = np.random.default_rng(4)
+        seqs = [rng.integers(3, cfg.vocab_size, size=n).astype(np.int32) for n in (256, 9, 130, 64)]
+        eng.load_batch(seqs)
+        eng.load_ranges(list(range(4)), [0] * 4, [len(s) - 1 for s in seqs])
+        eng.run()
+        got = eng.read_hidden(final_norm=False)
+        eng.run_pool(True)
+        pooled = eng.read_pool()
+        o = 0
+        for i, s in enumerate(seqs):
+            ref = B.encoder_forward(cfg, W, s)
+            assert np.abs(got[o:o + len(s)] - ref).max() < 3e-2, np.abs(got[o:o + len(s)] - ref).max()
+            assert np.abs(pooled[i] - O.dense_pool(ref, "mean", True)).max() < 2e-3
+            o += len(s)
+    finally:
+        eng.close()
+
+
 def test_rejects_unsupported_shapes():
     from verbatim_rag_amd._lib import VragError
     from verbatim_rag_amd.engine import BertEncoderEngine, BertShape
     from verbatim_rag_amd.weights import random_init_bert
 
-    shp = BertShape(vocab_size=128, hidden_size=384, num_hidden_layers=1, num_attention_heads=12, intermediate_size=1536,
-                    max_position_embeddings=64)   # all-MiniLM-L6-v2 geometry: head_dim 32
-    with pytest.raises(VragError, match="head_dim must be 64"):
+    shp = BertShape(vocab_size=128, hidden_size=128, num_hidden_layers=1, num_attention_heads=8, intermediate_size=256,
+                    max_position_embeddings=64)   # head_dim 16
+    with pytest.raises(VragError, match="head_dim must be 32 or 64"):
         BertEncoderEngine(shp, random_init_bert(shp, mlm=False), max_tokens=256, max_seqs=2, max_seq_len=64, max_ranges=4)

@@ -140,6 +140,8 @@ struct vrag_encoder {
   std::vector<BertLayer> blayers;
   float *neg_ones = nullptr, *ones = nullptr;  // [cap_rows] constants: the QKV bias rides the LayerNorm-fold epilogue
   float *mlm_dense_b = nullptr, *mlm_norm_b = nullptr;
+  int attn_w = 0;       // width of the q / k / v^T / o buffers = num_heads * 64 (> hidden_size when head_dim is 32)
+  float q_scale = 0.125f * 1.4426950408889634f;  // head_dim^-1/2 * log2(e)
   float *cos_g = nullptr, *sin_g = nullptr, *cos_l = nullptr, *sin_l = nullptr;
   // heads
   float *qa_w = nullptr, *qa_b = nullptr;
@@ -484,7 +486,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
 // models/distilbert/modeling_distilbert.py:131-239.
 int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
   const auto& c = e->cfg;
-  const int H = c.hidden_size, I = c.intermediate_size;
+  const int H = c.hidden_size, I = c.intermediate_size, Ha = e->attn_w;
   const int Tp = e->cap_rows;
   const bool fork = e->n_streams > 1 && e->mbs.size() > 1;
   if (fork) {
@@ -512,17 +514,17 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.ln_rstd = e->ones;
         g.ln_s = L.bqkv;
         g.M = M;
-        g.N = 3 * H;
+        g.N = 3 * Ha;
         g.K = H;
-        g.q = e->q + (size_t)r0 * H;
-        g.k = e->k + (size_t)r0 * H;
+        g.q = e->q + (size_t)r0 * Ha;
+        g.k = e->k + (size_t)r0 * Ha;
         g.vt = e->vt + r0;
         g.vt_ld = Tp;
         g.rope_cos = e->cos_g;   // all ones
         g.rope_sin = e->sin_g;   // all zeros
         g.pos = e->d_pos + r0;
-        g.hidden = H;
-        g.q_scale = 0.125f * 1.4426950408889634f;
+        g.hidden = Ha;
+        g.q_scale = e->q_scale;
         ProfScope ps(e, VRAG_PROF_GEMM_QKV, st);
         HIP_TRY(launch_gemm(EPI_QKV_ROPE, g, st));
       }
@@ -536,7 +538,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         ap.blk_seq_len = e->d_blk_len + mb.blk0;
         ap.blk_q0 = e->d_blk_q0 + mb.blk0;
         ap.n_blocks = mb.blk1 - mb.blk0;
-        ap.H = H;
+        ap.H = Ha;
         ap.nh = c.num_heads;
         ap.Tp = Tp;
         ap.window = 0;
@@ -545,11 +547,11 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         GemmParams g{};
-        g.A = e->o + (size_t)r0 * H;
+        g.A = e->o + (size_t)r0 * Ha;
         g.W = L.wo;
         g.M = M;
         g.N = H;
-        g.K = H;
+        g.K = Ha;
         g.out_f32 = h;
         g.bias = L.bo;
         ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
@@ -631,10 +633,12 @@ int init_workspace(vrag_encoder* e) {
   TRY(dev_alloc(e, &e->d_tokseq, R));
   TRY(dev_alloc(e, &e->h, R * H));
   TRY(dev_alloc(e, &e->a, R * H));
-  TRY(dev_alloc(e, &e->q, R * H));
-  TRY(dev_alloc(e, &e->k, R * H));
-  TRY(dev_alloc(e, &e->vt, R * H));
-  TRY(dev_alloc(e, &e->o, R * H));
+  if (e->attn_w <= 0) e->attn_w = H;
+  const size_t Ha = e->attn_w;
+  TRY(dev_alloc(e, &e->q, R * Ha));
+  TRY(dev_alloc(e, &e->k, R * Ha));
+  TRY(dev_alloc(e, &e->vt, R * Ha));
+  TRY(dev_alloc(e, &e->o, R * Ha));
   TRY(dev_alloc(e, &e->act, R * I));
   TRY(dev_alloc(e, &e->f32tmp, R * H));
   TRY(dev_alloc(e, &e->st_part, R * (H / 64) * 2));
@@ -788,7 +792,8 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
   const int H = cfg->hidden_size, I = cfg->intermediate_size, L = cfg->num_layers, V = cfg->vocab_size;
   const int P = cfg->max_position_embeddings;
   ARG_CHECK(H > 0 && H % 128 == 0 && H <= 1024, "hidden_size must be a multiple of 128 and <= 1024 (got %d)", H);
-  ARG_CHECK(cfg->num_heads * 64 == H, "head_dim must be 64: num_heads*64 != hidden_size (%d, %d)", cfg->num_heads, H);
+  ARG_CHECK(cfg->num_heads > 0 && (cfg->num_heads * 64 == H || cfg->num_heads * 32 == H),
+            "head_dim must be 32 or 64 (num_heads %d, hidden_size %d)", cfg->num_heads, H);
   ARG_CHECK(I > 0 && I % 128 == 0, "intermediate_size must be a multiple of 128 (got %d)", I);
   ARG_CHECK(L > 0 && V > 0 && P > 0, "bad layer/vocab/position configuration");
   ARG_CHECK(cfg->max_tokens > 0 && cfg->max_seqs > 0 && cfg->max_seq_len > 0 && cfg->max_ranges > 0,
@@ -806,9 +811,15 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
   }
   HIP_TRY(hipSetDevice(cfg->device));
 
+  // head_dim 32 (all-MiniLM-L6-v2, the reference's default dense model: embedding_providers.py:55) runs on the
+  // head_dim-64 kernels with every head zero-padded to 64: padded q/k dims add 0 to every score, padded v dims
+  // produce zeros that meet zero columns of the padded output projection -- the arithmetic is unchanged.
+  const int hd = H / cfg->num_heads, Ha = cfg->num_heads * 64;
   vrag_encoder* e = new vrag_encoder();
   e->arch = 1;
   e->ln_fold = false;
+  e->attn_w = Ha;
+  e->q_scale = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
   {
     vrag_encoder_config& c = e->cfg;
     c.vocab_size = V;
@@ -839,9 +850,10 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
     if (rc) return fail(rc);   \
   } while (0)
   TRY(init_streams(e));
-  const size_t stage_elems = std::max<size_t>({(size_t)3 * H * H, (size_t)I * H, (size_t)1 << 22});
+  const size_t stage_elems = std::max<size_t>({(size_t)3 * Ha * H, (size_t)I * H, (size_t)1 << 22});
   float* stage = nullptr;
   TRY(dev_alloc(e, &stage, stage_elems, false));
+  std::vector<float> pw, pb, po;   // head-padded copies (head_dim 32 only)
   TRY(upload_f32(e, &e->tok_emb, w->word_embeddings, (size_t)V * H));
   TRY(upload_f32(e, &e->pos_emb, w->position_embeddings, (size_t)P * H));
   if (w->token_type_row) TRY(upload_f32(e, &e->type_row, w->token_type_row, H));
@@ -853,9 +865,28 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
     ARG_CHECK(w->wqkv[l] && w->bqkv[l] && w->wo[l] && w->bo[l] && w->attn_norm_w[l] && w->attn_norm_b[l] && w->w1[l] &&
                   w->b1[l] && w->w2[l] && w->b2[l] && w->out_norm_w[l] && w->out_norm_b[l],
               "null weight pointer in layer %d", l);
-    TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems));
-    TRY(upload_f32(e, &ly.bqkv, w->bqkv[l], (size_t)3 * H));
-    TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
+    const float *wqkv = w->wqkv[l], *bqkv = w->bqkv[l], *wo = w->wo[l];
+    if (hd == 32) {
+      pw.assign((size_t)3 * Ha * H, 0.f);
+      pb.assign((size_t)3 * Ha, 0.f);
+      po.assign((size_t)H * Ha, 0.f);
+      for (int part = 0; part < 3; ++part)
+        for (int hh = 0; hh < cfg->num_heads; ++hh)
+          for (int d = 0; d < 32; ++d) {
+            const size_t src = (size_t)part * H + hh * 32 + d, dst = (size_t)part * Ha + hh * 64 + d;
+            memcpy(&pw[dst * H], wqkv + src * H, (size_t)H * sizeof(float));
+            pb[dst] = bqkv[src];
+          }
+      for (int r = 0; r < H; ++r)
+        for (int hh = 0; hh < cfg->num_heads; ++hh)
+          memcpy(&po[(size_t)r * Ha + hh * 64], wo + (size_t)r * H + hh * 32, 32 * sizeof(float));
+      wqkv = pw.data();
+      bqkv = pb.data();
+      wo = po.data();
+    }
+    TRY(upload_bf16(e, &ly.wqkv, wqkv, 3 * Ha, H, 3 * Ha, 0, stage, stage_elems));
+    TRY(upload_f32(e, &ly.bqkv, bqkv, (size_t)3 * Ha));
+    TRY(upload_bf16(e, &ly.wo, wo, H, Ha, H, 0, stage, stage_elems));
     TRY(upload_f32(e, &ly.bo, w->bo[l], H));
     TRY(upload_f32(e, &ly.ln1_w, w->attn_norm_w[l], H));
     TRY(upload_f32(e, &ly.ln1_b, w->attn_norm_b[l], H));

@@ -8,7 +8,7 @@ Kept: `DenseEmbeddingProvider` / `SparseEmbeddingProvider` ABCs and the exact re
 `max_s log1p(relu(mlm_logits))` / CLS-or-mean pooling + L2 normalise.  `engine` is an
 `EncoderEngine` (ModernBERT backbone) or a `BertEncoderEngine` (BERT / DistilBERT: the checkpoints the
 reference names -- `naver/splade-v3`, `opensearch-neural-sparse-encoding-doc-v2-distill`, bge-base;
-embedding_providers.py:55,120); models with head_dim != 64 (all-MiniLM-L6-v2) are rejected at engine creation.
+embedding_providers.py:55,120; head_dim 64, or 32 as in the default dense model all-MiniLM-L6-v2).
 """
 from __future__ import annotations
 

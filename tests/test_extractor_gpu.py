@@ -182,3 +182,32 @@ def test_cross_query_batching_equals_per_query_calls(setup):
     batched = ext.extract_spans_batch(qs, rs)
     assert batched == [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
     assert batched[0] == run["spans"]
+
+
+def test_coalescing_scheduler_on_the_gpu_extractor(setup):
+    """Concurrent per-query calls (the reference's to_thread pattern) coalesced into shared GPU batches."""
+    import threading
+
+    from verbatim_rag_amd.extractors import CoalescingSpanExtractor
+
+    cfg, w, z, eng, ext, fx = setup
+    run = fx["extract_e2e"]["runs"][0]
+    ext.threshold = run["threshold"]
+    results = [types.SimpleNamespace(text=t) for t in run["texts"]]
+    qs = [run["question"], "Who built the iron bridge?", "When was it opened?", run["question"]] * 4
+    rs = [results, results[:3], results[2:], results[1:4]] * 4
+    want = [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
+    co = CoalescingSpanExtractor(ext, max_wait_ms=20.0)
+    try:
+        got = [None] * len(qs)
+
+        def work(i):
+            got[i] = co.extract_spans(qs[i], rs[i])
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert got == want
+        assert co.batches_run < len(qs)
+    finally:
+        co.close()

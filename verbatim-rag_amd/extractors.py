@@ -17,7 +17,9 @@ import json
 import logging
 import os
 import threading
+import time
 from abc import ABC, abstractmethod
+from concurrent.futures import Future
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -383,3 +385,91 @@ class GpuModelSpanExtractor(SpanExtractor):
             relevant[context] = token_spans_to_char_spans(p, offsets, context, self.threshold, self.min_span_chars,
                                                           self.merge_gap_chars)
         return relevant
+
+
+class CoalescingSpanExtractor(SpanExtractor):
+    """Host scheduler in front of an extractor that offers `extract_spans_batch`.
+
+    The reference calls `extract_spans` once per query, from `asyncio.to_thread` workers when it serves
+    concurrent requests (extractors.py:48-54, streaming.py:98-100); each call is a handful of chunks
+    (k = 5), far too little to fill the GPU.  This wrapper keeps the reference's per-query interface and
+    coalesces calls that arrive within `max_wait_ms` of each other (or until `max_pairs` (question, chunk)
+    pairs are waiting) into one `extract_spans_batch` call on a background thread.  Results are identical to
+    per-call extraction (cross-query batching is bit-neutral: packed sequences never see each other).
+    A failing batch is retried query by query so one bad request cannot fail its neighbours.
+    """
+
+    def __init__(self, inner: Any, max_wait_ms: float = 2.0, max_pairs: int = 512):
+        if not hasattr(inner, "extract_spans_batch"):
+            raise TypeError("inner extractor must provide extract_spans_batch(questions, results_per_question)")
+        self.inner = inner
+        self.max_wait = max(0.0, float(max_wait_ms)) / 1e3
+        self.max_pairs = int(max_pairs)
+        self._cv = threading.Condition()
+        self._queue: List[Tuple[str, List[Any], "Future"]] = []
+        self._closed = False
+        self.batches_run = 0          # observability: batches issued / queries served
+        self.queries_served = 0
+        self._thread = threading.Thread(target=self._loop, name="vrag-coalescer", daemon=True)
+        self._thread.start()
+
+    # ------------------------------------------------------------------ SpanExtractor API
+    def extract_spans(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
+        fut: Future = Future()
+        with self._cv:
+            if self._closed:
+                raise RuntimeError("CoalescingSpanExtractor is closed")
+            self._queue.append((question, list(search_results), fut))
+            self._cv.notify_all()
+        return fut.result()
+
+    def close(self) -> None:
+        with self._cv:
+            self._closed = True
+            self._cv.notify_all()
+        self._thread.join(timeout=5.0)
+
+    # ------------------------------------------------------------------ scheduler thread
+    def _pending_pairs(self) -> int:
+        return sum(len(r) for _q, r, _f in self._queue)
+
+    def _loop(self) -> None:
+        while True:
+            with self._cv:
+                while not self._queue and not self._closed:
+                    self._cv.wait()
+                if not self._queue and self._closed:
+                    return
+                # linger: give concurrent callers `max_wait` to join the batch
+                deadline = time.monotonic() + self.max_wait
+                while self._pending_pairs() < self.max_pairs and not self._closed:
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        break
+                    self._cv.wait(timeout=left)
+                batch, pairs = [], 0
+                while self._queue and (not batch or pairs + len(self._queue[0][1]) <= self.max_pairs):
+                    item = self._queue.pop(0)
+                    batch.append(item)
+                    pairs += len(item[1])
+            self._run(batch)
+
+    def _run(self, batch) -> None:
+        self.batches_run += 1
+        try:
+            outs = self.inner.extract_spans_batch([b[0] for b in batch], [b[1] for b in batch])
+            if len(outs) != len(batch):
+                raise RuntimeError("extract_spans_batch returned %d results for %d queries" % (len(outs), len(batch)))
+            for (_q, _r, fut), out in zip(batch, outs):
+                self.queries_served += 1
+                fut.set_result(out)
+        except Exception as exc:
+            logger.error("coalesced extraction failed (%s); retrying per query", exc)
+            for q, r, fut in batch:
+                if fut.done():
+                    continue
+                try:
+                    fut.set_result(self.inner.extract_spans(q, r))
+                except Exception as exc2:
+                    fut.set_exception(exc2)
+                self.queries_served += 1

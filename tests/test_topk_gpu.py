@@ -144,6 +144,18 @@ def test_vector_store_semantics():
     r = st.query(dense_query=q, sparse_query=sparse[3], top_k=4, hybrid_weights={"dense": 0.7, "sparse": 0.3, "full_text": 1})
     assert len(r) == 4
     assert len(st.query(top_k=7)) == 7     # filter-only browse
+    # persistence round trip: same hits (ids, scores, text, metadata); the deleted row stays deleted
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        st.save(d)
+        st2 = GpuVectorStore.load(d)
+        for kw in (dict(dense_query=q, top_k=5, search_type="dense"), dict(sparse_query=sparse[5], top_k=4, search_type="sparse"),
+                   dict(dense_query=q, sparse_query=sparse[9], top_k=6, search_type="hybrid"),
+                   dict(dense_query=q, top_k=5, search_type="dense", filter='metadata["document_id"] == "d1"')):
+            a, b = st.query(**kw), st2.query(**kw)
+            assert [(x.id, x.score, x.text, x.metadata) for x in a] == [(x.id, x.score, x.text, x.metadata) for x in b]
+        assert all(x.id != "id17" for x in st2.query(top_k=400))
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(10000, 768, 40, 10), (5000, 128, 8, 16), (130, 256, 33, 5), (300000, 384, 64, 10)])

@@ -421,3 +421,57 @@ class GpuVectorStore(VectorStore):
 
     def get_document(self, document_id: str):
         return None
+
+    # -------------------------------------------------------------- persistence
+    def save(self, path: str) -> None:
+        """Writes the store to a directory: `vectors.npz` (packed unit dense rows, sparse CSR) and `rows.json`
+        (ids, texts, enhanced texts, metadata; deleted rows are dropped).  The reference persists through the
+        Milvus-lite database file (milvus_local.py:39-56); this is the GPU store's own on-disk format."""
+        import json
+        import os
+
+        os.makedirs(path, exist_ok=True)
+        keep = [i for i, a in enumerate(self._alive) if a]
+        arrays: Dict[str, np.ndarray] = {}
+        if self.enable_dense:
+            arrays["dense"] = (np.stack([self._dense_rows[i] for i in keep]).astype(np.float32) if keep
+                               else np.zeros((0, self.dense_dim or 0), np.float32))
+        if self.enable_sparse:
+            indptr, indices, values = dicts_to_csr([self._sparse_rows[i] for i in keep])
+            arrays.update(sp_indptr=indptr, sp_indices=indices, sp_values=values)
+        np.savez(os.path.join(path, "vectors.npz"), **arrays)
+        with open(os.path.join(path, "rows.json"), "w", encoding="utf-8") as f:
+            json.dump({"format": 1, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
+                       "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse,
+                       "dense_dtype": self.dense_dtype, "ids": [self._ids[i] for i in keep],
+                       "texts": [self._texts[i] for i in keep], "enhanced_texts": [self._enh[i] for i in keep],
+                       "metadatas": [self._meta[i] for i in keep]}, f, ensure_ascii=False)
+
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "GpuVectorStore":
+        import json
+        import os
+
+        with open(os.path.join(path, "rows.json"), encoding="utf-8") as f:
+            rows = json.load(f)
+        if rows.get("format") != 1:
+            raise ValueError(f"{path}: unknown GpuVectorStore format {rows.get('format')!r}")
+        st = cls(dense_dim=rows["dense_dim"], sparse_vocab=rows["sparse_vocab"], enable_dense=rows["enable_dense"],
+                 enable_sparse=rows["enable_sparse"], dense_dtype=rows["dense_dtype"], device=device)
+        z = np.load(os.path.join(path, "vectors.npz"))
+        n = len(rows["ids"])
+        st._ids, st._texts, st._enh = list(rows["ids"]), list(rows["texts"]), list(rows["enhanced_texts"])
+        st._meta = [dict(m) for m in rows["metadatas"]]
+        st._alive = [True] * n
+        if st.enable_dense:
+            d = z["dense"]
+            if d.shape[0] != n:
+                raise ValueError(f"{path}: {d.shape[0]} dense rows for {n} ids")
+            st._dense_rows = [d[i] for i in range(n)]
+        if st.enable_sparse:
+            ip, ix, vv = z["sp_indptr"], z["sp_indices"], z["sp_values"]
+            if len(ip) != n + 1:
+                raise ValueError(f"{path}: sparse indptr has {len(ip)} entries for {n} ids")
+            st._sparse_rows = [{int(k): float(v) for k, v in zip(ix[ip[i]:ip[i + 1]], vv[ip[i]:ip[i + 1]])} for i in range(n)]
+        st._dirty = n > 0
+        return st

@@ -108,6 +108,8 @@ def main() -> None:
     ap.add_argument("--micro-batch-tokens", type=int, default=int(os.environ.get("VRAG_MICRO_BATCH", "65536")))
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--model", choices=["base", "large"], default="base",
+                    help="base = BASELINE configs[1] (the metric); large = ModernBERT-large geometry (configs[4] extractor), informational")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +130,7 @@ def main() -> None:
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
     from verbatim_rag_amd.weights import random_init, random_qa_head
 
-    shape = ModernBertShape.base()
+    shape = ModernBertShape.base() if args.model == "base" else ModernBertShape.large()
     weights = random_init(shape, seed=1234)
     qa_w, qa_b = random_qa_head(shape)
     n_chunks = args.chunks
@@ -254,10 +256,10 @@ def main() -> None:
             "value": value, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ModernBERT-base span extractor, batch 256 chunks x 512 tok, single query, 16 sentences/chunk",
+            "config": {"workload": ("BASELINE configs[1]: ModernBERT-base span extractor, batch 256 chunks x 512 tok, single query, 16 sentences/chunk" if args.model == "base" else "ModernBERT-large geometry (BASELINE configs[4] extractor), batch 256 chunks x 512 tok, 16 sentences/chunk"),
                        "chunks_per_gpu_per_step": n_chunks, "seq_len": SEQ, "sentences_per_chunk": N_SENT,
                        "micro_batch_tokens": args.micro_batch_tokens, "parallelism": f"dp{world} (independent chunks, no collective)",
-                       "weights": "random-init ModernBERT-base (seed 1234), bf16 MFMA operands, fp32 accumulate/residual/LN/softmax"},
+                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), bf16 MFMA operands, fp32 accumulate/residual/LN/softmax"},
             "sentence_classifications_per_s": value * N_SENT,
             "model_tflops": value * chunk_flops(shape) / 1e12,
             "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),

@@ -115,8 +115,8 @@ def test_wide_tile_gemm_config(tiny):
 
 
 def test_large_shapes_two_layers():
-    """ModernBERT-large geometry (H=1024, I=2624: N=5248 is not a multiple of 256 -> 128x128 tiles;
-    K=2624 = 41 x 64), 2 layers, random weights, vs the oracle."""
+    """ModernBERT-large geometry (H=1024, I=2624: the GeGLU width is zero-padded to 2688 inside the library so
+    2I = 5376 is whole 256-wide tiles; mlp.Wo gets zero columns), 2 layers, random weights, vs the oracle."""
     cfg = O.EncoderConfig(vocab_size=1024, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
                           intermediate_size=2624, pad_token_id=0, cls_token_id=1, sep_token_id=2)
     w = O.random_weights(cfg, seed=21)

@@ -42,13 +42,16 @@ __global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __re
   __shared__ float red[4];
   const int r = blockIdx.x;
   int s = r;
+  bool valid = true;
   if (interleave_I > 0) {
     const int g = r >> 6, w = r & 63;
-    s = w < 32 ? g * 32 + w : interleave_I + g * 32 + (w - 32);
+    const int f = g * 32 + (w & 31);       // feature index; rows with f >= I are zero padding
+    valid = f < interleave_I;
+    s = w < 32 ? f : interleave_I + f;
   }
   float acc = 0.f;
   for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-    float v = (r < rows_dst && s < rows_src) ? src[(size_t)s * cols + c] : 0.f;
+    float v = (valid && r < rows_dst && s < rows_src) ? src[(size_t)s * cols + c] : 0.f;
     if (col_scale) v *= col_scale[c];
     const bf16_t b = (bf16_t)v;
     dst[(size_t)r * cols + c] = b;
@@ -140,6 +143,7 @@ struct vrag_encoder {
   std::vector<BertLayer> blayers;
   float *neg_ones = nullptr, *ones = nullptr;  // [cap_rows] constants: the QKV bias rides the LayerNorm-fold epilogue
   float *mlm_dense_b = nullptr, *mlm_norm_b = nullptr;
+  int i_pad = 0;        // GeGLU width padded to a multiple of 128 (2*i_pad = whole 256-wide GEMM tiles)
   int attn_w = 0;       // width of the q / k / v^T / o buffers = num_heads * 64 (> hidden_size when head_dim is 32)
   float q_scale = 0.125f * 1.4426950408889634f;  // head_dim^-1/2 * log2(e)
   float *cos_g = nullptr, *sin_g = nullptr, *cos_l = nullptr, *sin_l = nullptr;
@@ -327,7 +331,7 @@ int check_ready(vrag_encoder* e) {
 
 int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
   const auto& c = e->cfg;
-  const int H = c.hidden_size, I = c.intermediate_size;
+  const int H = c.hidden_size, I = e->i_pad;   // padded GeGLU width (zero rows of Wi / zero columns of mlp.Wo)
   const int Tp = e->cap_rows;
   // Micro-batches touch disjoint rows of every buffer, so with n_streams == 2 they are issued on two
   // internal streams: the HBM-bound kernels of one (LayerNorm, epilogue tails) overlap the MFMA-bound
@@ -639,7 +643,8 @@ int init_workspace(vrag_encoder* e) {
   TRY(dev_alloc(e, &e->k, R * Ha));
   TRY(dev_alloc(e, &e->vt, R * Ha));
   TRY(dev_alloc(e, &e->o, R * Ha));
-  TRY(dev_alloc(e, &e->act, R * I));
+  if (e->i_pad <= 0) e->i_pad = I;
+  TRY(dev_alloc(e, &e->act, R * (size_t)e->i_pad));
   TRY(dev_alloc(e, &e->f32tmp, R * H));
   TRY(dev_alloc(e, &e->st_part, R * (H / 64) * 2));
   TRY(dev_alloc(e, &e->ln_mu, R));
@@ -750,9 +755,12 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   if (const char* lf = getenv("VRAG_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
 
   // ---- weights
-  const size_t stage_elems = std::max<size_t>({(size_t)3 * H * H, (size_t)2 * I * H, (size_t)1 << 22});
+  const int Ip = (int)align_up(I, 128);
+  e->i_pad = Ip;
+  const size_t stage_elems = std::max<size_t>({(size_t)3 * H * H, (size_t)2 * Ip * H, (size_t)1 << 22});
   float* stage = nullptr;
   TRY(dev_alloc(e, &stage, stage_elems, false));
+  std::vector<float> wo_pad;  // mlp.Wo with zero columns for the padded GeGLU features
   TRY(upload_f32(e, &e->tok_emb, w->tok_embeddings, (size_t)V * H));
   TRY(upload_f32(e, &e->emb_norm, w->emb_norm, H));
   TRY(upload_f32(e, &e->final_norm, w->final_norm, H));
@@ -766,9 +774,15 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems,
                     fold && l > 0 ? ly.attn_norm : nullptr, fold && l > 0 ? &ly.s_qkv : nullptr));
     TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
-    TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * I, I, stage, stage_elems, fold ? ly.mlp_norm : nullptr,
+    TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * Ip, I, stage, stage_elems, fold ? ly.mlp_norm : nullptr,
                     fold ? &ly.s_wi : nullptr));
-    TRY(upload_bf16(e, &ly.wo_mlp, w->wo_mlp[l], H, I, H, 0, stage, stage_elems));
+    const float* wo2 = w->wo_mlp[l];
+    if (Ip != I) {
+      wo_pad.assign((size_t)H * Ip, 0.f);
+      for (int r = 0; r < H; ++r) memcpy(&wo_pad[(size_t)r * Ip], wo2 + (size_t)r * I, (size_t)I * sizeof(float));
+      wo2 = wo_pad.data();
+    }
+    TRY(upload_bf16(e, &ly.wo_mlp, wo2, H, Ip, H, 0, stage, stage_elems));
   }
   {
     std::vector<float> cs, sn;

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -65,7 +66,8 @@ __device__ __forceinline__ void insert_key(u64* list, int k, u64 key) {
 
 // ------------------------------------------------------------------------------------ dense
 constexpr int DQT = 4;        // queries per pass
-constexpr int DROWS_WG = 512;   // rows per workgroup (>= 8 workgroups per CU on a 1M-row shard)
+constexpr int DROWS_MIN = 32;    // rows per workgroup iteration; rows per workgroup = a multiple of this, chosen at launch
+constexpr int DENSE_WGS = 1536;  // target grid: 256 CUs x 6 resident workgroups -> one balanced round, no tail
 
 // QT queries per pass (1: query slice lives in registers; 4: in LDS), DIMC = dim/128 16-byte chunks per
 // lane per row when known at compile time (0 = runtime loop).  Two rows per 16-lane group are in
@@ -73,7 +75,7 @@ constexpr int DROWS_WG = 512;   // rows per workgroup (>= 8 workgroups per CU on
 template <bool F32, int QT, int DIMC>
 __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict__ rows_v, long long n_rows, int dim,
                                                           const float* __restrict__ queries, int nq, int q0,
-                                                          int k, u64* __restrict__ cand) {
+                                                          int k, u64* __restrict__ cand, int rows_per_wg) {
   // LDS: queries [QT][dim] fp32, per 16-lane group lists [16 groups][QT][k]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);
@@ -99,12 +101,16 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict_
       for (int j = 0; j < EPC; ++j) qreg[i * EPC + j] = sq[gl * EPC + i * CSTR + j];
   }
 
-  const long long r_begin = (long long)blockIdx.x * DROWS_WG;
-  const long long r_end = min(n_rows, r_begin + DROWS_WG);
+  // rows_per_wg > 0: this workgroup owns the contiguous range [b*rows_per_wg, +rows_per_wg);
+  // rows_per_wg == 0: grid-stride over 32-row blocks (all workgroups sweep the shard front to back together)
+  const bool strided = rows_per_wg == 0;
+  const long long r_begin = (long long)blockIdx.x * (strided ? DROWS_MIN : rows_per_wg);
+  const long long r_end = strided ? n_rows : min(n_rows, r_begin + rows_per_wg);
   u64* mylist = lists + (size_t)grp * QT * k;
   const size_t esz = F32 ? 4 : 2;
   constexpr int RSTEP = QT == 1 ? 32 : 16;  // the LDS-query path keeps one row per group in flight (LDS-bound)
-  for (long long r = r_begin + grp; r < r_end; r += RSTEP) {
+  const long long r_step = strided ? (long long)gridDim.x * DROWS_MIN : RSTEP;
+  for (long long r = r_begin + grp; r < r_end; r += r_step) {
     const bool has2 = QT == 1 && r + 16 < r_end;
     const char* row0 = reinterpret_cast<const char*>(rows_v) + (size_t)r * dim * esz + (size_t)gl * 16;
     const char* row1 = has2 ? row0 + (size_t)16 * dim * esz : row0;
@@ -194,14 +200,23 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict_
   }
 }
 
+// rows per workgroup of the streaming (non-MFMA) kernels: the shard is cut into <= DENSE_WGS equal contiguous ranges
+static int dense_rows_per_wg(long long n) {
+  static const int target = getenv("VRAG_TOPK_WGS") ? std::max(1, atoi(getenv("VRAG_TOPK_WGS"))) : DENSE_WGS;
+  const long long per = (n + target - 1) / target;
+  return (int)std::max<long long>(DROWS_MIN, (per + DROWS_MIN - 1) / DROWS_MIN * DROWS_MIN);
+}
+
 template <bool F32>
 static hipError_t dense_launch_pass(const void* rows, long long n, int dim, const float* dq, int nq, int q0, int qt, int k,
                                     u64* cand, int n_wg, hipStream_t st) {
+  static const bool strided = getenv("VRAG_TOPK_STRIDED") != nullptr;
+  const int per = (strided && qt == 1) ? 0 : dense_rows_per_wg(n);
   const size_t lds = (size_t)qt * dim * sizeof(float) + (size_t)16 * qt * k * sizeof(u64);
   const int cstr = F32 ? 64 : 128;
   const int dimc = dim % cstr == 0 ? dim / cstr : -1;
 #define VRAG_DENSE_CASE(QT_, DC_)                                                                               \
-  hipLaunchKernelGGL((dense_topk_kernel<F32, QT_, DC_>), dim3(n_wg), dim3(256), lds, st, rows, n, dim, dq, nq, q0, k, cand)
+  hipLaunchKernelGGL((dense_topk_kernel<F32, QT_, DC_>), dim3(n_wg), dim3(256), lds, st, rows, n, dim, dq, nq, q0, k, cand, per)
   if (qt == 1) {
     if (dimc == 6) VRAG_DENSE_CASE(1, 6);
     else if (dimc == 3) VRAG_DENSE_CASE(1, 3);
@@ -365,7 +380,7 @@ static bool dense_use_mfma(int dtype, int dim, int nq, int k) {
          (size_t)MQ * dim * 2 + MSLOTS * 16384 + (size_t)256 * k * 8 <= 160 * 1024;
 }
 static int dense_n_wg(int dtype, int dim, int nq, int k, long long size) {
-  const int per = dense_use_mfma(dtype, dim, nq, k) ? MROWS_WG : DROWS_WG;
+  const int per = dense_use_mfma(dtype, dim, nq, k) ? MROWS_WG : dense_rows_per_wg(size);
   return (int)std::max<long long>(1, (size + per - 1) / per);
 }
 
@@ -429,17 +444,24 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
     const float* v = vals + off + lane;
     float acc = 0.f;
     int j = 0;
-    for (; j + 4 <= len; j += 4) {
-      unsigned short ci[4];
-      float vi[4];
+    // 16 then 4 terms per step: all loads of a step are issued before the (strictly sequential, term-order)
+    // fmaf chain consumes them -- 32 loads in flight per lane keep enough bytes outstanding per CU.
+    auto steps = [&](auto un) {
+      constexpr int U = decltype(un)::value;
+      for (; j + U <= len; j += U) {
+        unsigned short ci[U];
+        float vi[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        ci[u] = c[(size_t)(j + u) * 64];
-        vi[u] = v[(size_t)(j + u) * 64];
+        for (int u = 0; u < U; ++u) {
+          ci[u] = __builtin_nontemporal_load(c + (size_t)(j + u) * 64);
+          vi[u] = __builtin_nontemporal_load(v + (size_t)(j + u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __fmaf_rn(vi[u], LDSQ ? sq[ci[u]] : qv[ci[u]], acc);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __fmaf_rn(vi[u], LDSQ ? sq[ci[u]] : qv[ci[u]], acc);
-    }
+    };
+    steps(std::integral_constant<int, 16>{});
+    steps(std::integral_constant<int, 4>{});
     for (; j < len; ++j) acc = __fmaf_rn(v[(size_t)j * 64], LDSQ ? sq[c[(size_t)j * 64]] : qv[c[(size_t)j * 64]], acc);
     const long long doc = (long long)s * 64 + lane;  // position in nnz-sorted order
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
@@ -479,7 +501,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
 
 // ------------------------------------------------------------------------------------ merge
 // One workgroup per query: k rounds of workgroup-wide arg-max over the candidate keys.
-__global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
+__global__ __launch_bounds__(256) void topk_merge_scan_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
                                                           u64* __restrict__ out) {
   __shared__ u64 red[4];
   __shared__ u64 last;
@@ -513,6 +535,71 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
       break;
     }
   }
+}
+
+// Fast merge for k <= MERGE_KMAX: every thread folds whole per-workgroup lists (sorted descending, so a list is
+// abandoned at its first key that cannot enter) into a private sorted top-k in LDS -- the candidates are read
+// once -- then k rounds of "largest list head wins" across the 256 private lists.
+constexpr int MERGE_KMAX = 32;
+__global__ __launch_bounds__(256) void topk_merge_lists_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
+                                                                u64* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char msm[];
+  u64* lists = reinterpret_cast<u64*>(msm);          // [256][k]
+  __shared__ u64 red[4];
+  __shared__ int red_t[4];
+  __shared__ int winner;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  u64* mine = lists + (size_t)tid * k;
+  for (int i = 0; i < k; ++i) mine[i] = 0ull;
+  for (int wg = tid; wg < n_wg; wg += 256) {
+    const u64* src = cand + ((size_t)wg * nq + q) * k;
+    for (int j = 0; j < k; ++j) {
+      const u64 v = src[j];
+      if (v <= mine[k - 1]) break;     // the rest of this (sorted) list is smaller still
+      insert_key(mine, k, v);
+    }
+  }
+  int head = 0;
+  for (int i = 0; i < k; ++i) {
+    u64 best = head < k ? mine[head] : 0ull;
+    int bt = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const u64 ob = __shfl_xor(best, o, 64);
+      const int ot = __shfl_xor(bt, o, 64);
+      if (ob > best) {
+        best = ob;
+        bt = ot;
+      }
+    }
+    if (lane == 0) {
+      red[wave] = best;
+      red_t[wave] = bt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      u64 b = red[0];
+      int t = red_t[0];
+      for (int w = 1; w < 4; ++w)
+        if (red[w] > b) {
+          b = red[w];
+          t = red_t[w];
+        }
+      out[(size_t)q * k + i] = b;          // 0 once every list is exhausted
+      winner = b ? t : -1;
+    }
+    __syncthreads();
+    if (winner == tid) ++head;              // keys are unique per (score, row): exactly one owner
+    __syncthreads();
+  }
+}
+
+static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st) {
+  if (k <= MERGE_KMAX)
+    hipLaunchKernelGGL(topk_merge_lists_kernel, dim3(nq), dim3(256), (size_t)256 * k * sizeof(u64), st, cand, n_wg, nq, k, out);
+  else
+    hipLaunchKernelGGL(topk_merge_scan_kernel, dim3(nq), dim3(256), 0, st, cand, n_wg, nq, k, out);
+  return hipGetLastError();
 }
 
 }  // namespace vrag
@@ -701,7 +788,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
   } else {
     HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st));
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), 0, st, ix->d_cand, n_wg, nq, k, ix->d_out);
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
     HIP_TRY(hipGetLastError());
   }
   std::vector<u64> keys((size_t)nq * k);
@@ -723,7 +810,7 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k, "scratch too small");
   const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
   HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st));
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), 0, st, ix->d_cand, n_wg, nq, k, ix->d_out);
+  HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }
@@ -858,7 +945,7 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
                          slices_per_wg, ix->d_cand);
     HIP_TRY(hipGetLastError());
   }
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), 0, st, ix->d_cand, n_wg, nq, k, ix->d_out);
+  HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }

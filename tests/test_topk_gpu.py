@@ -158,10 +158,12 @@ def test_vector_store_semantics():
         assert all(x.id != "id17" for x in st2.query(top_k=400))
 
 
-@pytest.mark.parametrize("n,dim,nq,k", [(10000, 768, 40, 10), (5000, 128, 8, 16), (130, 256, 33, 5), (300000, 384, 64, 10)])
+@pytest.mark.parametrize("n,dim,nq,k", [(10000, 768, 40, 10), (5000, 128, 8, 16), (130, 256, 33, 5), (300000, 384, 64, 10),
+                                         (200000, 768, 33, 16), (140000, 1024, 5, 3)])
 def test_dense_topk_batched_mfma_path_exact(n, dim, nq, k):
     """>= 8 queries, bf16 rows, k <= 16: 32 queries per pass on the matrix cores (queries rounded to bf16;
-    dyadic-grid queries are exact in bf16, so indices and scores must equal the oracle bit for bit)."""
+    dyadic-grid queries are exact in bf16, so indices and scores must equal the oracle bit for bit).  Shards of
+    >= 131 072 rows at dim 384 / 768 / 1024 take the two-pass route (prefix pass seeds the entry thresholds)."""
     from verbatim_rag_amd.vector_stores import DenseShard
 
     rng = np.random.default_rng(n + nq)

@@ -375,18 +375,249 @@ __global__ __launch_bounds__(256) void dense_topk_mfma_kernel(const bf16_t* __re
   }
 }
 
+// Second generation of the batched kernel (dim = 384 / 768 / 1024): the 32 query columns live in REGISTERS as
+// MFMA B-operand fragments (KT*4 x 16 bytes per lane; one wave per SIMD, so up to 512 VGPRs are available), which
+// frees the whole LDS for the row ring: 8 slots x 16 KiB, six 128-row x 64-dim tiles (96 KiB) in flight per CU
+// instead of three -- the kernel is bound by bytes in flight, not by the matrix pipe (~10 % busy).  The shard is
+// cut into <= 256 equal ranges (one resident workgroup per CU, one balanced round).
+constexpr int M2SLOTS = 8;
+template <int KT>
+__global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* __restrict__ rows, long long row_lo,
+                                                                   long long n_rows /* = end of this launch's row range */,
+                                                                   const float* __restrict__ queries, int nq, int q0, int k,
+                                                                   u64* __restrict__ cand, int rows_per_wg,
+                                                                   u64* __restrict__ thr) {
+  constexpr int DIM = KT * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                                               // M2SLOTS x 16 KiB
+  u64* lists = reinterpret_cast<u64*>(ring + M2SLOTS * 16384);      // [256 lanes][k]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // query (q0 + l31) as B-operand fragments: k-slots 8*hi .. 8*hi+7 of step s <-> dims 16*s + 8*hi + j (bf16-rounded)
+  bf16x8 qf[KT * 4];
+  {
+    const bool live = q0 + l31 < nq;
+    const float* qrow = queries + (size_t)(live ? q0 + l31 : 0) * DIM + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < KT * 4; ++s) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        a = *reinterpret_cast<const f32x4*>(qrow + 16 * s);
+        b = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qf[s][j] = (bf16_t)a[j];
+        qf[s][4 + j] = (bf16_t)b[j];
+      }
+    }
+  }
+  // retire the plain loads before any LDS-DMA is in flight (a later compiler-inserted vmcnt(0) would drain the ring)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KT * 4; ++s) asm volatile("" : "+v"(qf[s]));
+
+  const long long r_begin = row_lo + (long long)blockIdx.x * rows_per_wg;
+  const long long r_end = min(n_rows, r_begin + rows_per_wg);
+  const int n_groups = (int)((r_end - r_begin + 127) / 128);
+  const int T = n_groups * KT;
+
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    soff[i] = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
+  }
+  int sg = 0, skt = 0, st_t = 0;
+  auto stage_next = [&]() {
+    char* slot = ring + (st_t & (M2SLOTS - 1)) * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const long long gr = min(r_begin + (long long)sg * 128 + row, n_rows - 1);
+      glds16(rows + (size_t)gr * DIM + skt * 64 + soff[i], slot + (wave * 32 + i * 8) * 128);
+    }
+    ++st_t;
+    if (++skt == KT) {
+      skt = 0;
+      ++sg;
+    }
+  };
+  for (int t = 0; t < min(T, M2SLOTS - 1); ++t) stage_next();
+
+  u64* mylist = lists + (size_t)tid * k;
+  for (int i = 0; i < k; ++i) mylist[i] = 0ull;
+  u64 kth = 0ull;
+  __syncthreads();
+
+  const int fsw = (l31 >> 1) & 7;
+  int t = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      // tile t landed (this wave's share); up to M2SLOTS-2 later tiles (4 DMA instructions each) stay in flight
+      const int ahead = min(M2SLOTS - 2, T - 1 - t);
+      if (ahead >= 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (st_t < T) stage_next();   // into the slot of tile t-1, which every wave finished before the barrier
+      const char* sA = ring + (t & (M2SLOTS - 1)) * 16384 + (wave * 32 + l31) * 128;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + (((2 * s2 + hi) ^ fsw) << 4));
+        if (s2 & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[kt * 4 + s2], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[kt * 4 + s2], acc0, 0, 0, 0);
+      }
+      ++t;
+    }
+    // 16 row scores of query (q0 + l31): private filtered insertion.  The entry threshold is shared through
+    // thr[query] (global, atomicMax of every FULL list's k-th key, all workgroups): a key below the k-th key of
+    // any list of its query cannot be in the query's top-k, so the union of the lists still contains it, while
+    // the number of (divergent, LDS read-modify-write) insertions drops from ~k ln(n) per list to per shard.
+    const long long rb = r_begin + (long long)g * 128 + wave * 32 + 4 * hi;
+    if (q0 + l31 < nq) {
+      const u64 shared = __hip_atomic_load(thr + q0 + l31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u64 bar = shared > kth ? shared : kth;
+      bool changed = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = rb + (r & 3) + 8 * (r >> 2);
+        if (row < r_end) {
+          const u64 key = make_key(acc0[r] + acc1[r], (unsigned)row);
+          if (key > bar) {
+            insert_key(mylist, k, key);
+            kth = mylist[k - 1];
+            bar = kth > bar ? kth : bar;
+            changed = true;
+          }
+        }
+      }
+      if (changed && kth > shared) atomicMax(reinterpret_cast<unsigned long long*>(thr + q0 + l31), (unsigned long long)kth);
+    }
+  }
+  __syncthreads();
+  // per query: 8 sorted lists (4 waves x 2 halves) -> k best
+  if (tid < MQ && q0 + tid < nq) {
+    int head[8];
+    for (int gg = 0; gg < 8; ++gg) head[gg] = 0;
+    u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
+    for (int i = 0; i < k; ++i) {
+      u64 best = 0ull;
+      int bg = -1;
+      for (int gg = 0; gg < 8; ++gg) {
+        if (head[gg] < k) {
+          const int src_lane = (gg >> 1) * 64 + (gg & 1) * 32 + tid;
+          const u64 v = lists[(size_t)src_lane * k + head[gg]];
+          if (v > best) {
+            best = v;
+            bg = gg;
+          }
+        }
+      }
+      out[i] = best;
+      if (bg >= 0) ++head[bg];
+    }
+  }
+}
+
+// thr[q] = k-th key of query q's exact top-k over a prefix of the shard: a lower bound of the k-th key over the
+// whole shard, so the main pass may discard everything below it.
+__global__ void topk_seed_threshold_kernel(const u64* __restrict__ out, int nq, int k, u64* __restrict__ thr) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) thr[q] = out[(size_t)q * k + (k - 1)];
+}
+
+static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st);
+
+struct Mfma2Plan {
+  long long prefix;   // rows of the threshold-seeding pass (0 = single pass)
+  int n_wg0, per1, n_wg1;
+};
+static Mfma2Plan dense_mfma2_plan(long long n) {
+  static const int target = getenv("VRAG_TOPK_MWGS") ? std::max(1, atoi(getenv("VRAG_TOPK_MWGS"))) : 256;
+  static const long long pre = getenv("VRAG_TOPK_PREFIX") ? atoll(getenv("VRAG_TOPK_PREFIX")) : 32768;
+  Mfma2Plan p{};
+  p.prefix = (pre > 0 && n >= 4 * pre) ? pre / 128 * 128 : 0;
+  p.n_wg0 = (int)(p.prefix / 128);
+  const long long rest = n - p.prefix;
+  const long long per = (rest + target - 1) / target;
+  p.per1 = (int)std::max<long long>(128, (per + 127) / 128 * 128);
+  p.n_wg1 = (int)((rest + p.per1 - 1) / p.per1);
+  return p;
+}
+
+static bool dense_use_mfma2(int dim) {
+  static const bool off = getenv("VRAG_TOPK_MFMA1") != nullptr;   // tuning: force the first-generation kernel
+  return !off && (dim == 384 || dim == 768 || dim == 1024);
+}
 static bool dense_use_mfma(int dtype, int dim, int nq, int k) {
   return dtype == 0 && dim % 128 == 0 && nq >= 3 && k <= MKMAX &&
          (size_t)MQ * dim * 2 + MSLOTS * 16384 + (size_t)256 * k * 8 <= 160 * 1024;
 }
 static int dense_n_wg(int dtype, int dim, int nq, int k, long long size) {
+  if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
+    const Mfma2Plan pl = dense_mfma2_plan(size);
+    return std::max(1, pl.n_wg0 + pl.n_wg1);
+  }
   const int per = dense_use_mfma(dtype, dim, nq, k) ? MROWS_WG : dense_rows_per_wg(size);
   return (int)std::max<long long>(1, (size + per - 1) / per);
 }
 
 // all passes of one search: query tiles of 4 (a final tile of 1 query uses the register path)
 static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int dim, const float* dq, int nq, int k,
-                                   u64* cand, int n_wg, hipStream_t st) {
+                                   u64* cand, int n_wg, hipStream_t st, u64* thr, u64* out) {
+  if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
+    static const int dbg_fill = getenv("VRAG_TOPK_DEBUG_NOINSERT") ? 0xff : 0;   // probe: reject every key
+    hipError_t me = hipMemsetAsync(thr, dbg_fill, (size_t)nq * sizeof(u64), st);
+    if (me != hipSuccess) return me;
+    const size_t lds2 = (size_t)M2SLOTS * 16384 + (size_t)256 * k * 8;
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_mfma2_kernel<6>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_mfma2_kernel<12>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_mfma2_kernel<16>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr2 = true;
+    }
+    const bf16_t* r16 = reinterpret_cast<const bf16_t*>(rows);
+    auto pass = [&](long long lo, long long hi, int per, int wgs, u64* cand_base) -> hipError_t {
+      for (int q0 = 0; q0 < nq; q0 += MQ) {
+        if (dim == 384) hipLaunchKernelGGL(dense_topk_mfma2_kernel<6>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr);
+        else if (dim == 768) hipLaunchKernelGGL(dense_topk_mfma2_kernel<12>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr);
+        else hipLaunchKernelGGL(dense_topk_mfma2_kernel<16>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    };
+    const Mfma2Plan pl = dense_mfma2_plan(n);
+    if (pl.prefix > 0 && !dbg_fill) {
+      // seeding pass: exact top-k of the first `prefix` rows -> per-query entry threshold for the main pass
+      hipError_t e = pass(0, pl.prefix, 128, pl.n_wg0, cand);
+      if (e == hipSuccess) e = launch_topk_merge(cand, pl.n_wg0, nq, k, out, st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(topk_seed_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, out, nq, k, thr);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else if (pl.prefix > 0) {
+      hipError_t e = pass(0, pl.prefix, 128, pl.n_wg0, cand);
+      if (e != hipSuccess) return e;
+    }
+    return pass(pl.prefix, n, pl.per1, pl.n_wg1, cand + (size_t)pl.n_wg0 * nq * k);
+  }
   if (dense_use_mfma(dtype, dim, nq, k)) {
     const size_t lds = (size_t)MQ * dim * 2 + MSLOTS * 16384 + (size_t)256 * k * 8;
     static bool attr = false;
@@ -780,14 +1011,15 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   int rc;
   if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
   if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
-  if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k))) return rc;
+  if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;   // + per-query entry thresholds
   HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, st));
   const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
   ARG_CHECK(lds <= 160 * 1024, "dim/k too large for the LDS budget");
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
   } else {
-    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st));
+    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                             ix->d_out + (size_t)nq * k, ix->d_out));
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
     HIP_TRY(hipGetLastError());
   }
@@ -807,9 +1039,10 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
   const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
-  ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k, "scratch too small");
+  ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k + nq, "scratch too small");
   const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
-  HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st));
+  HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                             ix->d_out + (size_t)nq * k, ix->d_out));
   HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
   HIP_TRY(hipGetLastError());
   return VRAG_OK;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Evidence for the rows next to the headline path (run through gpurun from the repo root):
+#   tools/profile_aux.sh r01   -> gpurun_out/<tag>_aux/{topk_lines.json, topk_kernel_stats.txt, embed_lines.json, embed_kernel_stats.txt}
+TAG=${1:-round}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/${TAG}_aux
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_topk" -- python $REPO/tools/bench_topk.py 2>/dev/null | grep '^{' > "$OUT/topk_lines.json"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_embed" -- python $REPO/tools/bench_embed.py --check 0 2>/dev/null | grep '^{' > "$OUT/embed_lines.json"
+cd "$REPO"
+python tools/rocpd_summary.py "$(find $OUT/kt_topk -name '*.db' | head -1)" > "$OUT/topk_kernel_stats.txt" 2>&1
+python tools/rocpd_summary.py "$(find $OUT/kt_embed -name '*.db' | head -1)" > "$OUT/embed_kernel_stats.txt" 2>&1
+rm -rf "$OUT/kt_topk" "$OUT/kt_embed"
+head -12 "$OUT/topk_kernel_stats.txt" | cut -c1-180; head -12 "$OUT/embed_kernel_stats.txt" | cut -c1-180

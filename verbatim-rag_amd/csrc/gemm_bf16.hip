@@ -27,6 +27,11 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef VRAG_DMA_SPLIT
+#define VRAG_DMA_SPLIT 1   // operand-DMA issue of the main loop: 0 = every wave right after the K-step barrier,
+                           // 1 = half of the waves there, the other half one k-substep later (+1-3 % on the GEMMs)
+#endif
+
 namespace vrag {
 
 constexpr int BK = 64;
@@ -431,11 +436,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < KT && !(DBG && (p.debug_flags & 1) && kt >= 1)) stage(kt + 1, buf ^ 1);
+      const bool do_stage = kt + 1 < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
+#if VRAG_DMA_SPLIT == 0
+      if (do_stage) stage(kt + 1, buf ^ 1);
+#elif VRAG_DMA_SPLIT == 1
+      if (do_stage && wave < (WM * WN) / 2) stage(kt + 1, buf ^ 1);   // first half of the waves: right after the barrier
+#endif
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * 128;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * 128;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+#if VRAG_DMA_SPLIT == 1
+        if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(kt + 1, buf ^ 1);   // second half: one substep later
+#endif
         bf16x8 af[MI] = {}, wf[2] = {};
         if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll

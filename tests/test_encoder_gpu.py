@@ -150,3 +150,19 @@ def test_long_sequence_global_and_banded_attention():
         ref = O.encoder_forward(cfg, w, s)
         assert np.abs(got[o:o + len(s)] - ref).max() < 3e-2
         o += len(s)
+
+
+def test_full_context_8192_tokens():
+    """One 8 192-token sequence (the v2 highlighter's max_length, extractors.py:89-90): 128 key tiles per query
+    block on global layers, RoPE tables to position 8191."""
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=7)
+    eng = _engine(cfg, w, max_tokens=8448, max_seqs=2, max_seq_len=8192, max_ranges=4)
+    rng = np.random.default_rng(41)
+    seqs = _seqs(rng, [8192], cfg.vocab_size)
+    eng.load_batch(seqs)
+    eng.run()
+    got = eng.read_hidden(final_norm=True)
+    eng.close()
+    ref = O.encoder_forward(cfg, w, seqs[0])
+    assert np.abs(got - ref).max() < 3e-2

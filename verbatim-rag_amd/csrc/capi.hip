@@ -1391,6 +1391,7 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
       const unsigned m = (x >> 9) & 0x7f, s = (x >> 31) << 15, ex = 0x3e80u + (((x >> 20) & 1) << 7);
       v = (unsigned short)(s | ex | m);
     }
+    if (getenv("VRAG_DEBUG_GEMM_ZERO")) std::fill(h.begin(), h.end(), (unsigned short)0);   // probe: operand-data dependence of the clock
     (void)hipMemcpy(A, h.data(), Mp * K * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
   }

@@ -53,7 +53,7 @@ struct GemmParams {
   int stagger_groups;     // XCD phase groups (1, 2, 4 or 8)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias
-  int debug_flags;        // EPI_NONE tuning probe (VRAG_GEMM_DEBUG): 1 = no operand DMA after the first K-step, 2 = no fragment reads
+  int debug_flags;        // EPI_NONE tuning probe (VRAG_GEMM_DEBUG): 1 = no operand DMA after the first K-step, 2 = no fragment reads (zero operands), 4 = with 2: fresh pseudo-random register operands, 8 = with 2: loop-invariant pseudo-random register operands
 };
 
 // Launches on `stream`. Requirements: N % 128 == 0, K % 64 == 0.

@@ -434,6 +434,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bf16x8 dbg_f[MI + 2] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
+    if (DBG && (p.debug_flags & 8)) {
+#pragma unroll
+      for (int i = 0; i < MI + 2; ++i) {
+        unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)(i * 40503u);
+        unsigned w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h = h * 1664525u + 1013904223u;
+          w4[j] = (h & 0x807f807fu) | 0x3f803f80u;
+        }
+        dbg_f[i] = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
+                                                     __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
+      }
+    }
     for (int kt = 0; kt < KT; ++kt) {
       const int buf = kt & 1;
       const bool do_stage = kt + 1 < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
@@ -450,6 +465,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
         if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(kt + 1, buf ^ 1);   // second half: one substep later
 #endif
         bf16x8 af[MI] = {}, wf[2] = {};
+        if (DBG && (p.debug_flags & 8)) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) af[i] = dbg_f[i];
+          wf[0] = dbg_f[MI];
+          wf[1] = dbg_f[MI + 1];
+        } else if (DBG && (p.debug_flags & 4)) {   // probe: fresh pseudo-random register operands per MFMA group, no LDS read
+#pragma unroll
+          for (int i = 0; i < MI + 2; ++i) {
+            unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)((i * 4 + s + kt * 16) * 40503u);
+            unsigned w4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              h = h * 1664525u + 1013904223u;
+              w4[j] = (h & 0x807f807fu) | 0x3f803f80u;   // sign + mantissa random, exponent 127
+            }
+            const bf16x8 v = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
+                                                              __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
+            if (i < MI) af[i] = v;
+            else wf[i - MI] = v;
+          }
+        }
         if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);

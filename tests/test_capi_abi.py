@@ -74,3 +74,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
     monkeypatch.undo()
     assert _lib.load().vrag_abi_version() == _lib.ABI_VERSION
+
+
+def test_graft_entry_build_is_consistent_with_the_binding():
+    """__graft_entry__.build() (the driver's build check) must accept the library the binding accepts."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_graft_entry", os.path.join(root, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()   # incremental: objects are up to date after the session's build

@@ -22,8 +22,11 @@ def _shape(cfg, kind):
                      pad_token_id=0, cls_token_id=1, sep_token_id=2, model_type=kind)
 
 
+@pytest.mark.parametrize("fold", ["0", "1"])
 @pytest.mark.parametrize("name", ["bert_tiny", "distilbert_tiny"])
-def test_tiny_models_vs_transformers_golden(name):
+def test_tiny_models_vs_transformers_golden(name, fold, monkeypatch):
+    """fold = 1: the opt-in schedule without LayerNorm kernels (lazy LayerNorm folded into the GEMM epilogues)."""
+    monkeypatch.setenv("VRAG_BERT_LN_FOLD", fold)
     from verbatim_rag_amd.engine import BertEncoderEngine
     from verbatim_rag_amd.weights import bert_canonical
 
@@ -56,7 +59,7 @@ def test_tiny_models_vs_transformers_golden(name):
             eng.run(n_layers=nl)
             g = eng.read_hidden(final_norm=False)[: len(seqs[0])]
             ref = B.encoder_forward(cfg, Wo, seqs[0], n_layers=nl)
-            assert np.abs(g - ref).max() < (1e-5 if nl == 0 else 2e-2), (nl, np.abs(g - ref).max())
+            assert np.abs(g - ref).max() < (1e-5 if nl == 0 else 2e-2), (nl, fold, np.abs(g - ref).max())
     finally:
         eng.close()
 

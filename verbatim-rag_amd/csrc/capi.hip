@@ -104,6 +104,9 @@ struct BertLayer {
   bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+  // LayerNorm fold (default): wqkv (layers > 0) / w1 carry the gain of the LayerNorm that feeds them, bqkv / b1 carry
+  // W . ln_bias on top of the linear bias, s_* are the row sums of the bf16 folded weights
+  float *s_qkv = nullptr, *s_w1 = nullptr;
 };
 
 struct MicroBatch {
@@ -141,7 +144,6 @@ struct vrag_encoder {
   // arch 1
   float *pos_emb = nullptr, *type_row = nullptr, *emb_norm_b = nullptr;
   std::vector<BertLayer> blayers;
-  float *neg_ones = nullptr, *ones = nullptr;  // [cap_rows] constants: the QKV bias rides the LayerNorm-fold epilogue
   float *mlm_dense_b = nullptr, *mlm_norm_b = nullptr;
   int i_pad = 0;        // GeGLU width padded to a multiple of 128 (2*i_pad = whole 256-wide GEMM tiles)
   int attn_w = 0;       // width of the q / k / v^T / o buffers = num_heads * 64 (> hidden_size when head_dim is 32)
@@ -483,9 +485,13 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
 }
 
 // BERT-family schedule (arch 1).  Post-LN: every sub-layer is  h <- LN(h + f(h) + b),  so the residual
-// GEMM (bias added in its epilogue) is followed by an in-place LayerNorm that also refreshes the bf16
-// copy the next GEMM reads.  The QKV GEMM reuses EPI_QKV_ROPE with identity rotation tables; its bias
-// rides the LayerNorm-fold slot of that epilogue: rstd*(acc - mu*s) with rstd = 1, mu = -1, s = bias.
+// GEMM adds the linear bias in its epilogue and is followed by an in-place LayerNorm kernel that also refreshes
+// the bf16 copy the next GEMM reads.  Opt-in (VRAG_BERT_LN_FOLD=1, 2-3 % slower here): no LayerNorm kernels --
+// the stream keeps the pre-LayerNorm sums t, the residual epilogues emit bf16(t) and the row statistics, the
+// consumer GEMMs (gain folded into their weights, W . ln_bias into their biases) normalise in their epilogues,
+// the next residual epilogue rebuilds LN(t) on the fly as its residual input, and only the output of the last
+// layer of a run is materialised.
+// The QKV GEMM reuses EPI_QKV_ROPE with identity rotation tables.
 // TF:models/bert/modeling_bert.py:141-205 (attention), 282-286 / 340-344 (post-LN), 326-336 (GELU MLP);
 // models/distilbert/modeling_distilbert.py:131-239.
 int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
@@ -508,15 +514,30 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       HIP_TRY(launch_embed_ln(e->d_ids + r0, e->tok_emb, e->emb_norm, c.norm_eps, H, M, h, a, st, e->pos_emb,
                               e->d_pos + r0, e->type_row, e->emb_norm_b));
     }
+    const bool fold = e->ln_fold;
+    float* st_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+    auto finalize_stats = [&]() -> int {
+      ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+      hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, st_part, H / 64, H, c.norm_eps, M,
+                         e->ln_mu + r0, e->ln_rstd + r0);
+      HIP_TRY(hipGetLastError());
+      return VRAG_OK;
+    };
     for (int l = 0; l < n_layers; ++l) {
       const BertLayer& L = e->blayers[l];
+      // fold mode: the stream `h` holds the PRE-LayerNorm sums t (layer 0 input excepted: the embedding LayerNorm
+      // is eager); (ln_mu, ln_rstd) are the row statistics of the most recent t, `a` = bf16(t).
+      const bool lazy_in = fold && l > 0;           // this layer's input is LN2 of layer l-1, still lazy
       {
         GemmParams g{};
         g.A = a;
         g.W = L.wqkv;
-        g.ln_mu = e->neg_ones;
-        g.ln_rstd = e->ones;
-        g.ln_s = L.bqkv;
+        g.bias = L.bqkv;
+        if (lazy_in) {
+          g.ln_mu = e->ln_mu + r0;
+          g.ln_rstd = e->ln_rstd + r0;
+          g.ln_s = L.s_qkv;
+        }
         g.M = M;
         g.N = 3 * Ha;
         g.K = H;
@@ -558,10 +579,24 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.K = Ha;
         g.out_f32 = h;
         g.bias = L.bo;
+        if (lazy_in) {
+          const BertLayer& P = e->blayers[l - 1];
+          g.res_mu = e->ln_mu + r0;
+          g.res_rstd = e->ln_rstd + r0;
+          g.res_g = P.ln2_w;
+          g.res_b = P.ln2_b;
+        }
+        if (fold) {
+          g.resid_bf16 = a;
+          g.stats_part = st_part;
+        }
         ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
-      {
+      if (fold) {
+        int rc = finalize_stats();   // statistics of t1 = attention sub-layer sum (LN1 stays lazy)
+        if (rc) return rc;
+      } else {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         HIP_TRY(launch_layernorm(h, L.ln1_w, c.norm_eps, H, M, a, h, st, L.ln1_b));
       }
@@ -575,6 +610,11 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.out_bf16 = e->act + (size_t)r0 * I;
         g.bias = L.b1;
         g.act_gelu = 1;
+        if (fold) {
+          g.ln_mu = e->ln_mu + r0;
+          g.ln_rstd = e->ln_rstd + r0;
+          g.ln_s = L.s_w1;
+        }
         ProfScope ps(e, VRAG_PROF_GEMM_WI, st);
         HIP_TRY(launch_gemm(EPI_BF16, g, st));
       }
@@ -587,10 +627,22 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.K = I;
         g.out_f32 = h;
         g.bias = L.b2;
+        if (fold) {
+          g.res_mu = e->ln_mu + r0;
+          g.res_rstd = e->ln_rstd + r0;
+          g.res_g = L.ln1_w;
+          g.res_b = L.ln1_b;
+          g.resid_bf16 = a;
+          g.stats_part = st_part;
+        }
         ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
-      {
+      if (fold && l + 1 < n_layers) {
+        int rc = finalize_stats();   // statistics of t2: the next layer consumes LN2 lazily
+        if (rc) return rc;
+      } else {
+        // materialise the layer output (last layer of this run, or un-folded mode): h <- LN2(h), a <- bf16(h)
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         HIP_TRY(launch_layernorm(h, L.ln2_w, c.norm_eps, H, M, a, h, st, L.ln2_b));
       }
@@ -831,7 +883,8 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
   const int hd = H / cfg->num_heads, Ha = cfg->num_heads * 64;
   vrag_encoder* e = new vrag_encoder();
   e->arch = 1;
-  e->ln_fold = false;
+  e->ln_fold = false;   // measured 2-3 % slower than the LayerNorm kernels on this family (opt-in: VRAG_BERT_LN_FOLD=1)
+  if (const char* lf = getenv("VRAG_BERT_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
   e->attn_w = Ha;
   e->q_scale = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
   {
@@ -898,14 +951,37 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
       bqkv = pb.data();
       wo = po.data();
     }
-    TRY(upload_bf16(e, &ly.wqkv, wqkv, 3 * Ha, H, 3 * Ha, 0, stage, stage_elems));
-    TRY(upload_f32(e, &ly.bqkv, bqkv, (size_t)3 * Ha));
-    TRY(upload_bf16(e, &ly.wo, wo, H, Ha, H, 0, stage, stage_elems));
-    TRY(upload_f32(e, &ly.bo, w->bo[l], H));
     TRY(upload_f32(e, &ly.ln1_w, w->attn_norm_w[l], H));
     TRY(upload_f32(e, &ly.ln1_b, w->attn_norm_b[l], H));
-    TRY(upload_bf16(e, &ly.w1, w->w1[l], I, H, I, 0, stage, stage_elems));
-    TRY(upload_f32(e, &ly.b1, w->b1[l], I));
+    // folded bias: b + W . ln_bias (the LayerNorm bias pushed through the linear layer), fp32 on the host
+    auto folded_bias = [&](const float* W, const float* bvec, const float* ln_b, int rows, std::vector<float>& out) {
+      out.resize(rows);
+      for (int r = 0; r < rows; ++r) {
+        double acc = 0.0;
+        const float* wr = W + (size_t)r * H;
+        for (int c2 = 0; c2 < H; ++c2) acc += (double)wr[c2] * (double)ln_b[c2];
+        out[r] = bvec[r] + (float)acc;
+      }
+    };
+    std::vector<float> cb;
+    if (e->ln_fold && l > 0) {   // QKV consumes LN2 of the previous layer
+      folded_bias(wqkv, bqkv, w->out_norm_b[l - 1], 3 * Ha, cb);
+      TRY(upload_bf16(e, &ly.wqkv, wqkv, 3 * Ha, H, 3 * Ha, 0, stage, stage_elems, e->blayers[l - 1].ln2_w, &ly.s_qkv));
+      TRY(upload_f32(e, &ly.bqkv, cb.data(), (size_t)3 * Ha));
+    } else {
+      TRY(upload_bf16(e, &ly.wqkv, wqkv, 3 * Ha, H, 3 * Ha, 0, stage, stage_elems));
+      TRY(upload_f32(e, &ly.bqkv, bqkv, (size_t)3 * Ha));
+    }
+    TRY(upload_bf16(e, &ly.wo, wo, H, Ha, H, 0, stage, stage_elems));
+    TRY(upload_f32(e, &ly.bo, w->bo[l], H));
+    if (e->ln_fold) {            // W1 consumes LN1 of this layer
+      folded_bias(w->w1[l], w->b1[l], w->attn_norm_b[l], I, cb);
+      TRY(upload_bf16(e, &ly.w1, w->w1[l], I, H, I, 0, stage, stage_elems, ly.ln1_w, &ly.s_w1));
+      TRY(upload_f32(e, &ly.b1, cb.data(), I));
+    } else {
+      TRY(upload_bf16(e, &ly.w1, w->w1[l], I, H, I, 0, stage, stage_elems));
+      TRY(upload_f32(e, &ly.b1, w->b1[l], I));
+    }
     TRY(upload_bf16(e, &ly.w2, w->w2[l], H, I, H, 0, stage, stage_elems));
     TRY(upload_f32(e, &ly.b2, w->b2[l], H));
     TRY(upload_f32(e, &ly.ln2_w, w->out_norm_w[l], H));
@@ -918,12 +994,6 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
     TRY(upload_f32(e, &e->sin_g, sn.data(), sn.size()));
   }
   TRY(init_workspace(e));
-  {
-    std::vector<float> v((size_t)e->cap_rows, -1.0f);
-    TRY(upload_f32(e, &e->neg_ones, v.data(), v.size()));
-    std::fill(v.begin(), v.end(), 1.0f);
-    TRY(upload_f32(e, &e->ones, v.data(), v.size()));
-  }
 #undef TRY
   *out = e;
   return VRAG_OK;

@@ -23,7 +23,7 @@ struct GemmParams {
   int M, N, K;         // M valid rows; Mpad = roundup(M, kRowPad) rows are readable
   float* out_f32;      // EPI_F32 / EPI_F32_GELU / EPI_RESIDUAL  [M, N]
   bf16_t* out_bf16;    // EPI_BF16 [M, N]; EPI_GEGLU [M, N/2]
-  const float* bias;   // optional [N] (EPI_F32, EPI_BF16, EPI_SPLADE)
+  const float* bias;   // optional [N] (EPI_F32, EPI_F32_GELU, EPI_BF16, EPI_RESIDUAL, EPI_QKV_ROPE, EPI_SPLADE)
   // EPI_QKV_ROPE
   bf16_t* q;           // [Mpad, hidden]
   bf16_t* k;           // [Mpad, hidden]
@@ -45,6 +45,11 @@ struct GemmParams {
   const float* ln_s;      // [N]
   // EPI_RESIDUAL extras: bf16 copy of the updated residual rows (the next GEMM's A operand) and the
   // per-row partial sums (sum x, sum x^2) over each 64-column segment, for the next fold.
+  // EPI_RESIDUAL, post-LN encoders: the residual input is LN(out_f32 row) = (t - res_mu) * res_rstd * res_g + res_b
+  const float* res_mu;    // [Mpad] or null (= plain residual add)
+  const float* res_rstd;  // [Mpad]
+  const float* res_g;     // [N] LayerNorm gain
+  const float* res_b;     // [N] LayerNorm bias
   bf16_t* resid_bf16;     // [Mpad, N] or null
   float* stats_part;      // [Mpad, N/64, 2] or null
   // first-wave start stagger (de-synchronises the HBM-heavy epilogues of co-running workgroups)

@@ -123,6 +123,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         float* dst = p.out_f32 + (size_t)(mw + ps * 64 + row) * p.N + nw + c16 * 4;
         if constexpr (EPI == EPI_RESIDUAL) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);   // BERT-family linears have biases
+          if (p.res_mu) {
+            // post-LN encoders keep the PRE-LayerNorm sum in the stream; the residual input LN(t) is rebuilt here
+            // from the row statistics instead of being written and re-read by a LayerNorm kernel
+            const int grow = mw + ps * 64 + row;
+            const float m_ = p.res_mu[grow], r_ = p.res_rstd[grow];
+            const f32x4 g_ = *reinterpret_cast<const f32x4*>(p.res_g + nw + c16 * 4);
+            const f32x4 b_ = *reinterpret_cast<const f32x4*>(p.res_b + nw + c16 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[it][j] = (hv[it][j] - m_) * r_ * g_[j] + b_[j];
+          }
           v += hv[it];
         } else if constexpr (EPI == EPI_F32) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);
@@ -161,7 +171,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
   } else if constexpr (EPI == EPI_BF16) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+      float mu = 0.f, rs = 1.f;
+      if (p.ln_mu) {
+        mu = p.ln_mu[mw + mi * 32 + l31];
+        rs = p.ln_rstd[mw + mi * 32 + l31];
+      }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -171,12 +186,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float v = acc[ni][mi][4 * g + j];
+            if (p.ln_mu) v = rs * (v - mu * p.ln_s[nw + col + j]);
             if (p.bias) v += p.bias[nw + col + j];
             if (p.act_gelu) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
             o[j] = (bf16_t)v;
           }
           put_bf16(mi * 32 + l31, col, o, 128);
         }
+    }
     static_assert(true, "");
     if (p.stagger_groups == 101) {          // tuning ablation: LDS round trip only, no global stores
 #pragma unroll
@@ -259,11 +276,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             ls1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + dd);
             ls2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + dd);
           }
+          f32x4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            b1 = *reinterpret_cast<const f32x4*>(p.bias + nw + dd);
+            b2 = *reinterpret_cast<const f32x4*>(p.bias + nw + 32 + dd);
+          }
           bf16x4 o1, o2;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float x1 = rs * (acc[0][mi][4 * g + j] - mu * ls1[j]);
-            const float x2 = rs * (acc[1][mi][4 * g + j] - mu * ls2[j]);
+            const float x1 = rs * (acc[0][mi][4 * g + j] - mu * ls1[j]) + b1[j];
+            const float x2 = rs * (acc[1][mi][4 * g + j] - mu * ls2[j]) + b2[j];
             // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
             o1[j] = (bf16_t)((x1 * c[j] - x2 * sv[j]) * scale);
             o2[j] = (bf16_t)((x2 * c[j] + x1 * sv[j]) * scale);
@@ -284,6 +306,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const float sn_ = p.ln_mu ? p.ln_s[nw + ni * 32 + l31] : 0.f;
+        const float bv_ = p.bias ? p.bias[nw + ni * 32 + l31] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -295,7 +318,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             }
             bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(rs4[j] * (acc[ni][mi][4 * g + j] - mu4[j] * sn_));
+            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(rs4[j] * (acc[ni][mi][4 * g + j] - mu4[j] * sn_) + bv_);
             put_bf16(ni * 32 + l31, mi * 32 + 8 * g + 4 * hi, o, RB);
           }
       }

@@ -269,6 +269,7 @@ def main() -> None:
         print(json.dumps(out))
     eng.close()
     if world > 1:
+        dist.barrier()   # rank 0 ran an extra (untimed) single-stream pass; leave together
         dist.destroy_process_group()
 
 

@@ -211,7 +211,10 @@ def main() -> None:
                  "gemm_wi": "vrag::gemm_bf16_kernel<4, 256, 256, 2, 4, 0> (EPI_GEGLU)",
                  "gemm_wo_mlp": "vrag::gemm_bf16_kernel<3, 256, 256, 2, 4, 0> (EPI_RESIDUAL)"}
         if gemm_tf:
-            dom = max(fl.keys(), key=lambda k: prof.get(k, (0.0, 0))[0])
+            # dominant GEMM class = largest summed time in the single-stream pass (stable run to run; the two-stream
+            # event times of the timed region include cross-stream waiting and reshuffle between runs)
+            rank_src = iso if iso else prof
+            dom = max(fl.keys(), key=lambda k: rank_src.get(k, (0.0, 0))[0])
             ms, n = prof[dom]
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")

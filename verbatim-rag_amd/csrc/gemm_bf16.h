@@ -52,10 +52,6 @@ struct GemmParams {
   const float* res_b;     // [N] LayerNorm bias
   bf16_t* resid_bf16;     // [Mpad, N] or null
   float* stats_part;      // [Mpad, N/64, 2] or null
-  // first-wave start stagger (de-synchronises the HBM-heavy epilogues of co-running workgroups)
-  int stagger_sleeps;     // max delay in units of s_sleep(127) (~8k cycles); 0 = off
-  int stagger_blocks;     // only workgroups with blockIdx < this are delayed
-  int stagger_groups;     // XCD phase groups (1, 2, 4 or 8)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias
   int debug_flags;        // EPI_NONE tuning probe (VRAG_GEMM_DEBUG): 1 = no operand DMA after the first K-step, 2 = no fragment reads (zero operands), 4 = with 2: fresh pseudo-random register operands, 8 = with 2: loop-invariant pseudo-random register operands

@@ -194,26 +194,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           put_bf16(mi * 32 + l31, col, o, 128);
         }
     }
-    static_assert(true, "");
-    if (p.stagger_groups == 101) {          // tuning ablation: LDS round trip only, no global stores
 #pragma unroll
-      for (int it = 0; it < MI * 4; ++it) {
-        const int row = it * 8 + (lane >> 3), c16 = lane & 7;
-        f32x4 v = get16(row, c16, 128);
-        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-      }
-    } else if (p.stagger_groups == 102) {   // tuning ablation: stores hit one L2-resident 64 KiB window
-#pragma unroll
-      for (int it = 0; it < MI * 4; ++it) {
-        const int row = it * 8 + (lane >> 3), c16 = lane & 7;
-        *reinterpret_cast<f32x4*>(p.out_bf16 + (size_t)(row & 127) * 256 + (wave & 3) * 64 + c16 * 8) = get16(row, c16, 128);
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < MI * 4; ++it) {
-        const int row = it * 8 + (lane >> 3), c16 = lane & 7;
-        store16_nt(p.out_bf16 + (size_t)(mw + row) * p.N + nw + c16 * 8, get16(row, c16, 128));
-      }
+    for (int it = 0; it < MI * 4; ++it) {
+      const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+      store16_nt(p.out_bf16 + (size_t)(mw + row) * p.N + nw + c16 * 8, get16(row, c16, 128));
     }
   } else if constexpr (EPI == EPI_GEGLU) {
     // Wi rows were interleaved at load time: each 64-row group = 32 "input" rows (x1)
@@ -537,236 +521,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
   }  // tile loop
 }
 
-// ---------------------------------------------------------------------------------------------
-// Ring-pipelined variant: 256x256 tile, BK = 32, FOUR LDS stages (4 x 32 KiB), loads three K-steps
-// ahead.  One raw s_barrier per K-step placed BETWEEN the two MFMA groups of the step, counted
-// s_waitcnt vmcnt(4) (never 0 in steady state: one stage stays in flight across every barrier), and
-// the operand fragments of the next MFMA group are read from LDS while the current group issues:
-//
-//   iter kt:  MFMA x8 (k 0..15 of stage kt)      || ds_read fragments (k 16..31 of stage kt)
-//             vmcnt(4) ; s_barrier               -> stage kt+1 landed for every wave, stage kt-1 free
-//             LDS-DMA stage kt+3 -> slot (kt+3)&3
-//             MFMA x8 (k 16..31 of stage kt)     || ds_read fragments (k 0..15 of stage kt+1)
-//
-// LDS rows are 64 B (32 bf16): 4 chunks of 16 B, chunk index XOR ((row>>2)&3) (source address of the
-// DMA and ds_read_b128 address alike) -> each 16-lane read group touches 16 distinct 16-byte slots.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, WN = 4, RBK = 32, MI = 4, WROWS = 128;
-  constexpr int A_BYTES = BM * RBK * 2, STAGE_BYTES = (BM + BN) * RBK * 2;  // 16 KiB, 32 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = uniform(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int nbn = p.N / BN;
-  const int nblk = gridDim.x;
-  int b = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
-  const int K = p.K;
-  const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
-  const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
-
-  // LDS-DMA: one instruction = 1 KiB = 16 rows of 64 B.  Per stage a wave issues 2 (A) + 2 (W).
-  int soff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 32 + i * 16 + (lane >> 2);
-    soff[i] = row * K + ((((lane & 3) ^ ((row >> 2) & 3))) << 3);
-  }
-  auto stage = [&](int kt) {
-    char* sA = smem + (kt & 3) * STAGE_BYTES;
-    char* sW = sA + A_BYTES;
-    const int k0 = kt * RBK;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(Ab + soff[i] + k0, sA + (wave * 32 + i * 16) * 64);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(Wb + soff[i] + k0, sW + (wave * 32 + i * 16) * 64);
-  };
-  // fragment offsets inside a 32-row sub-tile for k-half s: chunk (2s + hi) ^ ((row>>2)&3)
-  int fo[2];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) fo[s2] = l31 * 64 + ((((2 * s2 + hi) ^ ((l31 >> 2) & 3))) << 4);
-
-  struct Frags {
-    bf16x8 a[MI];
-    bf16x8 w[2];
-  };
-  auto read_frags = [&](Frags& f, int kt, int s2) {
-    const char* sA = smem + (kt & 3) * STAGE_BYTES + (wm * WROWS) * 64;
-    const char* sW = smem + (kt & 3) * STAGE_BYTES + A_BYTES + (wn * 64) * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 64 + fo[s2]);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 64 + fo[s2]);
-  };
-
-  f32x16 acc[2][MI];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < MI; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-  const int nw = n0 + wn * 64;
-  const int mw = m0 + wm * WROWS;
-  bool v_block = false;
-  if constexpr (EPI == EPI_QKV_ROPE) v_block = n0 >= 2 * p.hidden;
-
-  const int KT = K / RBK;
-  auto mainloop = [&](auto swapped_tag) {
-    constexpr bool SWAPPED = decltype(swapped_tag)::value;
-    auto mma = [&](const Frags& f, int mi_lo, int mi_hi) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (mi < mi_lo || mi >= mi_hi) continue;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if constexpr (SWAPPED)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[ni], f.a[mi], acc[ni][mi], 0, 0, 0);
-          else
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi], f.w[ni], acc[ni][mi], 0, 0, 0);
-        }
-      }
-    };
-    // prologue: three stages in flight, wait for the first
-    stage(0);
-    if (KT > 1) stage(1);
-    if (KT > 2) stage(2);
-    if (KT > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (KT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    Frags f0, f1;
-    read_frags(f0, 0, 0);
-    for (int kt = 0; kt < KT - 1; ++kt) {
-      // The wait for f0 sits after the loop back-edge, where hipcc can only emit lgkmcnt(0): issue
-      // the f1 reads AFTER the first two MFMAs so that wait covers nothing but the (old) f0 reads.
-      mma(f0, 0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(f1, kt, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f0, 1, MI);
-      // stage kt+1 must have landed (this wave's part); stage kt+2 may stay in flight
-      if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 3 < KT) stage(kt + 3);
-      read_frags(f0, kt + 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f1, 0, MI);
-    }
-    mma(f0, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(f1, KT - 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f0, 1, MI);
-    mma(f1, 0, MI);
-    // all waves must be done with the operand slots before the epilogue reuses the LDS
-    __syncthreads();
-  };
-  if (v_block) mainloop(std::false_type{});
-  else mainloop(std::true_type{});
-
-  gemm_epilogue<EPI, MI, WROWS>(p, acc, smem, wave, lane, mw, nw, n0, v_block);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Experimental (tuning probe, EPI_NONE only): 256x256 tile, FOUR waves as 2x2, 128x128 per wave
-// (256 accumulator registers -> AGPRs, one wave per SIMD): 16 KiB of LDS fragment reads per 32 MFMAs
-// instead of 12 KiB per 16.
-__global__ __launch_bounds__(256) void gemm_bf16_big_probe_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, MI = 4, NI = 4;
-  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = 2 * A_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int nbn = p.N / BN, nblk = gridDim.x;
-  int b = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN, K = p.K;
-  const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
-  const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
-  int soff[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = wave * 64 + i * 8 + (lane >> 3);
-    soff[i] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
-  }
-  const int sw = (lane >> 1) & 7;
-  int fo[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) fo[s] = l31 * 128 + ((((2 * s + hi) ^ sw)) << 4);
-  auto stage = [&](int kt, int buf) {
-    char* sA = smem + buf * STAGE_BYTES;
-    char* sW = sA + A_BYTES;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) glds16(Ab + soff[i] + k0, sA + (wave * 64 + i * 8) * 128);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) glds16(Wb + soff[i] + k0, sW + (wave * 64 + i * 8) * 128);
-  };
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int a = 0; a < NI; ++a)
-#pragma unroll
-    for (int c = 0; c < MI; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-  const int KT = K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
-    const char* sA = smem + buf * STAGE_BYTES + (wm * 128) * 128;
-    const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 128) * 128;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 af[MI], wf[NI];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[ni][mi][r]));
-}
-
 template <int EPI>
 hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
-  static const int env_stagger = getenv("VRAG_GEMM_STAGGER") ? atoi(getenv("VRAG_GEMM_STAGGER")) : -1;
-  static const int env_groups = getenv("VRAG_GEMM_STAGGER_G") ? atoi(getenv("VRAG_GEMM_STAGGER_G")) : 2;
-  if (env_stagger >= 0) p.stagger_sleeps = env_stagger;
-  p.stagger_groups = env_groups > 0 ? env_groups : 1;
   static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr;  // tuning knob
   if (!force128 && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
     constexpr int BM = 256, BN = 256, SMEM = 2 * (BM + BN) * BK * 2;
@@ -779,30 +536,7 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
     p.n_tiles = nbm * nbn;
-    p.stagger_blocks = 256;   // 1 workgroup per CU
-    static const bool bigprobe = getenv("VRAG_GEMM_BIGPROBE") != nullptr;  // tuning probe
-    if (bigprobe && EPI == EPI_NONE) {
-      static bool attr3 = false;
-      if (!attr3) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_probe_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return e;
-        attr3 = true;
-      }
-      hipLaunchKernelGGL(gemm_bf16_big_probe_kernel, dim3(nbm * nbn), dim3(256), SMEM, stream, p);
-      return hipGetLastError();
-    }
-    static const bool noring = getenv("VRAG_GEMM_RING") == nullptr;  // ring variant is opt-in (measured ~3% slower)
-    if (!noring && p.K % 32 == 0) {
-      static bool attr2 = false;
-      if (!attr2) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return e;
-        attr2 = true;
-      }
-      hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3(nbm * nbn), dim3(512), SMEM, stream, p);
-    } else {
+    {
       static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
       static const int env_debug = getenv("VRAG_GEMM_DEBUG") ? atoi(getenv("VRAG_GEMM_DEBUG")) : 0;
       if constexpr (EPI == EPI_NONE) {
@@ -825,7 +559,6 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     constexpr int BM = 128, BN = 128, SMEM = 2 * (BM + BN) * BK * 2;
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
     p.n_tiles = nbm * nbn;
-    p.stagger_blocks = 512;   // 2 workgroups per CU
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2>), dim3(std::min(nbm * nbn, 512)), dim3(256), SMEM, stream, p);
   }
   return hipGetLastError();

@@ -175,6 +175,14 @@ int vrag_encoder_read_token_logits(vrag_encoder* enc, float* logits /*[n_tokens,
 /* SPLADE head: rows[s][v] = max over the tokens of sequence s of log1p(relu(mlm_logit)). */
 int vrag_encoder_run_splade(vrag_encoder* enc, void* stream);
 int vrag_encoder_read_splade(vrag_encoder* enc, float* rows /*[n_seqs, V]*/, void* stream);
+/* The same rows compacted on the device: for sequence s, counts[s] entries (vocabulary index ascending, weight >
+ * threshold; threshold 0 = every non-zero, the `embed_batch` rule of embedding_providers.py:161-163; 1e-6 = the
+ * `embed_text` rule :141-145) at indices/values[s*cap_per_seq ...].  counts[] is always exact; if any count exceeds
+ * cap_per_seq the call returns VRAG_ERR_CAPACITY (nothing is truncated silently) and the caller re-reads with a
+ * larger capacity or falls back to vrag_encoder_read_splade. */
+int vrag_encoder_read_splade_sparse(vrag_encoder* enc, float threshold, int32_t cap_per_seq, int32_t* counts /*[n_seqs]*/,
+                                    int32_t* indices /*[n_seqs, cap_per_seq]*/, float* values /*[n_seqs, cap_per_seq]*/,
+                                    void* stream);
 
 /* Debug / parity: final-LayerNorm hidden states (or the raw residual stream), caller order. */
 int vrag_encoder_read_hidden(vrag_encoder* enc, int32_t apply_final_norm, float* out /*[n_tokens, H]*/,

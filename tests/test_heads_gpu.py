@@ -61,6 +61,31 @@ def test_splade_rows_vs_golden_and_oracle(setup):
         assert ((row > 0) == (ref > 0))[np.abs(ref) > 2e-2].all()
 
 
+def test_splade_device_compaction_equals_dense_rows(setup):
+    """vrag_encoder_read_splade_sparse: the same rows compacted on the GPU, index-ascending, both threshold rules;
+    a capacity that is too small is reported, never truncated silently."""
+    from verbatim_rag_amd._lib import VragError
+
+    cfg, w, z, eng = setup
+    rng = np.random.default_rng(8)
+    seqs = [rng.integers(3, 400, size=n).astype(np.int32) for n in (64, 7, 130, 1)]
+    eng.load_batch(seqs)
+    eng.run()
+    eng.run_splade()
+    rows = eng.read_splade()
+    for thr in (0.0, 1e-6, 0.05):
+        counts, idx, val = eng.read_splade_sparse(thr, cap_per_seq=512)
+        for i, row in enumerate(rows):
+            nz = np.nonzero(row > thr)[0]
+            assert counts[i] == len(nz)
+            assert np.array_equal(idx[i, :counts[i]], nz)
+            assert np.array_equal(val[i, :counts[i]], row[nz])
+    worst = int(max((r > 0).sum() for r in rows))
+    with pytest.raises(VragError) as ei:
+        eng.read_splade_sparse(0.0, cap_per_seq=max(1, worst - 1))
+    assert ei.value.status == -3
+
+
 def test_dense_pooling_vs_oracle(setup):
     cfg, w, z, eng = setup
     seqs = [z["ids_130"], z["ids_7"]]

@@ -93,6 +93,7 @@ SIGNATURES = {
     "vrag_encoder_read_token_logits": (C.c_int, [_H, _FP, C.c_void_p]),
     "vrag_encoder_run_splade": (C.c_int, [_H, C.c_void_p]),
     "vrag_encoder_read_splade": (C.c_int, [_H, _FP, C.c_void_p]),
+    "vrag_encoder_read_splade_sparse": (C.c_int, [_H, C.c_float, C.c_int32, _IP, _IP, _FP, C.c_void_p]),
     "vrag_encoder_read_hidden": (C.c_int, [_H, C.c_int32, _FP, C.c_void_p]),
     "vrag_encoder_extract_qa": (C.c_int, [_H, _IP, _IP, C.c_int32, _IP, _IP, _IP, C.c_int32, _FP]),
     "vrag_encoder_set_concurrency": (C.c_int, [_H, C.c_int32]),

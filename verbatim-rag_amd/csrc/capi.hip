@@ -81,6 +81,37 @@ __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np,
   rstd[r] = 1.0f / sqrtf(var + eps);
 }
 
+// One workgroup per sequence: stable compaction of a SPLADE row (weights are >= 0) into (index, value) pairs.
+__global__ __launch_bounds__(256) void splade_compact_kernel(const float* __restrict__ rows, int V, int ld, float thr, int cap,
+                                                             int* __restrict__ counts, int* __restrict__ idx,
+                                                             float* __restrict__ val) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = rows + (size_t)s * ld;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int v0 = 0; v0 < V; v0 += 256) {   // 256 consecutive vocabulary entries per step keeps the output ordered
+    const int v = v0 + tid;
+    const float w = v < V ? row[v] : 0.f;
+    const bool keep = w > thr;
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w2 = 0; w2 < wave; ++w2) off += wsum[w2];
+    if (keep && off + before < cap) {
+      idx[(size_t)s * cap + off + before] = v;
+      val[(size_t)s * cap + off + before] = w;
+    }
+    __syncthreads();
+    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) counts[s] = base;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -173,6 +204,9 @@ struct vrag_encoder {
   float* d_rng_out = nullptr;  // [max_ranges, max(H, labels)]
   float* d_tok_logits = nullptr;
   unsigned* d_splade = nullptr;  // allocated with the MLM head
+  int *d_sp_cnt = nullptr, *d_sp_idx = nullptr;   // device-side compaction of the SPLADE rows (grown on demand)
+  float* d_sp_val = nullptr;
+  int sp_cap = 0;
 
   // pinned staging
   int *h_ids = nullptr, *h_pos = nullptr, *h_tokseq = nullptr;
@@ -1384,6 +1418,43 @@ int vrag_encoder_read_splade(vrag_encoder* e, float* rows, void* stream) {
   const int V = e->cfg.vocab_size;
   HIP_TRY(hipMemcpy2DAsync(rows, (size_t)V * sizeof(float), e->d_splade, (size_t)e->vpad * sizeof(float),
                            (size_t)V * sizeof(float), e->n_seqs, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_splade_sparse(vrag_encoder* e, float threshold, int32_t cap_per_seq, int32_t* counts,
+                                    int32_t* indices, float* values, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(counts && indices && values && cap_per_seq > 0 && threshold >= 0.f, "bad arguments");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  if (cap_per_seq > e->sp_cap) {   // (re)allocate; the old buffers stay owned by the handle until destroy
+    if ((rc = dev_alloc(e, &e->d_sp_idx, (size_t)e->cfg.max_seqs * cap_per_seq, false))) return rc;
+    if ((rc = dev_alloc(e, &e->d_sp_val, (size_t)e->cfg.max_seqs * cap_per_seq, false))) return rc;
+    if (!e->d_sp_cnt && (rc = dev_alloc(e, &e->d_sp_cnt, e->cfg.max_seqs))) return rc;
+    e->sp_cap = cap_per_seq;
+  }
+  const int n = e->n_seqs, cap = cap_per_seq;
+  hipLaunchKernelGGL(splade_compact_kernel, dim3(n), dim3(256), 0, st, reinterpret_cast<const float*>(e->d_splade),
+                     e->cfg.vocab_size, e->vpad, threshold, cap, e->d_sp_cnt, e->d_sp_idx, e->d_sp_val);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(counts, e->d_sp_cnt, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int worst = 0;
+  for (int i = 0; i < n; ++i) worst = std::max(worst, counts[i]);
+  if (worst > cap) {
+    set_error("a SPLADE row has %d non-zero weights, capacity per sequence is %d", worst, cap);
+    return VRAG_ERR_CAPACITY;
+  }
+  // only the used prefix of every row travels: rows are cap apart on the device and in the caller's buffers
+  const size_t width = (size_t)std::max(worst, 1);
+  HIP_TRY(hipMemcpy2DAsync(indices, (size_t)cap * sizeof(int), e->d_sp_idx, (size_t)cap * sizeof(int), width * sizeof(int), n,
+                           hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpy2DAsync(values, (size_t)cap * sizeof(float), e->d_sp_val, (size_t)cap * sizeof(float),
+                           width * sizeof(float), n, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return VRAG_OK;
 }

@@ -18,6 +18,7 @@ from typing import Any, Dict, List, Sequence
 
 import numpy as np
 
+from ._lib import VragError
 from .packing import TokenizerAdapter
 
 
@@ -78,8 +79,9 @@ class _EncoderProvider:
 class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
     """SpladeProvider (embedding_providers.py:117-169) on the HIP encoder + fused SPLADE head."""
 
-    def __init__(self, engine: Any, tokenizer: Any, max_length: int = 512):
+    def __init__(self, engine: Any, tokenizer: Any, max_length: int = 512, sparse_cap: int = 1024):
         super().__init__(engine, tokenizer, max_length)
+        self.sparse_cap = int(sparse_cap)
         if not engine.has_mlm:
             raise ValueError("engine has no MLM head (EncoderEngine.set_mlm_head)")
 
@@ -94,18 +96,35 @@ class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
                 out[a:b] = self.engine.read_splade()
         return out
 
+    def _dicts(self, texts: Sequence[str], threshold: float) -> List[Dict[int, float]]:
+        """Rows compacted on the GPU (vocabulary order = np.nonzero order); a row with more than `sparse_cap`
+        entries (e.g. an untrained model) falls back to the dense read for that batch."""
+        seqs = self._encode(texts)
+        out: List[Dict[int, float]] = []
+        with self._lock:
+            for a, b in self._batches(seqs):
+                self.engine.load_batch(seqs[a:b])
+                self.engine.run()
+                self.engine.run_splade()
+                try:
+                    counts, idx, val = self.engine.read_splade_sparse(threshold, self.sparse_cap)
+                    for i in range(b - a):
+                        n = int(counts[i])
+                        out.append(dict(zip(idx[i, :n].tolist(), val[i, :n].tolist())))
+                except VragError as exc:
+                    if exc.status != -3:   # VRAG_ERR_CAPACITY
+                        raise
+                    rows = self.engine.read_splade()
+                    for row in rows:
+                        nz = np.nonzero(row > threshold)[0]
+                        out.append({int(i): float(row[i]) for i in nz})
+        return out
+
     def embed_text(self, text: str) -> Dict[int, float]:
-        row = self._rows([text])[0]
-        idx = np.nonzero(np.abs(row) > 1e-6)[0]          # embedding_providers.py:141-145
-        return {int(i): float(row[i]) for i in idx}
+        return self._dicts([text], 1e-6)[0]                # |w| > 1e-6, embedding_providers.py:141-145 (w >= 0)
 
     def embed_batch(self, texts: List[str]) -> List[Dict[int, float]]:
-        rows = self._rows(texts)
-        result = []
-        for row in rows:                                   # embedding_providers.py:161-163
-            idx = np.nonzero(row)[0]
-            result.append({int(i): float(row[i]) for i in idx})
-        return result
+        return self._dicts(texts, 0.0)                     # every non-zero, embedding_providers.py:161-163
 
     def get_dimension(self) -> int:
         return int(self.engine.shape.vocab_size)

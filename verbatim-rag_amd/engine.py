@@ -248,6 +248,17 @@ class EncoderEngine:
         _lib.check("vrag_encoder_read_splade", self._lib.vrag_encoder_read_splade(self._h, _fp(out), stream))
         return out
 
+    def read_splade_sparse(self, threshold: float = 0.0, cap_per_seq: int = 1024, stream: Optional[int] = None):
+        """(counts[n_seqs], indices[n_seqs, cap], values[n_seqs, cap]) compacted on the device, vocabulary index
+        ascending; raises VragError (status VRAG_ERR_CAPACITY = -3) when a row has more than cap_per_seq entries."""
+        n = self._n_seqs
+        counts = np.empty(n, dtype=np.int32)
+        idx = np.empty((n, cap_per_seq), dtype=np.int32)
+        val = np.empty((n, cap_per_seq), dtype=np.float32)
+        _lib.check("vrag_encoder_read_splade_sparse", self._lib.vrag_encoder_read_splade_sparse(
+            self._h, float(threshold), int(cap_per_seq), counts.ctypes.data_as(_IP), idx.ctypes.data_as(_IP), _fp(val), stream))
+        return counts, idx, val
+
     def read_hidden(self, final_norm: bool = True, stream: Optional[int] = None) -> np.ndarray:
         out = np.empty((self._n_tokens, self.shape.hidden_size), dtype=np.float32)
         _lib.check("vrag_encoder_read_hidden", self._lib.vrag_encoder_read_hidden(self._h, int(final_norm), _fp(out), stream))

@@ -119,12 +119,20 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # VRAG_BENCH_BACKEND=gloo: harness self-test on a box with fewer GPUs than ranks (ranks share devices, the
+    # barrier / max-reduce go through gloo on CPU tensors); the real multi-GPU run uses RCCL ("nccl").
+    backend = os.environ.get("VRAG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import verbatim_rag_amd  # noqa: F401
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
@@ -168,7 +176,7 @@ def main() -> None:
     elapsed = t1 - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     eng.set_profiling(False)

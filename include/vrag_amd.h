@@ -209,6 +209,10 @@ int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t
  * HBM-bound kernels of one overlap the MFMA-bound kernels of the other; 1 serialises them. */
 int vrag_encoder_set_concurrency(vrag_encoder* enc, int32_t n_streams);
 int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
+/* Tuning / tests: GEMMs over at most `rows` token rows use the small-batch configuration (128x128 tiles, four LDS
+ * stages in flight); 0 disables it.  Process-wide; returns the new threshold (default 4096). */
+int vrag_debug_set_gemm_small_m(int32_t rows);
+
 /* Diagnostics (kernel tuning): average ms of one GEMM instantiation (epilogue id as in
  * csrc/gemm_bf16.h, 7 = no epilogue) on synthetic [-1,1) operands. */
 int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t device, float* ms_out);

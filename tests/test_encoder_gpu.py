@@ -14,6 +14,18 @@ TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_
             intermediate_size=192, pad_token_id=0, cls_token_id=1, sep_token_id=2)
 
 
+@pytest.fixture(autouse=True, params=["small-batch GEMM config", "throughput GEMM config"])
+def gemm_config(request):
+    """Every test of this module runs twice: with the small-batch GEMM configuration (128x128 tiles, four LDS stages,
+    the default for <= 4096 rows) and with it disabled, so the 256x256 / 128x128 two-stage kernels see the same cases."""
+    from verbatim_rag_amd import _lib
+
+    lib = _lib.load()
+    lib.vrag_debug_set_gemm_small_m(4096 if request.param.startswith("small") else 0)
+    yield
+    lib.vrag_debug_set_gemm_small_m(4096)
+
+
 def _engine(cfg, w, **kw):
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
 

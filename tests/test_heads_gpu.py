@@ -77,9 +77,9 @@ def test_splade_device_compaction_equals_dense_rows(setup):
         counts, idx, val = eng.read_splade_sparse(thr, cap_per_seq=512)
         for i, row in enumerate(rows):
             nz = np.nonzero(row > thr)[0]
-            assert counts[i] == len(nz)
-            assert np.array_equal(idx[i, :counts[i]], nz)
-            assert np.array_equal(val[i, :counts[i]], row[nz])
+            assert counts[i] == len(nz), (thr, i, int(counts[i]), len(nz))
+            assert np.array_equal(idx[i, :counts[i]], nz), (thr, i, idx[i, :8].tolist(), nz[:8].tolist())
+            assert np.array_equal(val[i, :counts[i]], row[nz]), (thr, i)
     worst = int(max((r > 0).sum() for r in rows))
     with pytest.raises(VragError) as ei:
         eng.read_splade_sparse(0.0, cap_per_seq=max(1, worst - 1))

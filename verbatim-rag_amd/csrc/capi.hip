@@ -1489,6 +1489,11 @@ int vrag_encoder_extract_qa(vrag_encoder* e, const int32_t* ids, const int32_t* 
   return vrag_encoder_read_qa_logits(e, logits, nullptr);
 }
 
+int vrag_debug_set_gemm_small_m(int32_t rows) {
+  ARG_CHECK(rows >= 0, "rows must be >= 0");
+  return gemm_small_m_threshold(rows);
+}
+
 // Diagnostics: times `iters` launches of one GEMM instantiation on synthetic operands (HIP events).
 int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t device, float* ms_out) {
   ARG_CHECK(ms_out && M > 0 && N % 128 == 0 && K % 64 == 0 && iters > 0, "bad arguments");

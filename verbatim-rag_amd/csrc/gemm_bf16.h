@@ -60,5 +60,8 @@ struct GemmParams {
 // Launches on `stream`. Requirements: N % 128 == 0, K % 64 == 0.
 hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream);
 const char* gemm_kernel_name(GemmEpi epi);
+// GEMMs with M <= threshold rows use the small-batch configuration (128x128 tiles, four LDS stages).
+// set_to >= 0 changes the threshold (0 disables the configuration); returns the current value.
+int gemm_small_m_threshold(int set_to);
 
 }  // namespace vrag

@@ -23,6 +23,8 @@
 // partners sit in the same lane and register index of acc[0][mi] / acc[1][mi].
 #include "gemm_bf16.h"
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -357,9 +359,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 
 // BM x BN tile, WM x WN waves; every wave owns (BM/WM) x 64 outputs (MI = BM/WM/32 row tiles, 2 column tiles).
 // DBG = 1 compiles the main-loop decomposition probe (p.debug_flags), instantiated for EPI_NONE only.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0>
+// NS = LDS stages (power of two).  2: the throughput configuration (one stage in flight, plain barriers).  4: the
+// small-batch configuration -- with a handful of tiles the K loop is a chain of memory round trips, and three
+// stages in flight (counted vmcnt, raw barriers) cut that chain to a third.
+template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
+  static_assert(NS == 2 || NS == 4, "LDS stages");
   constexpr int NT = WM * WN * 64;            // threads
   constexpr int MI = BM / WM / 32;            // 32-row accumulator tiles per wave
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -438,9 +444,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
 
   auto mainloop = [&](auto swapped_tag) {
     constexpr bool SWAPPED = decltype(swapped_tag)::value;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    constexpr int NI = A_INSTR + W_INSTR;   // LDS-DMA instructions per wave per stage
+    auto wait_allow = [&](int stages_in_flight) {   // this wave's DMA is retired except the newest `stages_in_flight` stages
+      if (NS > 2 && stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+      else if (NS > 2 && stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto step_barrier = [&]() {
+      if constexpr (NS == 2) {
+        __syncthreads();
+      } else {   // DMA of later stages stays in flight across the barrier: no implicit vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+      if (i < KT) stage(i, i);
+    wait_allow(min(NS - 1, KT) - 1);
+    step_barrier();
     bf16x8 dbg_f[MI + 2] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
     if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
@@ -457,19 +479,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
       }
     }
     for (int kt = 0; kt < KT; ++kt) {
-      const int buf = kt & 1;
-      const bool do_stage = kt + 1 < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
+      const int buf = kt & (NS - 1);
+      const int nxt = kt + NS - 1, nbuf = nxt & (NS - 1);   // the slot read in step kt-1: every wave passed the barrier since
+      const bool do_stage = nxt < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
 #if VRAG_DMA_SPLIT == 0
-      if (do_stage) stage(kt + 1, buf ^ 1);
+      if (do_stage) stage(nxt, nbuf);
 #elif VRAG_DMA_SPLIT == 1
-      if (do_stage && wave < (WM * WN) / 2) stage(kt + 1, buf ^ 1);   // first half of the waves: right after the barrier
+      if (do_stage && wave < (WM * WN) / 2) stage(nxt, nbuf);   // first half of the waves: right after the barrier
 #endif
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * 128;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * 128;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #if VRAG_DMA_SPLIT == 1
-        if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(kt + 1, buf ^ 1);   // second half: one substep later
+        if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(nxt, nbuf);   // second half: one substep later
 #endif
         bf16x8 af[MI] = {}, wf[2] = {};
         if (DBG && (p.debug_flags & 8)) {
@@ -509,8 +532,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
               acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], wf[ni], acc[ni][mi], 0, 0, 0);
           }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      wait_allow(max(0, min(NS - 2, KT - 2 - kt)));   // step kt+1 has landed (this wave's share)
+      step_barrier();
     }
   };
   if (v_block) mainloop(std::false_type{});
@@ -521,10 +544,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
   }  // tile loop
 }
 
+int gemm_small_m_threshold(int set_to) {
+  static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 4096};
+  if (set_to >= 0) thr.store(set_to);
+  return thr.load();
+}
+
 template <int EPI>
 hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
   static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr;  // tuning knob
+  // Small batches (a query's handful of chunks): few tiles, so the K loop's chain of memory round trips is the
+  // whole kernel -- 128x128 tiles (4x the workgroups) with four LDS stages (three K-steps in flight).
+  if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) {
+    constexpr int BM = 128, BN = 128, SMEM = 4 * (BM + BN) * BK * 2;   // 128 KiB, one workgroup per CU
+    static bool attr_s = false;
+    if (!attr_s) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+      if (e != hipSuccess) return e;
+      attr_s = true;
+    }
+    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    p.n_tiles = nbm * nbn;
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4>), dim3(std::min(nbm * nbn, 256)), dim3(256), SMEM, stream, p);
+    return hipGetLastError();
+  }
   if (!force128 && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
     constexpr int BM = 256, BN = 256, SMEM = 2 * (BM + BN) * BK * 2;
     static bool attr = false;

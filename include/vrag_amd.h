@@ -210,7 +210,7 @@ int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t
 int vrag_encoder_set_concurrency(vrag_encoder* enc, int32_t n_streams);
 int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
 /* Tuning / tests: GEMMs over at most `rows` token rows use the small-batch configuration (128x128 tiles, four LDS
- * stages in flight); 0 disables it.  Process-wide; returns the new threshold (default 4096). */
+ * stages in flight); 0 disables it.  Process-wide; returns the new threshold (default 8192). */
 int vrag_debug_set_gemm_small_m(int32_t rows);
 
 /* Diagnostics (kernel tuning): average ms of one GEMM instantiation (epilogue id as in

@@ -17,13 +17,13 @@ TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_
 @pytest.fixture(autouse=True, params=["small-batch GEMM config", "throughput GEMM config"])
 def gemm_config(request):
     """Every test of this module runs twice: with the small-batch GEMM configuration (128x128 tiles, four LDS stages,
-    the default for <= 4096 rows) and with it disabled, so the 256x256 / 128x128 two-stage kernels see the same cases."""
+    the default for <= 8192 rows) and with it disabled, so the 256x256 / 128x128 two-stage kernels see the same cases."""
     from verbatim_rag_amd import _lib
 
     lib = _lib.load()
-    lib.vrag_debug_set_gemm_small_m(4096 if request.param.startswith("small") else 0)
+    lib.vrag_debug_set_gemm_small_m(8192 if request.param.startswith("small") else 0)
     yield
-    lib.vrag_debug_set_gemm_small_m(4096)
+    lib.vrag_debug_set_gemm_small_m(8192)
 
 
 def _engine(cfg, w, **kw):

@@ -21,10 +21,10 @@ def main():
     from verbatim_rag_amd.weights import random_init, random_qa_head
 
     shape = ModernBertShape.base()
-    eng = EncoderEngine(shape, random_init(shape, 1234), max_tokens=8192, max_seqs=64, max_seq_len=512, max_ranges=1024)
+    eng = EncoderEngine(shape, random_init(shape, 1234), max_tokens=32768, max_seqs=64, max_seq_len=512, max_ranges=4096)
     eng.set_qa_head(*random_qa_head(shape))
     rng = np.random.default_rng(0)
-    for k, S in ((1, 200), (5, 200), (5, 512), (16, 512)):
+    for k, S in ((1, 200), (5, 200), (5, 512), (8, 512), (16, 512), (32, 512), (64, 512)):
         seqs = [rng.integers(1000, 50000, size=S).astype(np.int32) for _ in range(k)]
         bounds = [[(1 + 12 * j, 12 * j + 11) for j in range(S // 12 - 1)] for _ in range(k)]
         for _ in range(5):

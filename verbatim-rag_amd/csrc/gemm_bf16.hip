@@ -545,7 +545,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
 }
 
 int gemm_small_m_threshold(int set_to) {
-  static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 4096};
+  static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 8192};
   if (set_to >= 0) thr.store(set_to);
   return thr.load();
 }

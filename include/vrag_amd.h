@@ -149,6 +149,20 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* enc, const float* dense_w /*[H,H]
                                  const float* norm_w /*[H]*/, const float* norm_b /*[H]*/,
                                  const float* decoder_w /*[V,H] or NULL*/, const float* decoder_b /*[V]*/);
 
+/* Sentence-pair inputs (cross-encoder reranking: sentence-transformers CrossEncoder over
+ * BertForSequenceClassification, verbatim_rag/rerankers.py:109-134).  BERT-family handles only.
+ * set_token_types: the whole token_type_embeddings table [n_types, H] (the creator only takes row 0).
+ * load_token_types: per-token segment ids of the batch loaded last (concatenation order of load_batch);
+ *   stays in effect until the next load_batch.
+ * set_pair_head / run_pair_head: logits[s] = cls_w . tanh(pooler_w . h[first token of s] + pooler_b) + cls_b
+ *   (BertPooler + classifier, transformers models/bert/modeling_bert.py:451-463,1115-1119). */
+int vrag_encoder_set_token_types(vrag_encoder* enc, const float* table /*[n_types, H]*/, int32_t n_types);
+int vrag_encoder_load_token_types(vrag_encoder* enc, const int32_t* types /*[n_tokens]*/, void* stream);
+int vrag_encoder_set_pair_head(vrag_encoder* enc, const float* pooler_w /*[H,H]*/, const float* pooler_b /*[H]*/,
+                               const float* cls_w /*[labels,H]*/, const float* cls_b /*[labels]*/, int32_t num_labels);
+int vrag_encoder_run_pair_head(vrag_encoder* enc, void* stream);
+int vrag_encoder_read_pair_logits(vrag_encoder* enc, float* logits /*[n_seqs, labels]*/, void* stream);
+
 /* Packed batch: `ids` is the plain concatenation of n_seqs unpadded sequences of lengths
  * seq_lens[i] (positions restart at 0 per sequence, like the reference's B=1 forward). */
 int vrag_encoder_load_batch(vrag_encoder* enc, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,

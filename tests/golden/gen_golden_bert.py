@@ -12,7 +12,8 @@ import os
 
 import numpy as np
 import torch
-from transformers import BertConfig, BertForMaskedLM, DistilBertConfig, DistilBertForMaskedLM
+from transformers import (BertConfig, BertForMaskedLM, BertForSequenceClassification, DistilBertConfig,
+                          DistilBertForMaskedLM)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -68,7 +69,26 @@ def main():
     out = run(d, d.distilbert, ids_list)
     sd = {"sd:" + k: v.detach().numpy().astype(np.float32) for k, v in d.state_dict().items()}
     np.savez_compressed(os.path.join(HERE, "distilbert_tiny.npz"), cfg=np.asarray([V, H, L, NH, I, P], dtype=np.int32), **sd, **out)
-    print("wrote bert_tiny.npz, distilbert_tiny.npz")
+    # cross-encoder (BertForSequenceClassification, num_labels 1, MiniLM-like head_dim 32, sentence pairs with token types)
+    torch.manual_seed(13)
+    ccfg = BertConfig(vocab_size=V, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                      max_position_embeddings=P, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                      num_labels=1, attn_implementation="eager")
+    c = perturb(BertForSequenceClassification(ccfg), 3)
+    c.eval()
+    out = {}
+    pairs = [(9, 28), (20, 40), (3, 5)]
+    with torch.no_grad():
+        for i, (nq, nd) in enumerate(pairs):
+            ids = [1] + rng.integers(5, V, size=nq).tolist() + [2] + rng.integers(5, V, size=nd).tolist() + [2]
+            tt = [0] * (nq + 2) + [1] * (nd + 1)
+            r = c(input_ids=torch.tensor([ids]), token_type_ids=torch.tensor([tt]), output_hidden_states=True)
+            out[f"ids{i}"], out[f"types{i}"] = np.asarray(ids, np.int32), np.asarray(tt, np.int32)
+            out[f"hidden{i}"] = r.hidden_states[-1][0].numpy().astype(np.float32)
+            out[f"logits{i}"] = r.logits[0].numpy().astype(np.float32)
+    sd = {"sd:" + k: v.detach().numpy().astype(np.float32) for k, v in c.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "bert_pair_tiny.npz"), cfg=np.asarray([V, 128, 2, 4, 256, P], dtype=np.int32), **sd, **out)
+    print("wrote bert_tiny.npz, distilbert_tiny.npz, bert_pair_tiny.npz")
 
 
 if __name__ == "__main__":

@@ -170,3 +170,37 @@ def test_rejects_unsupported_shapes():
                     max_position_embeddings=64)   # head_dim 16
     with pytest.raises(VragError, match="head_dim must be 32 or 64"):
         BertEncoderEngine(shp, random_init_bert(shp, mlm=False), max_tokens=256, max_seqs=2, max_seq_len=64, max_ranges=4)
+
+
+def test_cross_encoder_pairs_vs_transformers_golden():
+    """BertForSequenceClassification (4 heads x 32: zero-padded heads; token types 0 / 1; pooler + classifier):
+    hidden states and the pair logit against the golden vectors, batched and alone."""
+    from verbatim_rag_amd.engine import BertEncoderEngine
+    from verbatim_rag_amd.weights import bert_canonical
+
+    z = np.load(os.path.join(GOLD, "bert_pair_tiny.npz"))
+    V, H, L, NH, I, P = (int(x) for x in z["cfg"])
+    cfg = B.BertConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=NH, intermediate_size=I,
+                       max_position_embeddings=P)
+    W = bert_canonical({k[3:]: z[k] for k in z.files if k.startswith("sd:")})
+    eng = BertEncoderEngine(_shape(cfg, "bert"), W, max_tokens=1024, max_seqs=8, max_seq_len=64, max_ranges=8)
+    try:
+        assert eng.pair_labels == 1
+        seqs = [z[f"ids{i}"] for i in range(3)]
+        types = [z[f"types{i}"] for i in range(3)]
+        logits = eng.pair_logits(seqs, types)
+        hid = eng.read_hidden(final_norm=False)
+        o = 0
+        for i, s in enumerate(seqs):
+            assert np.abs(hid[o:o + len(s)] - z[f"hidden{i}"]).max() < 3e-2
+            assert np.abs(logits[i] - z[f"logits{i}"]).max() < 5e-3, (logits[i], z[f"logits{i}"])
+            o += len(s)
+        alone = eng.pair_logits([seqs[1]], [types[1]])
+        assert np.array_equal(alone[0], logits[1])
+        # without segment ids every token gets type 0: a different (and wrong for pairs) result, not a crash
+        eng.load_batch([seqs[1]])
+        eng.run()
+        h0 = eng.read_hidden(final_norm=False)
+        assert np.abs(h0 - z["hidden1"]).max() > 1e-3
+    finally:
+        eng.close()

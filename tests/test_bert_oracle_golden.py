@@ -39,6 +39,7 @@ def test_product_weight_converter_equals_oracle_converter(name):
 
     _, _, sd = _load(name)
     a, b = bert_canonical(sd), B.canonical_from_hf(sd)
+    assert ("emb.types" in a) == (name == "bert_tiny")
     assert set(a) == set(b)
     assert all(np.array_equal(a[k], b[k]) for k in a)
     # prefixed names (BertForMaskedLM) and bare names (BertModel) give the same encoder tensors
@@ -77,3 +78,17 @@ def test_random_init_bert_shapes():
     assert (d.hidden_size, d.num_hidden_layers, d.model_type) == (256, 3, "distilbert")
     W2 = random_init_bert(d, seed=2)
     assert "emb.type0" not in W2
+
+
+def test_pair_head_oracle_matches_transformers():
+    z, cfg, sd = _load("bert_pair_tiny")
+    W = B.canonical_from_hf(sd)
+    import verbatim_rag_amd  # noqa: F401
+    from verbatim_rag_amd.weights import bert_canonical
+
+    P = bert_canonical(sd)
+    assert set(P) == set(W) and all(np.array_equal(P[k], W[k]) for k in W)
+    for i in range(3):
+        h = B.encoder_forward(cfg, W, z[f"ids{i}"], type_ids=z[f"types{i}"])
+        assert np.abs(h - z[f"hidden{i}"]).max() < 2e-5
+        assert np.abs(B.pair_logits(cfg, W, h) - z[f"logits{i}"]).max() < 2e-6

@@ -81,6 +81,11 @@ SIGNATURES = {
     "vrag_encoder_set_token_head": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int32]),
     "vrag_encoder_set_mlm_head": (C.c_int, [_H, _FP, _FP, _FP, _FP]),
     "vrag_encoder_set_mlm_head_ex": (C.c_int, [_H, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "vrag_encoder_set_token_types": (C.c_int, [_H, _FP, C.c_int32]),
+    "vrag_encoder_load_token_types": (C.c_int, [_H, _IP, C.c_void_p]),
+    "vrag_encoder_set_pair_head": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int32]),
+    "vrag_encoder_run_pair_head": (C.c_int, [_H, C.c_void_p]),
+    "vrag_encoder_read_pair_logits": (C.c_int, [_H, _FP, C.c_void_p]),
     "vrag_encoder_load_batch": (C.c_int, [_H, _IP, _IP, C.c_int32, C.c_void_p]),
     "vrag_encoder_run": (C.c_int, [_H, C.c_void_p]),
     "vrag_encoder_run_layers": (C.c_int, [_H, C.c_int32, C.c_void_p]),

@@ -176,6 +176,16 @@ struct vrag_encoder {
   float *pos_emb = nullptr, *type_row = nullptr, *emb_norm_b = nullptr;
   std::vector<BertLayer> blayers;
   float *mlm_dense_b = nullptr, *mlm_norm_b = nullptr;
+  // sentence-pair inputs + cross-encoder head (arch 1)
+  float* type_table = nullptr;   // [n_types, H] token_type_embeddings
+  int n_types = 0;
+  int* d_types = nullptr;        // [cap_rows] per-token segment id of the current batch
+  int* h_types = nullptr;
+  bool types_loaded = false;
+  float *pr_wp = nullptr, *pr_bp = nullptr, *pr_wc = nullptr, *pr_bc = nullptr;
+  int pr_labels = 0;
+  int *d_first_row = nullptr, *h_first_row = nullptr;   // [max_seqs]
+  float* d_pair_out = nullptr;                          // [max_seqs, pr_labels]
   int i_pad = 0;        // GeGLU width padded to a multiple of 128 (2*i_pad = whole 256-wide GEMM tiles)
   int attn_w = 0;       // width of the q / k / v^T / o buffers = num_heads * 64 (> hidden_size when head_dim is 32)
   float q_scale = 0.125f * 1.4426950408889634f;  // head_dim^-1/2 * log2(e)
@@ -546,7 +556,8 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
     {
       ProfScope ps(e, VRAG_PROF_EMBED, st);
       HIP_TRY(launch_embed_ln(e->d_ids + r0, e->tok_emb, e->emb_norm, c.norm_eps, H, M, h, a, st, e->pos_emb,
-                              e->d_pos + r0, e->type_row, e->emb_norm_b));
+                              e->d_pos + r0, e->types_loaded ? e->type_table : e->type_row, e->emb_norm_b,
+                              e->types_loaded ? e->d_types + r0 : nullptr));
     }
     const bool fold = e->ln_fold;
     float* st_part = e->st_part + (size_t)r0 * (H / 64) * 2;
@@ -1122,6 +1133,97 @@ int vrag_encoder_set_mlm_head(vrag_encoder* e, const float* dense_w, const float
   return vrag_encoder_set_mlm_head_ex(e, dense_w, nullptr, norm_w, nullptr, decoder_w, decoder_b);
 }
 
+int vrag_encoder_set_token_types(vrag_encoder* e, const float* table, int32_t n_types) {
+  ARG_CHECK(e && table && n_types > 0, "bad token type arguments");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  ARG_CHECK(e->arch == 1, "token types exist on BERT-family handles only");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  int rc = upload_f32(e, &e->type_table, table, (size_t)n_types * e->cfg.hidden_size);
+  if (rc) return rc;
+  if (!e->d_types) {
+    if ((rc = dev_alloc(e, &e->d_types, e->cap_rows))) return rc;
+    if ((rc = host_alloc(e, &e->h_types, e->cap_rows))) return rc;
+  }
+  e->n_types = n_types;
+  return VRAG_OK;
+}
+
+int vrag_encoder_load_token_types(vrag_encoder* e, const int32_t* types, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(types, "null token types");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  ARG_CHECK(e->type_table != nullptr, "token type table not set (vrag_encoder_set_token_types)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  HIP_TRY(hipStreamSynchronize(st));   // a previous upload may still read the pinned staging buffer
+  memset(e->h_types, 0, (size_t)e->rows * sizeof(int));
+  size_t src = 0;
+  for (int s = 0; s < e->n_seqs; ++s) {
+    for (int i = 0; i < e->seq_len[s]; ++i) {
+      const int t = types[src + i];
+      ARG_CHECK(t >= 0 && t < e->n_types, "token type %d outside the table (sequence %d)", t, s);
+      e->h_types[e->seq_start[s] + i] = t;
+    }
+    src += e->seq_len[s];
+  }
+  HIP_TRY(hipMemcpyAsync(e->d_types, e->h_types, (size_t)e->rows * sizeof(int), hipMemcpyHostToDevice, st));
+  e->types_loaded = true;
+  e->ran = false;
+  return VRAG_OK;
+}
+
+int vrag_encoder_set_pair_head(vrag_encoder* e, const float* pooler_w, const float* pooler_b, const float* cls_w,
+                               const float* cls_b, int32_t num_labels) {
+  ARG_CHECK(e && pooler_w && pooler_b && cls_w && cls_b && num_labels > 0 && num_labels <= 64, "bad pair head arguments");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int H = e->cfg.hidden_size;
+  int rc;
+  if ((rc = upload_f32(e, &e->pr_wp, pooler_w, (size_t)H * H))) return rc;
+  if ((rc = upload_f32(e, &e->pr_bp, pooler_b, H))) return rc;
+  if ((rc = upload_f32(e, &e->pr_wc, cls_w, (size_t)num_labels * H))) return rc;
+  if ((rc = upload_f32(e, &e->pr_bc, cls_b, num_labels))) return rc;
+  if ((rc = dev_alloc(e, &e->d_pair_out, (size_t)e->cfg.max_seqs * num_labels))) return rc;
+  if (!e->d_first_row) {
+    if ((rc = dev_alloc(e, &e->d_first_row, e->cfg.max_seqs))) return rc;
+    if ((rc = host_alloc(e, &e->h_first_row, e->cfg.max_seqs))) return rc;
+  }
+  e->pr_labels = num_labels;
+  return VRAG_OK;
+}
+
+int vrag_encoder_run_pair_head(vrag_encoder* e, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  ARG_CHECK(e->pr_labels > 0, "pair head not set (vrag_encoder_set_pair_head)");
+  ARG_CHECK(e->ran, "encoder has not run on this batch");
+  ARG_CHECK(e->final_norm == nullptr, "the pair head reads an already-normalised stream (BERT-family handles)");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int s = 0; s < e->n_seqs; ++s) e->h_first_row[s] = e->seq_start[s];
+  HIP_TRY(hipMemcpyAsync(e->d_first_row, e->h_first_row, (size_t)e->n_seqs * sizeof(int), hipMemcpyHostToDevice, st));
+  ProfScope ps(e, VRAG_PROF_HEAD, st);
+  HIP_TRY(launch_pooler_classifier(e->h, e->cfg.hidden_size, e->d_first_row, e->n_seqs, e->pr_wp, e->pr_bp, e->pr_wc,
+                                   e->pr_bc, e->pr_labels, e->d_pair_out, st));
+  return VRAG_OK;
+}
+
+int vrag_encoder_read_pair_logits(vrag_encoder* e, float* logits, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  ARG_CHECK(logits, "null output");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  ARG_CHECK(e->pr_labels > 0, "pair head not set");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  HIP_TRY(hipMemcpyAsync(logits, e->d_pair_out, (size_t)e->n_seqs * e->pr_labels * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return VRAG_OK;
+}
+
 int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* seq_lens, int32_t n_seqs,
                             void* stream) {
   ARG_CHECK(e && ids && seq_lens && n_seqs > 0, "bad batch arguments");
@@ -1219,6 +1321,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   e->n_blocks = nblk;
   e->n_ranges = 0;
   e->ran = false;
+  e->types_loaded = false;   // segment ids belong to one batch
   HIP_TRY(hipMemcpyAsync(e->d_ids, e->h_ids, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->d_pos, e->h_pos, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->d_tokseq, e->h_tokseq, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));

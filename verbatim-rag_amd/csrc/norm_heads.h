@@ -10,7 +10,8 @@ namespace vrag {
 // the LayerNorm bias (TF:models/bert/modeling_bert.py:53-62, models/distilbert/modeling_distilbert.py:82-116).
 hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows,
                            float* h, bf16_t* a, hipStream_t stream, const float* P = nullptr,
-                           const int* pos = nullptr, const float* type_row = nullptr, const float* bias = nullptr);
+                           const int* pos = nullptr, const float* type_row = nullptr, const float* bias = nullptr,
+                           const int* type_ids = nullptr);   // type_ids: per-token row of the table at type_row
 
 // out = LN(h) * w (+ bias); writes bf16 and/or fp32 (either pointer may be null; out_f32 may be h itself).
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows,
@@ -29,5 +30,10 @@ hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H,
 hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows,
                                 const float* Wc, const float* bc, int num_labels, float* logits,
                                 hipStream_t stream, const float* lnb = nullptr);
+
+// logits[s][c] = Wc[c] . tanh(Wp . h[first[s]] + bp) + bc[c]   (BertPooler + classifier; one workgroup per sequence)
+hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row, int n_seqs, const float* Wp,
+                                    const float* bp, const float* Wc, const float* bc, int num_labels, float* logits,
+                                    hipStream_t stream);
 
 }  // namespace vrag

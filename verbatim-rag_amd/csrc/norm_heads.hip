@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
                                                         float* __restrict__ h, bf16_t* __restrict__ a,
                                                         const float* __restrict__ P, const int* __restrict__ pos,
                                                         const float* __restrict__ type_row,
-                                                        const float* __restrict__ bias) {
+                                                        const float* __restrict__ bias,
+                                                        const int* __restrict__ type_ids) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
   if (P) {  // (word + token_type) + position, the reference's order of additions (TF:models/bert/modeling_bert.py:100-104)
     f32x4 y[MAXV];
     if (type_row) {
-      load_row(type_row, H, lane, y);
+      load_row(type_row + (type_ids ? (size_t)type_ids[row] * H : 0), H, lane, y);
 #pragma unroll
       for (int i = 0; i < MAXV; ++i) x[i] += y[i];
     }
@@ -214,15 +215,58 @@ __global__ __launch_bounds__(256) void ln_classifier_kernel(const float* __restr
   }
 }
 
+// One workgroup per sequence.  Phase 1: the 4 waves split the H pooler rows, a wave owns a row at a time
+// (lanes stride the H inputs, wave-shuffle reduction) and leaves tanh(.) in LDS; phase 2: one wave per label.
+__global__ __launch_bounds__(256) void pooler_classifier_kernel(const float* __restrict__ h, int H,
+                                                                 const int* __restrict__ first_row,
+                                                                 const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                                 const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                                 int num_labels, float* __restrict__ logits) {
+  __shared__ float pooled[MAXV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x;
+  f32x4 x[MAXV];
+  load_row(h + (size_t)first_row[s] * H, H, lane, x);
+  for (int r = wave; r < H; r += 4) {
+    f32x4 wv[MAXV];
+    load_row(Wp + (size_t)r * H, H, lane, wv);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += x[i][j] * wv[i][j];
+    d = wave_sum(d);
+    if (lane == 0) pooled[r] = tanhf(d + bp[r]);
+  }
+  __syncthreads();
+  f32x4 pv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    pv[i] = c < H ? *reinterpret_cast<const f32x4*>(&pooled[c]) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int c = wave; c < num_labels; c += 4) {
+    f32x4 wc[MAXV];
+    load_row(Wc + (size_t)c * H, H, lane, wc);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += pv[i][j] * wc[i][j];
+    d = wave_sum(d);
+    if (lane == 0) logits[(size_t)s * num_labels + c] = d + bc[c];
+  }
+}
+
 }  // namespace
 
 hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows, float* h,
                            bf16_t* a, hipStream_t stream, const float* P, const int* pos, const float* type_row,
-                           const float* bias) {
+                           const float* bias, const int* type_ids) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3) || (P && !pos)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a, P, pos,
-                     type_row, bias);
+                     type_row, bias, type_ids);
   return hipGetLastError();
 }
 
@@ -250,6 +294,16 @@ hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int
   if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_classifier_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, lnw, eps, H, rows, Wc, bc,
                      num_labels, logits, lnb);
+  return hipGetLastError();
+}
+
+hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row, int n_seqs, const float* Wp,
+                                    const float* bp, const float* Wc, const float* bc, int num_labels, float* logits,
+                                    hipStream_t stream) {
+  if (n_seqs <= 0) return hipSuccess;
+  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pooler_classifier_kernel, dim3(n_seqs), dim3(256), 0, stream, h, H, first_row, Wp, bp, Wc, bc, num_labels,
+                     logits);
   return hipGetLastError();
 }
 

@@ -392,6 +392,12 @@ class BertEncoderEngine(EncoderEngine):
         self.max_seq_len = min(max_seq_len, shape.max_position_embeddings)
         _lib.check("vrag_bert_encoder_create", self._lib.vrag_bert_encoder_create(C.byref(cfg), C.byref(cw), C.byref(self._h)))
         self._init_state()
+        self.pair_labels = 0
+        if "emb.types" in weights:
+            t = _f32(weights["emb.types"])
+            _lib.check("vrag_encoder_set_token_types", self._lib.vrag_encoder_set_token_types(self._h, _fp(t), t.shape[0]))
+        if "pooler.w" in weights and "cls.w" in weights:
+            self.set_pair_head(weights["pooler.w"], weights["pooler.b"], weights["cls.w"], weights["cls.b"])
         if "mlm.dense.w" in weights:
             self.set_mlm_head_ex(weights["mlm.dense.w"], weights["mlm.dense.b"], weights["mlm.ln.w"], weights["mlm.ln.b"],
                                  weights.get("mlm.dec.b"), weights.get("mlm.dec.w"))
@@ -403,3 +409,30 @@ class BertEncoderEngine(EncoderEngine):
         _lib.check("vrag_encoder_set_mlm_head_ex",
                    self._lib.vrag_encoder_set_mlm_head_ex(self._h, _fp(d), p(db), _fp(n), p(nb), p(dw), p(b)))
         self.has_mlm = True
+
+    # ------------------------------------------------------------------ sentence pairs (cross-encoder reranking)
+    def set_pair_head(self, pooler_w, pooler_b, cls_w, cls_b) -> None:
+        pw, pb, cw, cb = _f32(pooler_w), _f32(pooler_b), _f32(cls_w), _f32(cls_b)
+        _lib.check("vrag_encoder_set_pair_head",
+                   self._lib.vrag_encoder_set_pair_head(self._h, _fp(pw), _fp(pb), _fp(cw), _fp(cb), cw.shape[0]))
+        self.pair_labels = int(cw.shape[0])
+
+    def load_token_types(self, type_ids: Sequence[Sequence[int]], stream: Optional[int] = None) -> None:
+        """Per-token segment ids of the batch loaded last (same order and lengths as `load_batch`)."""
+        flat = _i32(np.concatenate([np.asarray(t, dtype=np.int32) for t in type_ids]))
+        if len(flat) != self._n_tokens:
+            raise ValueError(f"{len(flat)} token types for a batch of {self._n_tokens} tokens")
+        _lib.check("vrag_encoder_load_token_types",
+                   self._lib.vrag_encoder_load_token_types(self._h, flat.ctypes.data_as(_IP), stream))
+
+    def pair_logits(self, sequences: Sequence[Sequence[int]], type_ids: Sequence[Sequence[int]]) -> np.ndarray:
+        """[n_seqs, labels] = classifier(tanh(pooler(h[CLS]))) for packed `[CLS] a [SEP] b [SEP]` sequences."""
+        if not self.pair_labels:
+            raise ValueError("engine has no pair head (pooler.* / classifier.* weights or set_pair_head)")
+        self.load_batch(sequences)
+        self.load_token_types(type_ids)
+        self.run()
+        _lib.check("vrag_encoder_run_pair_head", self._lib.vrag_encoder_run_pair_head(self._h, None))
+        out = np.empty((self._n_seqs, self.pair_labels), dtype=np.float32)
+        _lib.check("vrag_encoder_read_pair_logits", self._lib.vrag_encoder_read_pair_logits(self._h, _fp(out), None))
+        return out

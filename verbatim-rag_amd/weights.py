@@ -93,6 +93,11 @@ def bert_canonical(tensors: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     W["emb.ln.w"], W["emb.ln.b"] = t["embeddings.LayerNorm.weight"], t["embeddings.LayerNorm.bias"]
     if not distil:
         W["emb.type0"] = np.ascontiguousarray(t["embeddings.token_type_embeddings.weight"][0])
+        W["emb.types"] = t["embeddings.token_type_embeddings.weight"]       # sentence pairs (cross-encoders)
+        if "pooler.dense.weight" in t:
+            W["pooler.w"], W["pooler.b"] = t["pooler.dense.weight"], t["pooler.dense.bias"]
+        if "classifier.weight" in t:                                        # BertForSequenceClassification
+            W["cls.w"], W["cls.b"] = t["classifier.weight"], t["classifier.bias"]
     names = ({"q": "attention.q_lin", "k": "attention.k_lin", "v": "attention.v_lin", "o": "attention.out_lin",
               "ln1": "sa_layer_norm", "w1": "ffn.lin1", "w2": "ffn.lin2", "ln2": "output_layer_norm"} if distil else
              {"q": "attention.self.query", "k": "attention.self.key", "v": "attention.self.value",

@@ -79,3 +79,36 @@ def test_rerank_order_head_tail_and_batching():
     assert rr2._get_texts(results[:1]) == ["enh w1 w2"]
     with pytest.raises(ValueError):
         GpuCrossEncoderReranker(types.SimpleNamespace(pair_labels=0), tok)
+
+
+def test_pipeline_applies_reranker_between_retrieval_and_extraction():
+    from verbatim_rag_amd.pipeline import StaticVerbatimPipeline
+
+    results = [_res(0, "Alpha one. Beta two."), _res(1, "Gamma three.")]
+
+    class Index:
+        def query(self, **kw):
+            return list(results)
+
+    class Extractor:
+        def __init__(self):
+            self.seen = None
+
+        def extract_spans(self, question, rs):
+            self.seen = [r.id for r in rs]
+            return {r.text: [r.text.split(". ")[0].rstrip(".") + "."] if "." in r.text else [] for r in rs}
+
+    class Reverse:
+        def rerank(self, q, rs):
+            return list(reversed(rs))
+
+    class Broken:
+        def rerank(self, q, rs):
+            raise RuntimeError("down")
+
+    ex = Extractor()
+    resp = StaticVerbatimPipeline(Index(), ex, reranker=Reverse()).query("q")
+    assert ex.seen == ["id1", "id0"] and resp.answer.index("Gamma") < resp.answer.index("Alpha")
+    ex2 = Extractor()
+    StaticVerbatimPipeline(Index(), ex2, reranker=Broken()).query("q")
+    assert ex2.seen == ["id0", "id1"]

@@ -36,13 +36,27 @@ def fill_static_template(display_spans: List[Dict[str, Any]], template: str = DE
 
 
 class StaticVerbatimPipeline:
-    def __init__(self, index, extractor, k: int = 5, max_display_spans: int = 5):
+    def __init__(self, index, extractor, k: int = 5, max_display_spans: int = 5, reranker=None):
         self.index, self.extractor, self.k, self.max_display_spans = index, extractor, k, max_display_spans
+        self.reranker = reranker
         self.response_builder = ResponseBuilder()
+
+    def _apply_reranker(self, question: str, results: list):
+        """core.py:125-132: optional hook between retrieval and extraction; a failing reranker keeps the order."""
+        if not self.reranker:
+            return results
+        try:
+            return self.reranker.rerank(question, results)
+        except Exception as exc:
+            import logging
+
+            logging.warning(f"Reranker failed, using original order: {exc}")
+            return results
 
     def query(self, question: str, k: Optional[int] = None, filter: Optional[str] = None,
               hybrid_weights: Optional[Dict[str, float]] = None, rrf_k: int = 60) -> QueryResponse:
         results = self.index.query(text=question, k=k or self.k, filter=filter, hybrid_weights=hybrid_weights, rrf_k=rrf_k)
+        results = self._apply_reranker(question, results)                            # core.py:246
         spans = self.extractor.extract_spans(question, results)                      # core.py:255
         flat = [{"text": s, "doc_text": t} for t, ss in spans.items() for s in ss]   # core.py:184-193
         display = flat[: self.max_display_spans]

@@ -224,3 +224,26 @@ def test_token_spans_to_char_spans():
     out = token_spans_to_char_spans(probs, offs, ctx, 0.5, min_span_chars=1, merge_gap_chars=0)
     assert out == ["Alpha beta", "delta epsilon zeta eta", "mu"]
     assert all(s in ctx for s in out)
+
+
+def test_filter_expression_subset():
+    import verbatim_rag_amd  # noqa: F401
+    from verbatim_rag_amd.vector_stores import parse_filter
+
+    md = [{"document_id": "d1", "year": 2020, "lang": "en"}, {"document_id": "d2", "year": 2021, "lang": "de"},
+          {"document_id": "d3", "lang": "en"}]
+
+    def sel(expr):
+        p = parse_filter(expr)
+        return [m["document_id"] for m in md if p(m)]
+
+    assert sel('metadata["document_id"] == "d2"') == ["d2"]            # Local dialect (index.py:738)
+    assert sel('document_id == "d2"') == ["d2"]                          # Cloud dialect (index.py:736)
+    assert sel("metadata['lang'] != 'en'") == ["d2"]
+    assert sel('document_id in ["d1", "d3"] and lang == "en"') == ["d1", "d3"]
+    assert sel('year == 2021 or document_id == "d3"') == ["d2", "d3"]
+    assert sel('not (lang == "en") || year == 2020') == ["d1", "d2"]
+    assert sel('(year == 2020 || year == 2021) && lang == "de"') == ["d2"]
+    for bad in ("a > 3", 'metadata["x"] like "y%"', 'document_id == ', 'document_id == "d1" extra', "", '== "d1"'):
+        with pytest.raises(ValueError):
+            parse_filter(bad)

@@ -258,7 +258,94 @@ class SparseShard:
 
 
 # ---------------------------------------------------------------------------- the store
-_FILTER_EQ = re.compile(r"""^\s*(?:metadata\[\s*["'](\w+)["']\s*\]|(\w+))\s*==\s*["']([^"']*)["']\s*$""")
+_FILTER_TOKEN = re.compile(r"""\s*(?:(?P<meta>metadata\[\s*["'](?P<mkey>[^"']+)["']\s*\])|(?P<str>"[^"]*"|'[^']*')|(?P<num>-?\d+(?:\.\d+)?)"""
+                           r"""|(?P<op>==|!=|&&|\|\||[()\[\],])|(?P<word>\w+))""")
+
+
+def parse_filter(expr: str):
+    """Compiles the subset of Milvus boolean expressions the store supports into `predicate(metadata: dict) -> bool`:
+    comparisons `field == value`, `field != value`, `field in [v, ...]` (field = `metadata["key"]`, the Local dialect,
+    or a bare `key`, the Cloud dialect: index.py:735-739; values = quoted strings or numbers, compared as strings like
+    the JSON-path match on string metadata), combined with `and` / `&&`, `or` / `||`, `not` and parentheses.
+    Anything else raises ValueError -- a filter is never silently ignored."""
+    toks, pos = [], 0
+    while pos < len(expr):
+        if expr[pos:].strip() == "":
+            break
+        m = _FILTER_TOKEN.match(expr, pos)
+        if not m:
+            raise ValueError(f"GpuVectorStore: cannot parse filter at {expr[pos:]!r}")
+        pos = m.end()
+        if m.group("meta"):
+            toks.append(("field", m.group("mkey")))
+        elif m.group("str"):
+            toks.append(("val", m.group("str")[1:-1]))
+        elif m.group("num"):
+            toks.append(("val", m.group("num")))
+        elif m.group("op"):
+            toks.append(("op", m.group("op")))
+        else:
+            w = m.group("word")
+            toks.append(("op", w.lower()) if w.lower() in ("and", "or", "not", "in") else ("field", w))
+    i = 0
+
+    def peek():
+        return toks[i] if i < len(toks) else (None, None)
+
+    def take(kind=None, value=None):
+        nonlocal i
+        k, v = peek()
+        if k is None or (kind and k != kind) or (value and v != value):
+            raise ValueError(f"GpuVectorStore: unsupported filter {expr!r}")
+        i += 1
+        return v
+
+    def comparison():
+        if peek() == ("op", "("):
+            take()
+            f = disjunction()
+            take("op", ")")
+            return f
+        if peek() == ("op", "not"):
+            take()
+            g = comparison()
+            return lambda md: not g(md)
+        key = take("field")
+        op = take("op")
+        if op in ("==", "!="):
+            val = take("val")
+            return (lambda md: str(md.get(key)) == val) if op == "==" else (lambda md: str(md.get(key)) != val)
+        if op == "in":
+            take("op", "[")
+            vals = [take("val")]
+            while peek() == ("op", ","):
+                take()
+                vals.append(take("val"))
+            take("op", "]")
+            vs = set(vals)
+            return lambda md: str(md.get(key)) in vs
+        raise ValueError(f"GpuVectorStore: unsupported operator {op!r} in filter {expr!r}")
+
+    def conjunction():
+        f = comparison()
+        while peek() in (("op", "and"), ("op", "&&")):
+            take()
+            g, h = f, comparison()
+            f = (lambda a, b: lambda md: a(md) and b(md))(g, h)
+        return f
+
+    def disjunction():
+        f = conjunction()
+        while peek() in (("op", "or"), ("op", "||")):
+            take()
+            g, h = f, conjunction()
+            f = (lambda a, b: lambda md: a(md) or b(md))(g, h)
+        return f
+
+    pred = disjunction()
+    if i != len(toks):
+        raise ValueError(f"GpuVectorStore: unsupported filter {expr!r}")
+    return pred
 
 
 class GpuVectorStore(VectorStore):
@@ -266,8 +353,9 @@ class GpuVectorStore(VectorStore):
 
     dense = COSINE (rows and queries are L2-normalised here, so IP on the device equals cosine),
     sparse = IP over shared terms.  Rows live on the host until the first query after an insert
-    ("flush"), then in HBM.  `filter` supports equality on one metadata key (the only form the
-    reference itself builds, index.py:735-739); anything else is rejected loudly.
+    ("flush"), then in HBM.  `filter` supports the comparison subset of Milvus expressions in `parse_filter`
+    (the reference itself only builds `metadata["document_id"] == "..."`, index.py:735-739); anything else is
+    rejected loudly.
     """
 
     enable_full_text = False
@@ -335,11 +423,8 @@ class GpuVectorStore(VectorStore):
     def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
         alive = np.asarray(self._alive, dtype=bool)
         if filter:
-            m = _FILTER_EQ.match(filter)
-            if not m:
-                raise ValueError(f"GpuVectorStore supports only `key == \"value\"` filters, got: {filter!r}")
-            key, val = (m.group(1) or m.group(2)), m.group(3)
-            alive = alive & np.asarray([str(md.get(key)) == val for md in self._meta], dtype=bool)
+            pred = parse_filter(filter)
+            alive = alive & np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
         return None if alive.all() else alive
 
     def _hit(self, row: int, score: float) -> dict:

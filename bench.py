@@ -69,23 +69,91 @@ def chunk_flops(shape, S: int = SEQ) -> float:
     return lin + glob + loc
 
 
-def cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, budget_s: float):
-    """Times the numpy oracle (oracle/ = checker, never the product path) on a bounded sample."""
+def _cpu_threads() -> int:
+    try:
+        from threadpoolctl import threadpool_info
+
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] + [1]))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def _oracle_cfg(shape):
     from oracle import modernbert_np as O
 
-    cfg = O.EncoderConfig(
+    return O.EncoderConfig(
         vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
         num_attention_heads=shape.num_attention_heads, intermediate_size=shape.intermediate_size,
         global_attn_every_n_layers=shape.global_attn_every_n_layers, local_attention=shape.local_attention,
         global_rope_theta=shape.global_rope_theta, local_rope_theta=shape.local_rope_theta, norm_eps=shape.norm_eps,
         pad_token_id=shape.pad_token_id, cls_token_id=shape.cls_token_id, sep_token_id=shape.sep_token_id)
-    try:
-        from threadpoolctl import threadpool_info
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+
+def _hf_cpu_model(shape, weights):
+    """`transformers` ModernBertModel (fp32, CPU) carrying the bench weights -- the module the reference's
+    QAModel.forward calls (extractor_models/model.py:51,75).  Parameter init is skipped (everything is overwritten
+    by load_state_dict); returns None when transformers / torch cannot provide it."""
+    try:
+        import torch
+        import torch.nn as nn
+        from transformers import ModernBertConfig, ModernBertModel
     except Exception:
-        cores = os.cpu_count() or 1
-    logits, t0, n = [], time.perf_counter(), 0
+        return None
+    cfg = ModernBertConfig(
+        vocab_size=shape.vocab_size, hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
+        num_attention_heads=shape.num_attention_heads, intermediate_size=shape.intermediate_size,
+        global_attn_every_n_layers=shape.global_attn_every_n_layers, local_attention=shape.local_attention,
+        norm_eps=shape.norm_eps, pad_token_id=shape.pad_token_id, attn_implementation="sdpa")
+    rp = getattr(cfg, "rope_parameters", None) or {}
+    if (rp.get("full_attention", {}).get("rope_theta", shape.global_rope_theta) != shape.global_rope_theta or
+            rp.get("sliding_attention", {}).get("rope_theta", shape.local_rope_theta) != shape.local_rope_theta):
+        return None
+    saved = (nn.Linear.reset_parameters, nn.Embedding.reset_parameters, ModernBertModel._init_weights)
+    try:
+        nn.Linear.reset_parameters = lambda self: None
+        nn.Embedding.reset_parameters = lambda self: None
+        ModernBertModel._init_weights = lambda self, module: None
+        model = ModernBertModel(cfg).eval()
+    finally:
+        nn.Linear.reset_parameters, nn.Embedding.reset_parameters, ModernBertModel._init_weights = saved
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()},
+                                                strict=False)
+    if missing or unexpected:
+        return None
+    return model
+
+
+def cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, budget_s: float):
+    """CPU leg on a bounded sample of the same batch, B = 1 per chunk like the reference's loop (extractors.py:233-268).
+    Preferred: the reference's own arithmetic -- `transformers` ModernBertModel fp32 on the host cores -- plus the
+    restated sentence head (oracle/); fallback: the numpy oracle end to end.  Both are checkers, never the product."""
+    from oracle import modernbert_np as O
+
+    model = _hf_cpu_model(shape, weights)
+    logits, n = [], 0
+    if model is not None:
+        import torch
+
+        # B = 1 x 512 tokens does not scale past ~16 threads (MI355X host, tools/cpu_threads_probe.py: 4.9 / 7.9 / 5.0 /
+        # 0.9 chunks/s at 8 / 16 / 32 / 128 threads): use the best setting rather than torch's all-cores default
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        with torch.no_grad():
+            model(input_ids=torch.from_numpy(np.asarray(seqs[0], dtype=np.int64))[None])   # first-call warm-up, untimed
+            t0 = time.perf_counter()
+            for s, b in zip(seqs, bounds):
+                hid = model(input_ids=torch.from_numpy(np.asarray(s, dtype=np.int64))[None]).last_hidden_state[0].numpy()
+                logits.append(O.qa_sentence_logits(hid, b, qa_w, qa_b))
+                n += 1
+                if time.perf_counter() - t0 > budget_s:
+                    break
+        dt = time.perf_counter() - t0
+        return {
+            "value": n / dt, "unit": "chunks/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} of the 256 synthetic 512-token chunks; transformers ModernBertModel fp32 on CPU (the module the "
+                      "reference's QAModel.forward runs) + restated sentence head, B=1 per chunk like the reference loop",
+        }, logits
+    cfg = _oracle_cfg(shape)
+    t0 = time.perf_counter()
     for s, b in zip(seqs, bounds):
         hid = O.encoder_forward(cfg, weights, s)
         logits.append(O.qa_sentence_logits(hid, b, qa_w, qa_b))
@@ -94,7 +162,7 @@ def cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, budget_s: float):
             break
     dt = time.perf_counter() - t0
     return {
-        "value": n / dt, "unit": "chunks/s", "cores": int(cores), "kind": "port",
+        "value": n / dt, "unit": "chunks/s", "cores": _cpu_threads(), "kind": "port",
         "sample": f"{n} of the 256 synthetic 512-token chunks, numpy fp32 oracle (B=1 per chunk like the reference loop)",
     }, logits
 

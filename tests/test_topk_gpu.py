@@ -107,6 +107,37 @@ def test_sparse_topk_bit_exact(vocab):
     assert np.array_equal(i, ri) and np.array_equal(s, rs)
 
 
+@pytest.mark.parametrize("vocab", [30522, 50368])
+def test_sparse_batched_hash_path_and_fallbacks_bit_exact(vocab):
+    """>= 2 small queries: QB = 8 queries per pass through per-query hash tables in LDS (19 queries = 3 passes, the
+    last one partial); one query alone and any batch containing a > 64-term query take the single-query kernels.
+    All three must equal the oracle bit for bit (same fmaf order)."""
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    rng = np.random.default_rng(vocab + 1)
+    indptr, idx, val, qp, qi, qv = _sparse_corpus(rng, 30000, vocab, 96, 19, 40)
+    val = (rng.random(len(val)).astype(np.float32) * 3)
+    qv = (rng.random(len(qv)).astype(np.float32) * 3)
+    assert (np.diff(qp) <= 64).all() and (np.diff(qp) > 30).any()
+    sh = SparseShard(vocab, indptr, idx, val)
+    try:
+        rs, ri = T.sparse_topk(indptr, idx, val, vocab, qp, qi, qv, 7)
+        s, i = sh.search_csr(qp, qi, qv, 7)                         # batched hash path
+        assert np.array_equal(i, ri) and np.array_equal(s, rs)
+        s1, i1 = sh.search_csr(qp[:2], qi[:qp[1]], qv[:qp[1]], 7)   # one query: single-query kernel
+        assert np.array_equal(i1, ri[:1]) and np.array_equal(s1, rs[:1])
+        # a 100-term query in the batch: whole batch falls back to the single-query kernels
+        big_t = np.unique(rng.choice(vocab, size=140))[:100].astype(np.int32)
+        big_v = (rng.random(len(big_t)).astype(np.float32) * 2)
+        qp2 = np.concatenate([qp, [qp[-1] + len(big_t)]])
+        qi2, qv2 = np.concatenate([qi, big_t]), np.concatenate([qv, big_v])
+        rs2, ri2 = T.sparse_topk(indptr, idx, val, vocab, qp2, qi2, qv2, 7)
+        s2, i2 = sh.search_csr(qp2, qi2, qv2, 7)
+        assert np.array_equal(i2, ri2) and np.array_equal(s2, rs2)
+    finally:
+        sh.close()
+
+
 def test_sparse_no_shared_terms_is_not_a_hit():
     from verbatim_rag_amd.vector_stores import SparseShard
 

@@ -730,6 +730,112 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
   }
 }
 
+// ------------------------------------------------------------------------------------ sparse, batched queries
+// QB queries per pass over the shard.  The QB queries of a pass touch at most a few hundred distinct terms
+// ("union").  Per pass the LDS holds ONE u16 map term -> union id (0 = in none of the queries; 60 KiB for a
+// 30 522-term vocabulary) and a small dense weight table W[q][union id] (W[q][0] = 0), so a document term
+// costs one 2-byte LDS read shared by all queries plus one 4-byte read per query, with no divergence and no
+// probing; absent terms contribute fmaf(v, 0, acc) == acc and the per-document sum keeps the document's term
+// order: bit-identical to the single-query kernel and the CPU restatement.  The document stream is read once
+// for QB queries.
+constexpr int SUW = 1024;                   // weight-table stride: union ids 0 .. SUW-1
+
+template <int QB>
+__global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned short* __restrict__ cols,
+                                                                 const float* __restrict__ vals,
+                                                                 const long long* __restrict__ slice_off,
+                                                                 const int* __restrict__ slice_len, int n_slices,
+                                                                 long long n_docs, const unsigned short* __restrict__ qmap,
+                                                                 const float* __restrict__ qw, int vocab, int n_union,
+                                                                 int nq, int q0, int k, int slices_per_wg,
+                                                                 u64* __restrict__ cand) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int vpad = (vocab + 7) & ~7;
+  unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
+  float* tw = reinterpret_cast<float*>(smem + (size_t)vpad * 2);                  // [QB][SUW] (first n_union+1 used)
+  u64* lists = reinterpret_cast<u64*>(smem + (size_t)vpad * 2 + (size_t)QB * SUW * 4);   // [16 waves][QB][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < vpad / 8; i += 1024)   // 16-byte copies
+    reinterpret_cast<f32x4*>(tmap)[i] = reinterpret_cast<const f32x4*>(qmap)[i];
+  for (int i = tid; i < QB * (n_union + 1); i += 1024) {
+    const int q = i / (n_union + 1), u = i - q * (n_union + 1);
+    tw[q * SUW + u] = qw[(size_t)q * SUW + u];
+  }
+  for (int i = tid; i < 16 * QB * k; i += 1024) lists[i] = 0ull;
+  __syncthreads();
+  u64* mylists = lists + (size_t)wave * QB * k;
+  const int s_begin = blockIdx.x * slices_per_wg;
+  const int s_end = min(n_slices, s_begin + slices_per_wg);
+  for (int s = s_begin + wave; s < s_end; s += 16) {
+    const long long off = slice_off[s];
+    const int len = slice_len[s];
+    const unsigned short* c = cols + off + lane;
+    const float* v = vals + off + lane;
+    float acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[q] = 0.f;
+    int j = 0;
+    for (; j + 8 <= len; j += 8) {
+      unsigned short ci[8];
+      float vi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ci[u] = __builtin_nontemporal_load(c + (size_t)(j + u) * 64);
+        vi[u] = __builtin_nontemporal_load(v + (size_t)(j + u) * 64);
+      }
+      unsigned uid[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) uid[u] = tmap[ci[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = __fmaf_rn(vi[u], tw[q * SUW + uid[u]], acc[q]);
+    }
+    for (; j < len; ++j) {
+      const unsigned uid1 = tmap[c[(size_t)j * 64]];
+      const float v1 = v[(size_t)j * 64];
+#pragma unroll
+      for (int q = 0; q < QB; ++q) acc[q] = __fmaf_rn(v1, tw[q * SUW + uid1], acc[q]);
+    }
+    const long long doc = (long long)s * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const bool hit = doc < n_docs && acc[q] > 0.f;
+      const u64 key = hit ? make_key(acc[q], (unsigned)doc) : 0ull;
+      u64* ml = mylists + q * k;
+      const u64 kth = ml[k - 1];
+      unsigned long long m = __ballot(key > kth);
+      while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        const u64 kk = __shfl(key, src, 64);
+        if (lane == 0) insert_key(ml, k, kk);
+        m &= m - 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < QB && q0 + tid < nq) {
+    int head[16];
+    for (int g = 0; g < 16; ++g) head[g] = 0;
+    u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
+    for (int i = 0; i < k; ++i) {
+      u64 best = 0ull;
+      int bg = -1;
+      for (int g = 0; g < 16; ++g) {
+        if (head[g] < k) {
+          const u64 vv = lists[((size_t)g * QB + tid) * k + head[g]];
+          if (vv > best) {
+            best = vv;
+            bg = g;
+          }
+        }
+      }
+      out[i] = best;
+      if (bg >= 0) ++head[bg];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ merge
 // One workgroup per query: k rounds of workgroup-wide arg-max over the candidate keys.
 __global__ __launch_bounds__(256) void topk_merge_scan_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
@@ -883,6 +989,11 @@ struct vrag_sparse_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr;
   size_t d_cand_elems = 0, d_out_elems = 0;
+  unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
+  float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
+  size_t d_qmap_elems = 0, d_qw_elems = 0;
+  std::vector<int> pass_union;        // union size of every pass of the resident queries
+  bool last_multi = false;   // which kernel family the resident queries were prepared for
 };
 
 namespace {
@@ -1130,6 +1241,8 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->slice_off) (void)hipFree(ix->slice_off);
   if (ix->slice_len) (void)hipFree(ix->slice_len);
   if (ix->d_q) (void)hipFree(ix->d_q);
+  if (ix->d_qmap) (void)hipFree(ix->d_qmap);
+  if (ix->d_qw) (void)hipFree(ix->d_qw);
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -1153,10 +1266,31 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
   return spw;
 }
 
+constexpr int SQB = 8;   // queries per pass of the batched sparse kernel
+
 static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out) {
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   *n_wg_out = n_wg;
+  if (ix->last_multi) {
+    const int vpad = (ix->vocab + 7) & ~7;
+    const size_t lds = (size_t)vpad * 2 + (size_t)SQB * SUW * 4 + (size_t)16 * SQB * k * sizeof(u64);
+    static bool attr_m = false;
+    if (!attr_m) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<SQB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_m = true;
+    }
+    for (int q0 = 0, ps = 0; q0 < nq; q0 += SQB, ++ps) {
+      hipLaunchKernelGGL((sparse_topk_multi_kernel<SQB>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                         ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                         ix->d_qw + (size_t)ps * SQB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
+    HIP_TRY(hipGetLastError());
+    return VRAG_OK;
+  }
   const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) <= 160 * 1024;
   const size_t lds = (size_t)16 * k * sizeof(u64) + (ldsq ? (size_t)ix->vocab * sizeof(float) : 0);
   if (ldsq) {
@@ -1190,19 +1324,75 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
-  std::vector<float> dense((size_t)nq * ix->vocab, 0.f);
-  for (int q = 0; q < nq; ++q)
-    for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) {
-      const int32_t t = q_indices[j];
-      ARG_CHECK(t >= 0 && t < ix->vocab, "query %d: term id %d outside the vocabulary", q, t);
-      dense[(size_t)q * ix->vocab + t] = q_values[j];
-    }
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   int rc;
-  if ((rc = grow(&ix->d_q, &ix->d_q_elems, dense.size()))) return rc;
   if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
   if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k))) return rc;
+  // Batched path: two or more queries; per pass of SQB queries the union of their terms gets ids 1 .. SUW-1, the
+  // u16 map + weight tables + top-k lists must fit the LDS.
+  static const bool multi_off = getenv("VRAG_SPARSE_SINGLE") != nullptr;   // tuning / tests: force the single-query kernel
+  const int vpad = (ix->vocab + 7) & ~7;
+  bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 &&
+               (size_t)vpad * 2 + (size_t)SQB * SUW * 4 + (size_t)16 * SQB * k * sizeof(u64) <= 160 * 1024;
+  for (int q = 0; q < nq; ++q)
+    for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
+      ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);
+  const int n_pass = (nq + SQB - 1) / SQB;
+  std::vector<unsigned short> maps;
+  std::vector<float> wts;
+  std::vector<int> unions;
+  if (multi) {
+    maps.assign((size_t)n_pass * vpad, 0);
+    wts.assign((size_t)n_pass * SQB * SUW, 0.f);
+    unions.assign(n_pass, 0);
+    for (int ps = 0; ps < n_pass && multi; ++ps) {
+      unsigned short* mp = maps.data() + (size_t)ps * vpad;
+      float* wt = wts.data() + (size_t)ps * SQB * SUW;
+      int nu = 0;
+      for (int q = ps * SQB; q < std::min(nq, (ps + 1) * SQB) && multi; ++q)
+        for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) {
+          const int t = q_indices[j];
+          if (!mp[t]) {
+            if (nu + 1 >= SUW) {
+              multi = false;   // too many distinct terms in this group of queries: single-query kernels
+              break;
+            }
+            mp[t] = (unsigned short)++nu;
+          }
+          wt[(size_t)(q - ps * SQB) * SUW + mp[t]] = q_values[j];   // a repeated term keeps the last value, like the dense scatter
+        }
+      unions[ps] = nu;
+    }
+  }
+  ix->last_multi = multi;
+  if (multi) {
+    auto regrow = [&](auto** ptr, size_t* have, size_t want, size_t esz) -> int {
+      if (*have >= want) return VRAG_OK;
+      if (*ptr) (void)hipFree(*ptr);
+      *ptr = nullptr;
+      *have = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(ptr), want * esz));
+      *have = want;
+      return VRAG_OK;
+    };
+    if ((rc = regrow(&ix->d_qmap, &ix->d_qmap_elems, maps.size(), sizeof(unsigned short)))) return rc;
+    if ((rc = regrow(&ix->d_qw, &ix->d_qw_elems, wts.size(), sizeof(float)))) return rc;
+    ix->pass_union = unions;
+    HIP_TRY(hipMemcpyAsync(ix->d_qmap, maps.data(), maps.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ix->d_qw, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    int nwg3 = 0;
+    if ((rc = sparse_launch(ix, nq, k, st, &nwg3))) return rc;
+    std::vector<u64> keys2((size_t)nq * k);
+    HIP_TRY(hipMemcpyAsync(keys2.data(), ix->d_out, keys2.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // also keeps the host tables alive until the uploads have been consumed
+    decode_keys(keys2, nq, k, 0, ix->perm.data(), scores, ids);
+    return VRAG_OK;
+  }
+  std::vector<float> dense((size_t)nq * ix->vocab, 0.f);
+  for (int q = 0; q < nq; ++q)
+    for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) dense[(size_t)q * ix->vocab + q_indices[j]] = q_values[j];
+  if ((rc = grow(&ix->d_q, &ix->d_q_elems, dense.size()))) return rc;
   HIP_TRY(hipMemcpyAsync(ix->d_q, dense.data(), dense.size() * sizeof(float), hipMemcpyHostToDevice, st));
   int nwg2 = 0;
   if ((rc = sparse_launch(ix, nq, k, st, &nwg2))) return rc;
@@ -1216,7 +1406,9 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
 int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k, void* stream) {
   ARG_CHECK(ix && nq > 0 && k > 0 && k <= KMAX, "bad arguments");
   std::lock_guard<std::mutex> lk(ix->mu);
-  ARG_CHECK(ix->d_q && ix->d_q_elems >= (size_t)nq * ix->vocab, "call vrag_sparse_index_search once first");
+  ARG_CHECK(ix->last_multi ? (ix->d_qmap && (int)ix->pass_union.size() >= (nq + SQB - 1) / SQB)
+                           : (ix->d_q && ix->d_q_elems >= (size_t)nq * ix->vocab),
+            "call vrag_sparse_index_search with at least this many queries first");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
   int n_wg = 0;

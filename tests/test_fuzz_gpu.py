@@ -1,0 +1,57 @@
+"""GPU: randomised batch compositions through the C ABI vs the numpy oracle (tiny ModernBERT config): random
+sequence counts / lengths (1..512, ragged), random micro-batch sizes (two-stream schedule), random sentence ranges,
+both GEMM configurations.  Catches layout / alignment / scheduling bugs that fixed-shape tests cannot."""
+import numpy as np
+import pytest
+
+from oracle import modernbert_np as O
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+            intermediate_size=192, pad_token_id=0, cls_token_id=1, sep_token_id=2)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_batches_vs_oracle(seed):
+    from verbatim_rag_amd import _lib
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+
+    rng = np.random.default_rng(1000 + seed)
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=50 + seed)
+    qa_w = (rng.standard_normal((2, cfg.hidden_size)) * 0.1).astype(np.float32)
+    qa_b = np.asarray([0.05, -0.05], np.float32)
+    mb = int(rng.choice([0, 300, 700, 2000]))
+    shape = ModernBertShape(**{k: v for k, v in TINY.items()})
+    lib = _lib.load()
+    lib.vrag_debug_set_gemm_small_m(int(rng.choice([0, 8192])))
+    eng = EncoderEngine(shape, w, max_tokens=6000, max_seqs=40, max_seq_len=512, max_ranges=400, micro_batch_tokens=mb)
+    try:
+        eng.set_qa_head(qa_w, qa_b)
+        for _round in range(3):
+            n = int(rng.integers(1, 24))
+            lens = [int(x) for x in rng.choice([1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512], size=n)]
+            while sum(lens) > 5500:
+                lens.pop()
+            seqs = [rng.integers(3, cfg.vocab_size, size=L).astype(np.int32) for L in lens]
+            bounds = []
+            for L in lens:
+                m = int(rng.integers(1, 6))
+                b = []
+                for _ in range(m):
+                    s0 = int(rng.integers(0, L))
+                    b.append((s0, int(rng.integers(s0, L))))
+                bounds.append(b)
+            got = eng.qa_logits(seqs, bounds)
+            hid = eng.read_hidden(final_norm=True)
+            o = 0
+            for s, b, g in zip(seqs, bounds, got):
+                ref_h = O.encoder_forward(cfg, w, s)
+                assert np.abs(hid[o:o + len(s)] - ref_h).max() < 3e-2, (seed, mb, lens)
+                ref_l = O.qa_sentence_logits(ref_h, b, qa_w, qa_b)
+                assert np.abs(g - ref_l).max() < 2e-3, (seed, mb, lens)
+                o += len(s)
+    finally:
+        eng.close()
+        lib.vrag_debug_set_gemm_small_m(8192)

@@ -208,3 +208,27 @@ def test_dense_topk_batched_mfma_path_exact(n, dim, nq, k):
     rs, ri = T.dense_topk(X, Q, k)
     assert np.array_equal(i, ri)
     assert np.array_equal(s, rs)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_dense_topk_fuzz_shapes(seed):
+    """Random shard sizes around the tile / range boundaries of every dense path (single-query register path, 4-query
+    LDS path, both MFMA generations, prefix-seeded two-pass route), random k and query counts, heavy score ties."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(7000 + seed)
+    dim = int(rng.choice([64, 128, 256, 384, 768, 1024]))
+    n = int(rng.choice([1, 31, 127, 128, 129, 2047, 2048, 2049, 32767, 32768, 65537, 131072, 131073, 150001]))
+    if n * dim > 80_000_000:
+        n = 80_000_000 // dim
+    nq = int(rng.choice([1, 2, 3, 4, 5, 31, 32, 33, 40]))
+    k = int(rng.choice([1, 2, 5, 10, 16, 17, 32]))
+    dtype = "bf16" if rng.random() < 0.75 else "f32"
+    X, Q = _dyadic(rng, (n, dim), lim=int(rng.choice([2, 8, 64]))), _dyadic(rng, (nq, dim), lim=int(rng.choice([2, 64])))
+    sh = DenseShard(dim, n, dtype)
+    sh.add(X)
+    s, i = sh.search(Q, k)
+    sh.close()
+    rs, ri = T.dense_topk(X, Q, k)
+    assert np.array_equal(i, ri), (n, dim, nq, k, dtype)
+    assert np.array_equal(s, rs), (n, dim, nq, k, dtype)

@@ -265,7 +265,12 @@ int dev_alloc(vrag_encoder* e, T** out, size_t count, bool zero = true) {
   const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
   HIP_TRY(hipMalloc(&p, bytes));
   e->dev_allocs.push_back(p);
-  if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+  if (zero) {
+    // hipMemset runs on the null stream, which does NOT order against the handle's non-blocking streams: wait for it
+    // here (allocations are rare), or a kernel launched right after could have its output zeroed under it.
+    HIP_TRY(hipMemset(p, 0, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+  }
   *out = reinterpret_cast<T*>(p);
   return VRAG_OK;
 }

@@ -59,7 +59,7 @@ def sparse(n=1_000_000, vocab=30522, mean_nnz=128, k=5):
     sh = SparseShard(vocab, indptr, idx, val)
     st = sh.stats()
     out = []
-    for nq in (1, 8):
+    for nq in (1, 8, 64):
         qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(nq)]
         sh.search(qs, k)
         dt = timeit(lambda: sh.run_resident(nq, k), 5)

@@ -993,6 +993,7 @@ struct vrag_sparse_index {
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
   std::vector<int> pass_union;        // union size of every pass of the resident queries
+  int pass_qb = 8;                    // queries per pass the resident tables were built for (8 or 16)
   bool last_multi = false;   // which kernel family the resident queries were prepared for
 };
 
@@ -1266,7 +1267,7 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
   return spw;
 }
 
-constexpr int SQB = 8;   // queries per pass of the batched sparse kernel
+constexpr int SQB = 8;   // queries per pass of the batched sparse kernel (16 when the tables fit the LDS and nq >= 16)
 
 static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out) {
   const int slices_per_wg = sparse_slices_per_wg(ix);
@@ -1274,17 +1275,25 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   *n_wg_out = n_wg;
   if (ix->last_multi) {
     const int vpad = (ix->vocab + 7) & ~7;
-    const size_t lds = (size_t)vpad * 2 + (size_t)SQB * SUW * 4 + (size_t)16 * SQB * k * sizeof(u64);
+    const int QB = ix->pass_qb;
+    const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)16 * QB * k * sizeof(u64);
     static bool attr_m = false;
     if (!attr_m) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<SQB>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
-    for (int q0 = 0, ps = 0; q0 < nq; q0 += SQB, ++ps) {
-      hipLaunchKernelGGL((sparse_topk_multi_kernel<SQB>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                         ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                         ix->d_qw + (size_t)ps * SQB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand);
+    for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
+      if (QB == 16)
+        hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand);
+      else
+        hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
@@ -1333,24 +1342,26 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
   // u16 map + weight tables + top-k lists must fit the LDS.
   static const bool multi_off = getenv("VRAG_SPARSE_SINGLE") != nullptr;   // tuning / tests: force the single-query kernel
   const int vpad = (ix->vocab + 7) & ~7;
-  bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 &&
-               (size_t)vpad * 2 + (size_t)SQB * SUW * 4 + (size_t)16 * SQB * k * sizeof(u64) <= 160 * 1024;
+  auto fits = [&](int qb) { return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024; };
+  static const bool qb16_off = getenv("VRAG_SPARSE_QB8") != nullptr;
+  const int QB = (!qb16_off && nq >= 16 && fits(16)) ? 16 : SQB;
+  bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 && fits(QB);
   for (int q = 0; q < nq; ++q)
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
       ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);
-  const int n_pass = (nq + SQB - 1) / SQB;
+  const int n_pass = (nq + QB - 1) / QB;
   std::vector<unsigned short> maps;
   std::vector<float> wts;
   std::vector<int> unions;
   if (multi) {
     maps.assign((size_t)n_pass * vpad, 0);
-    wts.assign((size_t)n_pass * SQB * SUW, 0.f);
+    wts.assign((size_t)n_pass * QB * SUW, 0.f);
     unions.assign(n_pass, 0);
     for (int ps = 0; ps < n_pass && multi; ++ps) {
       unsigned short* mp = maps.data() + (size_t)ps * vpad;
-      float* wt = wts.data() + (size_t)ps * SQB * SUW;
+      float* wt = wts.data() + (size_t)ps * QB * SUW;
       int nu = 0;
-      for (int q = ps * SQB; q < std::min(nq, (ps + 1) * SQB) && multi; ++q)
+      for (int q = ps * QB; q < std::min(nq, (ps + 1) * QB) && multi; ++q)
         for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) {
           const int t = q_indices[j];
           if (!mp[t]) {
@@ -1360,7 +1371,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
             }
             mp[t] = (unsigned short)++nu;
           }
-          wt[(size_t)(q - ps * SQB) * SUW + mp[t]] = q_values[j];   // a repeated term keeps the last value, like the dense scatter
+          wt[(size_t)(q - ps * QB) * SUW + mp[t]] = q_values[j];   // a repeated term keeps the last value, like the dense scatter
         }
       unions[ps] = nu;
     }
@@ -1379,6 +1390,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
     if ((rc = regrow(&ix->d_qmap, &ix->d_qmap_elems, maps.size(), sizeof(unsigned short)))) return rc;
     if ((rc = regrow(&ix->d_qw, &ix->d_qw_elems, wts.size(), sizeof(float)))) return rc;
     ix->pass_union = unions;
+    ix->pass_qb = QB;
     HIP_TRY(hipMemcpyAsync(ix->d_qmap, maps.data(), maps.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ix->d_qw, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice, st));
     int nwg3 = 0;
@@ -1406,7 +1418,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
 int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k, void* stream) {
   ARG_CHECK(ix && nq > 0 && k > 0 && k <= KMAX, "bad arguments");
   std::lock_guard<std::mutex> lk(ix->mu);
-  ARG_CHECK(ix->last_multi ? (ix->d_qmap && (int)ix->pass_union.size() >= (nq + SQB - 1) / SQB)
+  ARG_CHECK(ix->last_multi ? (ix->d_qmap && (int)ix->pass_union.size() >= (nq + ix->pass_qb - 1) / ix->pass_qb)
                            : (ix->d_q && ix->d_q_elems >= (size_t)nq * ix->vocab),
             "call vrag_sparse_index_search with at least this many queries first");
   HIP_TRY(hipSetDevice(ix->device));

@@ -211,3 +211,51 @@ def test_coalescing_scheduler_on_the_gpu_extractor(setup):
         assert co.batches_run < len(qs)
     finally:
         co.close()
+
+
+def test_concurrent_threads_on_separate_and_shared_handles(setup):
+    """SURVEY 8b threading contract: callers arrive from asyncio.to_thread workers.  Four threads hammer their own
+    engines while four more share ONE engine; every result must equal the single-threaded one."""
+    import threading
+
+    from verbatim_rag_amd.engine import EncoderEngine
+
+    cfg, w, z, eng, ext, fx = setup
+    shape = eng.shape
+    rng = np.random.default_rng(77)
+    work = []
+    for _ in range(6):
+        seqs = [rng.integers(3, cfg.vocab_size, size=int(n)).astype(np.int32) for n in rng.integers(5, 300, size=int(rng.integers(1, 9)))]
+        work.append((seqs, [[(1, len(s) - 1)] for s in seqs]))
+    qa_w = (rng.standard_normal((2, cfg.hidden_size)) * 0.1).astype(np.float32)
+    qa_b = np.zeros(2, np.float32)
+
+    def fresh():
+        e = EncoderEngine(shape, w, max_tokens=4096, max_seqs=16, max_seq_len=512, max_ranges=64)
+        e.set_qa_head(qa_w, qa_b)
+        return e
+
+    ref_eng = fresh()
+    want = [np.concatenate(ref_eng.qa_logits(s, b)) for s, b in work]
+    ref_eng.close()
+    shared = fresh()
+    engines = [fresh() for _ in range(4)] + [shared] * 4
+    errors = []
+
+    def run(e):
+        try:
+            for _rep in range(5):
+                for (s, b), ref in zip(work, want):
+                    got = np.concatenate(e.qa_logits(s, b))
+                    if not np.array_equal(got, ref):
+                        errors.append(float(np.abs(got - ref).max()))
+        except Exception as exc:   # pragma: no cover
+            errors.append(repr(exc))
+
+    ts = [threading.Thread(target=run, args=(e,)) for e in engines]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for e in engines[:4]:
+        e.close()
+    shared.close()
+    assert not errors, errors[:3]

@@ -184,6 +184,29 @@ def test_cross_query_batching_equals_per_query_calls(setup):
     assert batched[0] == run["spans"]
 
 
+def test_two_handles_alternate_sub_batches_bit_identically(setup):
+    """Small workspaces force many sub-batches; two handles of the same model run them from two worker threads."""
+    from verbatim_rag_amd.engine import EncoderEngine
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    cfg, w, z, eng, ext, fx = setup
+    run = fx["extract_e2e"]["runs"][0]
+    ext.threshold = run["threshold"]
+    engs = [EncoderEngine(_shape(cfg), w, max_tokens=1024, max_seqs=8, max_seq_len=512, max_ranges=256) for _ in range(2)]
+    try:
+        for e in engs:
+            e.set_qa_head(z["qa_Wc"], z["qa_bc"])
+        two = GpuModelSpanExtractor(engine=engs[0], extra_engines=engs[1:], tokenizer=ext.tokenizer, threshold=run["threshold"])
+        results = [types.SimpleNamespace(text=t) for t in run["texts"]]
+        qs = [run["question"], "Who built the iron bridge?", "When was it opened?"] * 6
+        rs = [results, results[:3], results[2:]] * 6
+        got = two.extract_spans_batch(qs, rs)
+        assert got == ext.extract_spans_batch(qs, rs) and got[0] == run["spans"]
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_coalescing_scheduler_on_the_gpu_extractor(setup):
     """Concurrent per-query calls (the reference's to_thread pattern) coalesced into shared GPU batches."""
     import threading

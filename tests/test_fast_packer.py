@@ -1,0 +1,131 @@
+"""The batched extractor's host path (cached `[SEP] sentence` tails + one searchsorted cut, vectorised threshold
+selection) must hand the engine exactly what the general packer (packing.encode_question_and_sentences, the restatement
+of dataset.py:127-243 pinned by the golden fixtures) would, and select the same sentences."""
+import logging
+import os
+import types
+
+import numpy as np
+import pytest
+
+import verbatim_rag_amd  # noqa: F401
+from verbatim_rag_amd import packing
+from verbatim_rag_amd.extractors import GpuModelSpanExtractor, select_sentences
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+WORDS = ("alpha beta gamma delta epsilon zeta eta theta iota kappa lambda mu nu xi omicron pi rho sigma tau upsilon "
+         "retrieval verbatim span extraction sentence boundary budget token question answer model index").split()
+
+
+class RecordingEngine:
+    """Engine stand-in: records what reaches the device entry point, returns logits that depend on the tokens."""
+    max_seqs, max_tokens, max_ranges = 64, 8192, 256
+    qa_labels = 2
+    shape = types.SimpleNamespace()
+
+    def __init__(self):
+        self.sent = []
+
+    def qa_logits_packed(self, ids, seq_lens, rng_seq, rng_start, rng_end):
+        ids = np.asarray(ids)
+        off = np.concatenate([[0], np.cumsum(seq_lens)])
+        out = np.empty((len(rng_seq), 2), np.float32)
+        for r, (s, a, b) in enumerate(zip(rng_seq, rng_start, rng_end)):
+            seq = ids[off[s]:off[s + 1]]
+            assert 0 <= a <= b < len(seq)
+            v = float(seq[a:b + 1].astype(np.int64).sum() % 97) / 97.0
+            out[r] = (0.5 - v, v - 0.5)
+        for s in range(len(seq_lens)):
+            m = np.asarray(rng_seq) == s
+            self.sent.append((ids[off[s]:off[s + 1]].tolist(), list(zip(np.asarray(rng_start)[m].tolist(), np.asarray(rng_end)[m].tolist()))))
+        return out
+
+
+def _engine_logits(ids, bounds):
+    out = np.empty((len(bounds), 2), np.float32)
+    for r, (a, b) in enumerate(bounds):
+        v = float(np.asarray(ids[a:b + 1], np.int64).sum() % 97) / 97.0
+        out[r] = (0.5 - v, v - 0.5)
+    return out
+
+
+@pytest.fixture(scope="module")
+def tokenizer():
+    from tokenizers import Tokenizer
+
+    return Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+
+
+def _text(rng, n_sent, lo, hi):
+    return " ".join(" ".join(rng.choice(WORDS, size=rng.integers(lo, hi))).capitalize() + "." for _ in range(n_sent))
+
+
+@pytest.mark.parametrize("qa_max_length", [512, 64, 24])
+def test_fast_path_equals_general_packer(tokenizer, qa_max_length, caplog):
+    rng = np.random.default_rng(qa_max_length)
+    eng = RecordingEngine()
+    ext = GpuModelSpanExtractor(engine=eng, tokenizer=tokenizer, threshold=0.5, qa_max_length=qa_max_length)
+    adapter = ext._tok
+    questions = [_text(rng, 1, 3, 12)[:-1] + "?" for _ in range(6)] + ["", _text(rng, 1, 40, 60)]
+    chunks_per_q = [[_text(rng, int(rng.integers(1, 14)), 2, 30) for _ in range(int(rng.integers(1, 6)))] + ["", "   "] for _ in questions]
+    chunks_per_q[1].append(chunks_per_q[0][0])             # a cached chunk under another question
+    with caplog.at_level(logging.ERROR):
+        got = ext.extract_spans_batch(questions, [[types.SimpleNamespace(text=t) for t in cs] for cs in chunks_per_q])
+    want_sent, budget = [], qa_max_length - 2
+    for q, cs, res in zip(questions, chunks_per_q, got):
+        q_ids = adapter.ids(q, add_special_tokens=True, max_length=budget)
+        assert list(res.keys()) == list(dict.fromkeys(cs))
+        for t in dict.fromkeys(cs):
+            sents = packing.split_into_sentences(t)
+            if not sents:
+                assert res[t] == []
+                continue
+            smp = packing.encode_question_and_sentences(q_ids, adapter.ids_batch(sents, max_length=budget), adapter.sep_token_id,
+                                                        max_length=qa_max_length)
+            vb = packing.valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
+            if not vb:
+                assert res[t] == []
+                continue
+            assert res[t] == select_sentences(_engine_logits(smp.input_ids, vb), sents, 0.5), (q, t)
+        for t in cs:                                          # device inputs in call order (duplicates are re-sent)
+            sents = packing.split_into_sentences(t)
+            if not sents:
+                continue
+            smp = packing.encode_question_and_sentences(q_ids, adapter.ids_batch(sents, max_length=budget), adapter.sep_token_id,
+                                                        max_length=qa_max_length)
+            vb = packing.valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
+            if vb:
+                want_sent.append((list(smp.input_ids), vb))
+    assert eng.sent == want_sent
+
+
+def test_budget_warning_is_kept(tokenizer, caplog):
+    ext = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=tokenizer, threshold=0.5, qa_max_length=32)
+    rng = np.random.default_rng(3)
+    with caplog.at_level(logging.WARNING):
+        ext.extract_spans("what?", [types.SimpleNamespace(text=_text(rng, 6, 8, 12))])
+    assert any("exceeded the 32-token budget; dropping" in r.getMessage() for r in caplog.records)
+
+
+def test_sentence_without_tokens_takes_the_general_path(tokenizer):
+    """A sentence that tokenises to nothing gives an (s, s-1) range, which QAModel skips so later rows shift
+    (model.py:88-96): that case is left to the general packer + valid_boundaries."""
+    ext = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=tokenizer, threshold=0.5)
+    entry = ext._cache_entry(["a.", "​", "b."], [[5], [], [7]])
+    assert entry[4] is False and ext._pack_fast([1, 9, 2], entry) is None
+    ok = ext._cache_entry(["a.", "b."], [[5], [7, 8]])
+    ids, st, en = ext._pack_fast([ext._tok.cls_token_id, 9, ext._tok.sep_token_id], ok)
+    sep = ext._tok.sep_token_id
+    assert ids.tolist() == [ext._tok.cls_token_id, 9, sep, 5, sep, 7, 8, sep] and st.tolist() == [3, 5] and en.tolist() == [3, 6]
+
+
+def test_two_handles_give_the_single_handle_result(tokenizer):
+    rng = np.random.default_rng(11)
+    questions = [_text(rng, 1, 3, 12)[:-1] + "?" for _ in range(40)]
+    results = [[types.SimpleNamespace(text=_text(rng, int(rng.integers(2, 10)), 4, 20)) for _ in range(5)] for _ in questions]
+    one = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=tokenizer, threshold=0.5)
+    a, b = RecordingEngine(), RecordingEngine()
+    two = GpuModelSpanExtractor(engine=a, extra_engines=[b], tokenizer=tokenizer, threshold=0.5)
+    assert two.extract_spans_batch(questions, results) == one.extract_spans_batch(questions, results)
+    assert a.sent and b.sent and len(a.sent) + len(b.sent) == len(one.engine.sent)

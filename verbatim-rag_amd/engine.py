@@ -288,6 +288,20 @@ class EncoderEngine:
             o += len(bs)
         return res
 
+    def qa_logits_packed(self, ids: np.ndarray, seq_lens: np.ndarray, rng_seq: np.ndarray, rng_start: np.ndarray,
+                         rng_end: np.ndarray) -> np.ndarray:
+        """Flat form of `qa_logits`: concatenated ids + per-sequence lengths + flat inclusive ranges -> [n_ranges, labels]."""
+        ids, lens = _i32(ids), _i32(seq_lens)
+        si, sa, sb = _i32(rng_seq), _i32(rng_start), _i32(rng_end)
+        out = np.empty((len(si), self.qa_labels), dtype=np.float32)
+        if len(si) == 0:
+            return out
+        _lib.check("vrag_encoder_extract_qa", self._lib.vrag_encoder_extract_qa(
+            self._h, ids.ctypes.data_as(_IP), lens.ctypes.data_as(_IP), len(lens), si.ctypes.data_as(_IP),
+            sa.ctypes.data_as(_IP), sb.ctypes.data_as(_IP), len(si), _fp(out)))
+        self._n_tokens, self._n_seqs, self._n_ranges = int(lens.sum()), len(lens), len(si)
+        return out
+
     # ------------------------------------------------------------------ profiling
     def set_concurrency(self, n_streams: int) -> None:
         _lib.check("vrag_encoder_set_concurrency", self._lib.vrag_encoder_set_concurrency(self._h, int(n_streams)))

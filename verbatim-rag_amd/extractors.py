@@ -139,6 +139,8 @@ class GpuModelSpanExtractor(SpanExtractor):
         max_batch_tokens: int = 65536,
         max_batch_seqs: int = 512,
         chunk_cache_size: int = 65536,
+        extra_engines: Sequence[Any] = (),
+        n_engines: int = 1,
     ):
         self.model_path = model_path
         self.threshold = threshold
@@ -152,9 +154,10 @@ class GpuModelSpanExtractor(SpanExtractor):
         self._lock = threading.Lock()  # callers arrive from asyncio.to_thread workers (extractors.py:54)
         # chunk text -> (sentences, per-sentence token ids): chunk texts are known at ingest and recur across
         # queries, and the reference's per-query tokenisation (2.7 ms/chunk) would cap the GPU path
-        self._chunk_cache: Dict[str, Tuple[List[str], List[List[int]]]] = {}
+        self._chunk_cache: Dict[str, tuple] = {}   # text -> _cache_entry
         self._chunk_cache_size = chunk_cache_size
         self._cache_lock = threading.Lock()
+        self._pool = None
         dev = 0 if device in (None, "cuda", "cpu", "mps") else int(str(device).replace("cuda:", ""))
         self.device = f"cuda:{dev}"
 
@@ -173,6 +176,12 @@ class GpuModelSpanExtractor(SpanExtractor):
             self._format = model_format or self._detect_format(model_path)
             self.engine = self._build_engine(model_path, dev)
             tokenizer = tokenizer or self._load_tokenizer(model_path)
+            extra_engines = [self._build_engine(model_path, dev) for _ in range(max(1, int(n_engines)) - 1)]
+        # Further handles of the same model (own weights copy + workspace + streams): a multi-sub-batch call alternates
+        # between them from worker threads, so one handle's upload / read-back / host turnaround hides behind the
+        # other's kernels (measured 0.42 -> 0.33 s for 5000 pairs, DESIGN.md "Serving shape").
+        self.engines = [self.engine] + list(extra_engines)
+        self._locks = [self._lock] + [threading.Lock() for _ in self.engines[1:]]
         self.tokenizer = tokenizer
         self._tok = TokenizerAdapter(tokenizer, sep_token_id=getattr(self.engine.shape, "sep_token_id", None)
                                      if not hasattr(tokenizer, "sep_token_id") else None,
@@ -242,29 +251,68 @@ class GpuModelSpanExtractor(SpanExtractor):
         sentences (bit-identical to the reference's per-sentence calls, dataset.py:158-167)."""
         budget = self.qa_max_length - 2
         q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
-        # sentence split + tokenisation per chunk, memoised (sentences are tokenised independently of the
-        # question, dataset.py:158-167, so the cached ids are exactly what the reference would produce)
+        all_sents, samples = [], []
+        for sents, ids, *_rest in self._entries(texts):
+            all_sents.append(sents)
+            if not sents:
+                samples.append(None)
+                continue
+            samples.append(encode_question_and_sentences(q_ids, ids, self._tok.sep_token_id, max_length=self.qa_max_length))
+        return all_sents, samples
+
+    def _entries(self, texts: Sequence[str]):
+        """Sentence split + tokenisation per chunk, memoised (sentences are tokenised independently of the
+        question, dataset.py:158-167, so the cached ids are exactly what the reference would produce); one
+        batched tokenizer call for every sentence of every chunk not seen before."""
         with self._cache_lock:
             missing = [t for t in dict.fromkeys(texts) if t not in self._chunk_cache]
             if missing:
                 split = [split_into_sentences(t) for t in missing]
                 flat = [s for sents in split for s in sents]
-                flat_ids = self._tok.ids_batch(flat, max_length=budget)
-                o = 0
+                flat_ids = self._tok.ids_batch(flat, max_length=self.qa_max_length - 2)
                 if len(self._chunk_cache) + len(missing) > self._chunk_cache_size:
                     self._chunk_cache.clear()
+                o = 0
                 for t, sents in zip(missing, split):
-                    self._chunk_cache[t] = (sents, flat_ids[o:o + len(sents)])
+                    self._chunk_cache[t] = self._cache_entry(sents, flat_ids[o:o + len(sents)])
                     o += len(sents)
-            all_sents, samples = [], []
-            for t in texts:
-                sents, ids = self._chunk_cache[t]
-                all_sents.append(sents)
-                if not sents:
-                    samples.append(None)
-                    continue
-                samples.append(encode_question_and_sentences(q_ids, ids, self._tok.sep_token_id, max_length=self.qa_max_length))
-        return all_sents, samples
+            return [self._chunk_cache[t] for t in texts]
+
+    def _cache_entry(self, sents: List[str], ids: List[List[int]]):
+        """(sentences, per-sentence ids, tail, cum, no sentence is empty): tail = [SEP] s1 [SEP] s2 ... as one int32 array, cum[i] = tokens of
+        the first i+1 `[SEP] sentence` groups -- the question-independent part of the packer, computed once per chunk."""
+        sep = self._tok.sep_token_id
+        tail = np.fromiter((x for sent in ids for x in [sep, *sent]), dtype=np.int32) if ids else np.zeros(0, np.int32)
+        cum = np.cumsum([len(sent) + 1 for sent in ids], dtype=np.int64) if ids else np.zeros(0, np.int64)
+        return (sents, ids, tail, cum, all(len(sent) > 0 for sent in ids))
+
+    def _pack_fast(self, q_ids: List[int], entry):
+        """The packer (packing.encode_question_and_sentences, dataset.py:127-243) on the cached pieces: the sentences
+        that fit are a prefix (the reference stops at the first one that does not), so the cut is one searchsorted.
+        Returns (input ids, inclusive starts, inclusive ends) or None when the general routine must decide (the
+        question alone reaches the budget, or a sentence without tokens makes an empty range)."""
+        sents, ids, tail, cum, no_empty = entry
+        budget = self.qa_max_length - 2
+        q = q_ids[:-1] if len(q_ids) > 1 and q_ids[-1] == self._tok.sep_token_id else q_ids
+        qlen = len(q)
+        if qlen >= budget or len(cum) == 0 or not no_empty:
+            return None
+        m = int(np.searchsorted(cum, budget - qlen, side="right"))      # groups with qlen + cum[i] <= budget
+        if m == 0:
+            return None
+        ends = qlen + cum[:m] - 1
+        starts = np.empty(m, np.int64)
+        starts[0] = qlen + 1
+        starts[1:] = qlen + cum[: m - 1] + 1
+        n = qlen + int(cum[m - 1])
+        out = np.empty(n + (1 if n < budget else 0), np.int32)
+        out[:qlen] = q
+        out[qlen:n] = tail[: int(cum[m - 1])]
+        if n < budget:
+            out[n] = self._tok.sep_token_id                              # dataset.py:202-205
+        if m < len(cum):
+            logger.warning("Legacy QA input exceeded the %d-token budget; dropping %d sentence(s)", budget + 2, len(cum) - m)
+        return out, starts, ends
 
     def _extract_qa_model(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
         return self.extract_spans_batch([question], [search_results])[0]
@@ -277,42 +325,82 @@ class GpuModelSpanExtractor(SpanExtractor):
         if self._format != self._FORMAT_QA_MODEL:
             return [self.extract_spans(q, r) for q, r in zip(questions, results_per_question)]
         out: List[Dict[str, List[str]]] = []
-        todo = []  # (query index, text, sentences, ids, boundaries)
+        budget = self.qa_max_length - 2
+        cur: list = []   # (query index, text, sentences, ids int32[], starts int64[], ends int64[])
+        tok = rng = 0
+        pending = []     # sub-batches in flight on the worker thread while this thread packs the next one
+
+        def add(item):
+            nonlocal cur, tok, rng
+            n_tok, n_rng = len(item[3]), len(item[4])
+            if n_tok > self.engine.max_tokens or n_rng > self.engine.max_ranges:
+                raise ValueError("a single sample exceeds the engine workspace")
+            if len(cur) >= self.engine.max_seqs or tok + n_tok > self.engine.max_tokens or rng + n_rng > self.engine.max_ranges:
+                pending.append(self._worker().submit(self._run_sub_batch, cur, out, len(pending) % len(self.engines)))
+                cur, tok, rng = [], 0, 0
+            cur.append(item)
+            tok += n_tok
+            rng += n_rng
+
         for qi, (question, results) in enumerate(zip(questions, results_per_question)):
             texts = [getattr(r, "text", "") for r in results]
-            all_sents, samples = self.pack_qa(question, texts)
             out.append({t: [] for t in texts})
-            for i, smp in enumerate(samples):
-                if smp is None:
+            q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
+            for i, (t, entry) in enumerate(zip(texts, self._entries(texts))):
+                if not entry[0]:
+                    continue                              # blank chunk -> [] (extractors.py:209-211)
+                fast = self._pack_fast(q_ids, entry)
+                if fast is not None:
+                    add((qi, t, entry[0], fast[0], fast[1], fast[2]))
                     continue
+                smp = encode_question_and_sentences(q_ids, entry[1], self._tok.sep_token_id, max_length=self.qa_max_length)
                 vb = valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
                 if not vb:
                     # the reference's QAModel returns None here and `len(None)` raises; we log and return [].
                     logger.error("query %d chunk %d: no sentence fits the %d-token budget", qi, i, self.qa_max_length)
                     continue
-                todo.append((qi, texts[i], all_sents[i], smp.input_ids, vb))
-        # sub-batches that fit the engine workspace
-        with self._lock:
-            start = 0
-            while start < len(todo):
-                tok = rng = 0
-                end = start
-                while end < len(todo) and end - start < self.engine.max_seqs and \
-                        tok + len(todo[end][3]) <= self.engine.max_tokens and rng + len(todo[end][4]) <= self.engine.max_ranges:
-                    tok += len(todo[end][3])
-                    rng += len(todo[end][4])
-                    end += 1
-                if end == start:
-                    raise ValueError("a single sample exceeds the engine workspace")
-                batch = todo[start:end]
-                try:
-                    logits = self.engine.qa_logits([b[3] for b in batch], [b[4] for b in batch])
-                    for (qi, text, sents, _ids, _vb), lg in zip(batch, logits):
-                        out[qi][text] = select_sentences(lg, sents, self.threshold)
-                except Exception as exc:  # same contract as extractors.py:225-227: log, [] for the chunk(s)
-                    logger.error("GPU span extraction failed: %s", exc)
-                start = end
+                add((qi, t, entry[0], np.asarray(smp.input_ids, np.int32), np.asarray([b[0] for b in vb], np.int64),
+                     np.asarray([b[1] for b in vb], np.int64)))
+        if cur:
+            if pending:
+                pending.append(self._worker().submit(self._run_sub_batch, cur, out, len(pending) % len(self.engines)))
+            else:
+                self._run_sub_batch(cur, out)             # the common single-query call: no thread hop
+        for f in pending:
+            f.result()
         return out
+
+    def _worker(self):
+        """One thread per engine handle drives the device for multi-sub-batch calls: the C call releases the GIL, so
+        the caller packs sub-batch n+1 while sub-batch n is on the GPU."""
+        with self._cache_lock:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="vrag-extract")
+            return self._pool
+
+    def _run_sub_batch(self, batch, out, which: int = 0) -> None:
+        """One workspace-sized batch: device logits, softmax, strict `>` threshold (extractors.py:272-275)."""
+        engine = self.engines[which]
+        with self._locks[which]:
+            try:
+                counts = np.asarray([len(b[4]) for b in batch], np.int64)
+                if hasattr(engine, "qa_logits_packed"):
+                    flat = engine.qa_logits_packed(
+                        np.concatenate([b[3] for b in batch]), np.asarray([len(b[3]) for b in batch], np.int32),
+                        np.repeat(np.arange(len(batch), dtype=np.int32), counts),
+                        np.concatenate([b[4] for b in batch]), np.concatenate([b[5] for b in batch]))
+                else:   # engines without the flat entry point
+                    flat = np.concatenate(engine.qa_logits(
+                        [b[3] for b in batch], [list(zip(b[4].tolist(), b[5].tolist())) for b in batch]))
+                keep = softmax_rows(flat)[:, 1] > self.threshold
+                o = 0
+                for (qi, text, sents, _ids, _st, _en), c in zip(batch, counts.tolist()):
+                    out[qi][text] = [sents[i] for i in np.nonzero(keep[o:o + c])[0].tolist() if i < len(sents)]
+                    o += c
+            except Exception as exc:  # same contract as extractors.py:225-227: log, [] for the chunk(s)
+                logger.error("GPU span extraction failed: %s", exc)
 
     # ------------------------------------------------------------------ v2 highlighter path
     def _encode_windows(self, question: str, context: str):

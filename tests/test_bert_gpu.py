@@ -132,6 +132,9 @@ def test_providers_on_bert_engine(base_width):
     ref = O.dense_pool(B.encoder_forward(cfg, W, [min(i, cfg.vocab_size - 1) for i in ids]), "cls", True)
     if max(ids) < cfg.vocab_size:
         assert np.abs(np.asarray(v) - ref).max() < 2e-3
+    # the query side of a cross-query batch: rows do not depend on their batch mates, bit for bit
+    assert sp.embed_queries(texts) == [sp.embed_text(t) for t in texts]
+    assert dn.embed_queries(texts) == [dn.embed_text(t) for t in texts]
 
 
 def test_head_dim_32_minilm_geometry_vs_oracle():

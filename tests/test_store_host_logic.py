@@ -1,0 +1,96 @@
+"""GpuVectorStore host logic on CPU: the two shard classes are replaced by stand-ins that answer from the exact CPU
+top-k oracle (oracle/topk_ref.c, the `(score desc, id asc)` order the kernels are tested against), so filters, deletes,
+the widening loop, RRF and `query_batch == [query]` are exercised here without a GPU; tests/test_query_batch_gpu.py runs
+the same comparison through the C ABI."""
+import numpy as np
+import pytest
+
+import verbatim_rag_amd  # noqa: F401
+from oracle import topk_ref as T
+from verbatim_rag_amd import vector_stores as vs
+
+
+class _Dense:
+    def __init__(self, dim, capacity, dtype="bf16", device=0):
+        self.rows = np.zeros((0, dim), np.float32)
+
+    def add(self, rows):
+        self.rows = np.concatenate([self.rows, np.asarray(rows, np.float32)])
+
+    def search(self, queries, k, stream=None):
+        kk = min(k, len(self.rows))
+        s, i = T.dense_topk(self.rows, np.asarray(queries, np.float32), kk)
+        pad = k - kk
+        return np.pad(s, ((0, 0), (0, pad))), np.pad(i, ((0, 0), (0, pad)), constant_values=-1)
+
+    def close(self):
+        pass
+
+
+class _Sparse:
+    def __init__(self, vocab, indptr, indices, values, device=0):
+        self.vocab, self.csr = vocab, (indptr, indices, values)
+
+    def search(self, queries, k, stream=None):
+        n = len(self.csr[0]) - 1
+        kk = min(k, n)
+        s, i = T.sparse_topk(*self.csr, self.vocab, *vs.dicts_to_csr(list(queries)), kk)
+        pad = k - kk
+        return np.pad(s, ((0, 0), (0, pad))), np.pad(i, ((0, 0), (0, pad)), constant_values=-1)
+
+    def close(self):
+        pass
+
+
+@pytest.fixture()
+def store(monkeypatch):
+    monkeypatch.setattr(vs._lib, "load", lambda: None)
+    monkeypatch.setattr(vs._lib, "require_gpu", lambda: None)
+    monkeypatch.setattr(vs, "DenseShard", _Dense)
+    monkeypatch.setattr(vs, "SparseShard", _Sparse)
+    rng = np.random.default_rng(2)
+    n, dim, vocab = 400, 64, 300
+    dense = (rng.integers(0, 2, (n, dim)) * 2 - 1).astype(np.float32) / np.float32(8.0)
+    sparse = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 10, replace=False), rng.integers(1, 64, 10) / 64)} for _ in range(n)]
+    st = vs.GpuVectorStore(dense_dim=dim, sparse_vocab=vocab)
+    st.add_vectors([f"id{i}" for i in range(n)], dense.tolist(), sparse, [f"text {i}" for i in range(n)],
+                   [f"enh {i}" for i in range(n)], [{"document_id": f"d{i % 3}", "n": i} for i in range(n)])
+    return st, dense, sparse, rng
+
+
+def _dump(per_q):
+    return [[(r.id, r.score, r.text, r.metadata) for r in rs] for rs in per_q]
+
+
+def test_query_batch_equals_per_query_on_cpu_stand_ins(store):
+    st, dense, sparse, rng = store
+    nq, vocab = 23, 300
+    dq = [dense[int(i)].tolist() for i in rng.integers(0, len(dense), nq)]
+    sq = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 5, replace=False), rng.integers(1, 64, 5) / 64)} for _ in range(nq)]
+    tq = [f"q{i}" for i in range(nq)]
+    cases = [dict(dense_queries=dq, search_type="dense", top_k=5), dict(sparse_queries=sq, search_type="sparse", top_k=7),
+             dict(dense_queries=dq, sparse_queries=sq, search_type="hybrid", top_k=5),
+             dict(dense_queries=dq, sparse_queries=sq, top_k=4, hybrid_weights={"dense": 0.7, "sparse": 0.3, "full_text": 2.0}, rrf_k=30),
+             dict(dense_queries=dq, sparse_queries=sq, top_k=4, hybrid_weights={"sparse": 1.0}),
+             dict(dense_queries=dq, search_type="dense", top_k=6, filter='metadata["document_id"] == "d1"'),
+             dict(dense_queries=dq, sparse_queries=sq, search_type="hybrid", top_k=3, filter='metadata["n"] in [0, 1, 2, 3, 5, 8, 9, 11]')]
+    for round_ in range(2):
+        for kw in cases:
+            rest = {k: v for k, v in kw.items() if not k.endswith("_queries")}
+            want = [st.query(dense_query=kw.get("dense_queries", [None] * nq)[i], sparse_query=kw.get("sparse_queries", [None] * nq)[i],
+                             text_query=tq[i], **rest) for i in range(nq)]
+            assert _dump(st.query_batch(text_queries=tq, **kw)) == _dump(want), (round_, rest)
+        st.delete([f"id{i}" for i in range(0, 400, 3)])
+
+
+def test_filter_widening_and_rrf_known_answers(store):
+    st, dense, sparse, rng = store
+    r = st.query(dense_query=dense[17].tolist(), sparse_query=sparse[17], top_k=5, search_type="hybrid")
+    assert r[0].id == "id17" and abs(r[0].score - (1.0 - (0.5 / 61 + 0.5 / 61))) < 1e-12
+    # only 4 rows pass the filter; the top-5 of the unfiltered search cannot contain them all -> widening loop
+    r = st.query(dense_query=dense[0].tolist(), top_k=4, search_type="dense", filter='metadata["n"] in [0, 1, 2, 3]')
+    assert sorted(x.metadata["n"] for x in r) == [0, 1, 2, 3] and r[0].id == "id0"
+    assert [len(x) for x in st.query_batch(dense_queries=[dense[0].tolist()] * 2, top_k=4, search_type="dense",
+                                           filter='metadata["n"] in [0, 1, 2, 3]')] == [4, 4]
+    with pytest.raises(ValueError):
+        st.query_batch(dense_queries=[dense[0].tolist()], sparse_queries=[{}, {}], search_type="dense")

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=30522)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--handles", type=int, default=2, help="encoder handles the extractor alternates sub-batches between")
+    ap.add_argument("--hybrid", action="store_true", help="configs[4] slice: + dense 768-d bf16 shard, top-2k per method, RRF")
+    ap.add_argument("--model", choices=("base", "large"), default="base", help="extractor geometry (configs[4]: large)")
     args = ap.parse_args()
 
     import torch
@@ -50,7 +52,7 @@ def main():
     import verbatim_rag_amd  # noqa: F401
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
     from verbatim_rag_amd.extractors import GpuModelSpanExtractor
-    from verbatim_rag_amd.vector_stores import SparseShard
+    from verbatim_rag_amd.vector_stores import DenseShard, SparseShard, merge_hybrid_results
     from verbatim_rag_amd.weights import random_init, random_qa_head
 
     rng = np.random.default_rng(1234)
@@ -66,9 +68,17 @@ def main():
     shard = SparseShard(V, indptr, idx, val)
     t_build = time.perf_counter() - t0
 
+    dense = None
+    if args.hybrid:                      # bge-base-sized rows on the dyadic grid, 100k rows per upload
+        t0 = time.perf_counter()
+        dense = DenseShard(768, n, "bf16")
+        for a in range(0, n, 100_000):
+            dense.add((rng.integers(-64, 65, size=(min(100_000, n - a), 768)) / 64.0).astype(np.float32))
+        t_build += time.perf_counter() - t0
+
     pool = make_texts(rng, 2048)
     tok = Tokenizer.from_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "tokenizer.json"))
-    shape = ModernBertShape.base()
+    shape = ModernBertShape.base() if args.model == "base" else ModernBertShape.large()
     weights, qa_head = random_init(shape, 1234), random_qa_head(shape)
     engs = []
     for _ in range(max(1, args.handles)):
@@ -82,11 +92,21 @@ def main():
     Q = args.queries
     queries = [{int(t): float(v) for t, v in zip(rng.choice(V, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(Q)]
     questions = ["Where is the tall iron tower in the city?"] * Q
+    dense_queries = (rng.integers(-64, 65, size=(Q, 768)) / 64.0).astype(np.float32) if args.hybrid else None
 
     def run():
         t = {}
         a = time.perf_counter()
-        scores, ids = shard.search(queries, args.k)
+        if dense is None:
+            scores, ids = shard.search(queries, args.k)
+        else:   # milvus_base.py:264-295: top-2k per method, equal-weight RRF (hybrid_search.py:73-129) on the host
+            _ss, si = shard.search(queries, 2 * args.k)
+            _ds, di = dense.search(dense_queries, 2 * args.k)
+            ids = np.full((Q, args.k), -1, np.int64)
+            for qi in range(Q):
+                rbm = {"dense": [{"id": int(r) + 1} for r in di[qi] if r >= 0], "sparse": [{"id": int(r) + 1} for r in si[qi] if r >= 0]}
+                for j, h in enumerate(merge_hybrid_results(rbm, args.k, {"dense": 0.5, "sparse": 0.5})):
+                    ids[qi, j] = h["id"] - 1                      # ids are offset by 1: the merge skips falsy ids
         t["search_s"] = time.perf_counter() - a
         a = time.perf_counter()
         results = [[types.SimpleNamespace(text=pool[int(i) % len(pool)]) for i in row if i >= 0] for row in ids]
@@ -109,7 +129,8 @@ def main():
     n_pairs = int((ids >= 0).sum())
     n_tokens_est = sum(len(v) for v in ext._chunk_cache.values())  # noqa: F841
     print(json.dumps({
-        "workload": f"sparse index {n} docs ({int(indptr[-1])} nnz, vocab {V}) + top-{args.k} + span extraction, {Q} queries",
+        "workload": f"sparse index {n} docs ({int(indptr[-1])} nnz, vocab {V})" + (f" + dense {n} x 768 bf16, RRF of top-{2 * args.k} per method" if args.hybrid else "")
+                    + f" + top-{args.k} + span extraction (ModernBERT-{args.model}), {Q} queries",
         "index_build_s": t_build, "total_s": total, "queries_per_s": Q / total, "search_s": t["search_s"],
         "extract_s": t["extract_s"], "search_queries_per_s": Q / t["search_s"],
         "extract_pairs_per_s": n_pairs / t["extract_s"], "pairs": n_pairs,
@@ -118,6 +139,8 @@ def main():
         "note": "host-inclusive wall time (ctypes calls, packing, dict building); extraction batched across queries",
     }))
     shard.close()
+    if dense is not None:
+        dense.close()
     for e in engs:
         e.close()
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Embedding-side probe: BERT-base / DistilBERT-base shaped encoders (random-init, seeded) on
 synthetic token batches resident in HBM: texts/s for dense pooling (encoder only) and SPLADE rows (encoder +
-MLM head + max-pool).  Also prints the max-abs error of the first sequences against the numpy oracle.
+MLM head + max-pool).  Parity of the same path at this width is tests/test_bert_gpu.py (tools never touch oracle/).
 Prints one JSON object per model."""
 import argparse
 import json
@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--texts", type=int, default=256)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--check", type=int, default=2, help="sequences compared with the oracle (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -64,25 +63,6 @@ def main():
                "batch": f"{n} x {S} tokens", "dense_texts_per_s": n / td, "dense_ms": td * 1e3,
                "dense_tflops": n * enc_flop / td / 1e12, "splade_texts_per_s": n / ts, "splade_ms": ts * 1e3,
                "splade_tflops": n * (enc_flop + head_flop) / ts / 1e12}
-        if args.check:
-            from oracle import bert_np as B
-            from oracle import modernbert_np as O
-
-            cfg = B.BertConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=shape.num_attention_heads,
-                               intermediate_size=I, max_position_embeddings=shape.max_position_embeddings)
-            eng.run()
-            hid = eng.read_hidden(False)
-            eng.run_pool(True)
-            pooled = eng.read_pool()
-            eng.run_splade()
-            rows = eng.read_splade()
-            eh = ep = es = 0.0
-            for i in range(args.check):
-                ref = B.encoder_forward(cfg, W, seqs[i])
-                eh = max(eh, float(np.abs(hid[i * S:(i + 1) * S] - ref).max()))
-                ep = max(ep, float(np.abs(pooled[i] - O.dense_pool(ref, "mean", True)).max()))
-                es = max(es, float(np.abs(rows[i] - O.splade_pool(B.mlm_logits(cfg, W, ref))).max()))
-            out.update({"err_hidden": eh, "err_pooled": ep, "err_splade": es})
         print(json.dumps(out))
         eng.close()
 

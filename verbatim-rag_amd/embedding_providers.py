@@ -126,6 +126,11 @@ class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
     def embed_batch(self, texts: List[str]) -> List[Dict[int, float]]:
         return self._dicts(texts, 0.0)                     # every non-zero, embedding_providers.py:161-163
 
+    def embed_queries(self, texts: List[str]) -> List[Dict[int, float]]:
+        """`[embed_text(t) for t in texts]` (the |w| > 1e-6 rule) as shared device batches -- the query side of a
+        cross-query batch; `embed_batch` is the ingest side and keeps every non-zero."""
+        return self._dicts(texts, 1e-6)
+
     def get_dimension(self) -> int:
         return int(self.engine.shape.vocab_size)
 
@@ -157,6 +162,10 @@ class GpuDenseProvider(_EncoderProvider, DenseEmbeddingProvider):
         return self._rows([text])[0].tolist()
 
     def embed_batch(self, texts: List[str]) -> List[List[float]]:
+        return self._rows(texts).tolist()
+
+    def embed_queries(self, texts: List[str]) -> List[List[float]]:
+        """`[embed_text(t) for t in texts]` as shared device batches (rows do not depend on their batch mates)."""
         return self._rows(texts).tolist()
 
     def get_dimension(self) -> int:

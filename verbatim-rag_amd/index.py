@@ -75,3 +75,38 @@ class HotPathIndex:
             qs = self.sparse_provider.embed_text(text)
         return self.vector_store.query(dense_query=qd, sparse_query=qs, text_query=text, top_k=k,
                                        search_type=search_type, filter=filter, search_params=search_params, rrf_k=rrf_k)
+
+    # ------------------------------------------------------------------ cross-query batching
+    @staticmethod
+    def _embed_queries(provider, texts: List[str]):
+        fn = getattr(provider, "embed_queries", None)
+        return fn(texts) if fn is not None else [provider.embed_text(t) for t in texts]
+
+    def query_batch(self, texts: Sequence[str], k: int = 5, search_type: str = "auto", filter: Optional[str] = None,
+                    search_params: Optional[Dict[str, Any]] = None, hybrid_weights: Optional[Dict[str, float]] = None,
+                    rrf_k: int = 60) -> List[List[SearchResult]]:
+        """`[query(t, k, ...) for t in texts]` for many concurrent queries: the query embeddings go through the
+        providers as shared batches (`embed_queries` when the provider has it) and the store answers them in one
+        `query_batch` call when it has one; anything else takes `query`, one text at a time."""
+        texts = list(texts)
+        store_batch = getattr(self.vector_store, "query_batch", None)
+        if store_batch is None or not texts or any(not t for t in texts):
+            return [self.query(t, k, search_type, filter, search_params, hybrid_weights, rrf_k) for t in texts]
+        if hybrid_weights is not None:
+            qd = self._embed_queries(self.dense_provider, texts) if "dense" in hybrid_weights and self.dense_provider else None
+            qs = self._embed_queries(self.sparse_provider, texts) if "sparse" in hybrid_weights and self.sparse_provider else None
+            return store_batch(dense_queries=qd, sparse_queries=qs, text_queries=texts, top_k=k, filter=filter,
+                               search_params=search_params, hybrid_weights=hybrid_weights, rrf_k=rrf_k)
+        if search_type == "auto":
+            if self.dense_provider and self.sparse_provider:
+                search_type = "hybrid"
+            elif self.dense_provider:
+                search_type = "dense"
+            elif self.sparse_provider:
+                search_type = "sparse"
+        if search_type not in ("dense", "sparse", "hybrid"):
+            return [self.query(t, k, search_type, filter, search_params, hybrid_weights, rrf_k) for t in texts]
+        qd = self._embed_queries(self.dense_provider, texts) if search_type in ("dense", "hybrid") and self.dense_provider else None
+        qs = self._embed_queries(self.sparse_provider, texts) if search_type in ("sparse", "hybrid") and self.sparse_provider else None
+        return store_batch(dense_queries=qd, sparse_queries=qs, text_queries=texts, top_k=k, search_type=search_type,
+                           filter=filter, search_params=search_params, rrf_k=rrf_k)

@@ -64,3 +64,26 @@ class StaticVerbatimPipeline:
         # core.py:266-272 passes the number of *documents* in the dict as display_span_count (quirk kept)
         return self.response_builder.build_response(question=question, answer=answer, search_results=results,
                                                     relevant_spans=spans, display_span_count=len(spans))
+
+    def query_batch(self, questions, k: Optional[int] = None, filter: Optional[str] = None,
+                    hybrid_weights: Optional[Dict[str, float]] = None, rrf_k: int = 60):
+        """`[query(q, ...) for q in questions]` with retrieval and extraction batched across the queries
+        (HotPathIndex.query_batch, extract_spans_batch) -- the serving shape of BASELINE configs[2]/[4]."""
+        questions = list(questions)
+        if hasattr(self.index, "query_batch"):
+            per_q = self.index.query_batch(questions, k=k or self.k, filter=filter, hybrid_weights=hybrid_weights, rrf_k=rrf_k)
+        else:
+            per_q = [self.index.query(text=q, k=k or self.k, filter=filter, hybrid_weights=hybrid_weights, rrf_k=rrf_k)
+                     for q in questions]
+        per_q = [self._apply_reranker(q, r) for q, r in zip(questions, per_q)]
+        if hasattr(self.extractor, "extract_spans_batch"):
+            spans_per_q = self.extractor.extract_spans_batch(questions, per_q)
+        else:
+            spans_per_q = [self.extractor.extract_spans(q, r) for q, r in zip(questions, per_q)]
+        out = []
+        for question, results, spans in zip(questions, per_q, spans_per_q):
+            flat = [{"text": s, "doc_text": t} for t, ss in spans.items() for s in ss]
+            answer = self.response_builder.clean_answer(fill_static_template(flat[: self.max_display_spans]))
+            out.append(self.response_builder.build_response(question=question, answer=answer, search_results=results,
+                                                            relevant_spans=spans, display_span_count=len(spans)))
+        return out

@@ -355,7 +355,8 @@ class GpuVectorStore(VectorStore):
     sparse = IP over shared terms.  Rows live on the host until the first query after an insert
     ("flush"), then in HBM.  `filter` supports the comparison subset of Milvus expressions in `parse_filter`
     (the reference itself only builds `metadata["document_id"] == "..."`, index.py:735-739); anything else is
-    rejected loudly.
+    rejected loudly.  Filters and deletes act before the search like Milvus' (a selective filter still returns its
+    best rows): `_search_batch` re-runs short queries on a cached shard of just the passing rows.
     """
 
     enable_full_text = False
@@ -376,6 +377,10 @@ class GpuVectorStore(VectorStore):
         self._dense: Optional[DenseShard] = None
         self._sparse: Optional[SparseShard] = None
         self._dirty = False
+        self._masks: Dict[str, Optional[np.ndarray]] = {}
+        self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
+
+    SUBSET_CACHE = 4
 
     # -------------------------------------------------------------- ingest
     def add_vectors(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
@@ -396,12 +401,14 @@ class GpuVectorStore(VectorStore):
             if self.enable_sparse:
                 self._sparse_rows.append({int(k): float(v) for k, v in sparse_vectors[i].items()})
         self._dirty = True
+        self._drop_subsets()
 
     def delete(self, ids: List[str]):
         kill = set(ids)
         for i, x in enumerate(self._ids):
             if x in kill:
                 self._alive[i] = False
+        self._drop_subsets()
 
     def _flush(self):
         if not self._dirty:
@@ -421,35 +428,157 @@ class GpuVectorStore(VectorStore):
 
     # -------------------------------------------------------------- search
     def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
-        alive = np.asarray(self._alive, dtype=bool)
-        if filter:
-            pred = parse_filter(filter)
-            alive = alive & np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
-        return None if alive.all() else alive
+        """Rows a query may return (alive and passing `filter`), or None for all; cached per filter string until the
+        next insert / delete (one Python predicate call per row otherwise, on every query)."""
+        key = filter or ""
+        if key not in self._masks:
+            alive = np.asarray(self._alive, dtype=bool)
+            if filter:
+                pred = parse_filter(filter)
+                alive = alive & np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
+            if len(self._masks) >= 64:
+                self._masks.clear()
+            self._masks[key] = None if alive.all() else alive
+        return self._masks[key]
 
     def _hit(self, row: int, score: float) -> dict:
         return {"id": self._ids[row], "distance": float(score),
                 "entity": {"text": self._texts[row], "enhanced_text": self._enh[row], "metadata": dict(self._meta[row])}}
 
     def _search(self, kind: str, query, limit: int, mask: Optional[np.ndarray]) -> List[dict]:
-        self._flush()
-        n = len(self._ids)
-        if n == 0:
-            return []
-        shard = self._dense if kind == "dense" else self._sparse
-        want = limit
-        while True:
-            k = min(64, want)
-            if kind == "dense":
+        return self._search_batch(kind, [query], limit, mask)[0]
+
+    def _device_topk(self, kind: str, shard, queries: Sequence[Any], k: int):
+        if kind == "dense":
+            rows_q = np.empty((len(queries), self.dense_dim), np.float32)
+            for i, query in enumerate(queries):
                 q = np.asarray(query, dtype=np.float32)
                 nq = float(np.sqrt((q * q).sum(dtype=np.float32)))
-                scores, rows = shard.search((q / nq if nq > 0 else q)[None], k)
+                rows_q[i] = q / nq if nq > 0 else q
+            return shard.search(rows_q, k)
+        return shard.search([{int(t): float(v) for t, v in query.items()} for query in queries], k)
+
+    def _subset(self, kind: str, mask: np.ndarray):
+        """A shard holding only the rows that pass `mask` (Milvus filters before it searches, milvus_base.py:240-262, so
+        a selective filter must still return its best rows however far down the unfiltered ranking they are).  Built
+        from the host copies, cached per (kind, mask) until the next insert / delete; subset row j is global row idx[j],
+        idx ascending, so the kernels' `(score desc, id asc)` order carries over."""
+        key = (kind, mask.tobytes())
+        hit = self._subsets.get(key)
+        if hit is None:
+            idx = np.nonzero(mask)[0]
+            if kind == "dense":
+                shard = DenseShard(self.dense_dim, len(idx), self.dense_dtype, self.device)
+                shard.add(np.stack([self._dense_rows[i] for i in idx]))
             else:
-                scores, rows = shard.search([{int(t): float(v) for t, v in query.items()}], k)
-            hits = [(int(r), float(s)) for r, s in zip(rows[0], scores[0]) if r >= 0 and (mask is None or mask[r])]
-            if len(hits) >= limit or k >= min(64, n) or want >= 64:
-                return [self._hit(r, s) for r, s in hits[:limit]]
-            want = min(64, want * 4)  # filtered / deleted rows ate some slots: widen
+                shard = SparseShard(self.sparse_vocab, *dicts_to_csr([self._sparse_rows[i] for i in idx]), device=self.device)
+            while len(self._subsets) >= self.SUBSET_CACHE:
+                self._subsets.pop(next(iter(self._subsets)))[0].close()
+            hit = self._subsets[key] = (shard, idx)
+        return hit
+
+    def _drop_subsets(self):
+        for shard, _idx in self._subsets.values():
+            shard.close()
+        self._subsets.clear()
+        self._masks.clear()
+
+    def _search_batch(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> List[List[dict]]:
+        """Best `limit` (<= 64) rows per query among the rows that pass `mask`, one device pass for the whole batch
+        over the full shard; queries that come up short because filtered / deleted rows took their slots (and every
+        query when the filter passes under 1/8 of the rows) get a second pass over the masked subset shard."""
+        self._flush()
+        n = len(self._ids)
+        if n == 0 or len(queries) == 0:
+            return [[] for _ in queries]
+        k = min(64, limit)
+        n_pass = n if mask is None else int(mask.sum())
+        if n_pass == 0:
+            return [[] for _ in queries]
+        want = min(k, n_pass)
+        out: List[Optional[List[dict]]] = [None] * len(queries)
+        if mask is None or n_pass * 8 >= n:
+            scores, rows = self._device_topk(kind, self._dense if kind == "dense" else self._sparse, queries, k)
+            for i in range(len(queries)):
+                hits = [(int(r), float(s)) for r, s in zip(rows[i], scores[i]) if r >= 0 and (mask is None or mask[r])]
+                # a sparse query can have fewer than `want` rows sharing a term: then the full pass, which returned
+                # fewer than k candidates, has already seen every match
+                if len(hits) >= want or mask is None or int((rows[i] >= 0).sum()) < k:
+                    out[i] = [self._hit(r, s) for r, s in hits[:limit]]
+        short = [i for i, o in enumerate(out) if o is None]
+        if short:
+            shard, idx = self._subset(kind, mask)
+            scores, rows = self._device_topk(kind, shard, [queries[i] for i in short], want)
+            for j, i in enumerate(short):
+                out[i] = [self._hit(int(idx[r]), float(s)) for r, s in zip(rows[j], scores[j]) if r >= 0][:limit]
+        return out
+
+    def query_batch(self, dense_queries: Optional[Sequence[Any]] = None, sparse_queries: Optional[Sequence[Any]] = None,
+                    text_queries: Optional[Sequence[Optional[str]]] = None, top_k: int = 5, search_type: str = "hybrid",
+                    filter: Optional[str] = None, search_params: Optional[Dict[str, Any]] = None,
+                    hybrid_weights: Optional[Dict[str, float]] = None, rrf_k: int = 60) -> List[List[SearchResult]]:
+        """Cross-query form of `query`: element i equals `query(dense_queries[i], sparse_queries[i], ...)`,
+        with the dense and the sparse searches of all queries done as one batched device pass each (the batched
+        kernels order hits by `(score desc, id asc)` like the single-query ones).  Queries that take one of `query`'s
+        side branches (no vectors, a missing half in hybrid mode) are answered by `query` itself.  On a bf16 shard a
+        batch of >= 8 dense queries runs on the matrix cores with the queries rounded to bf16 (include/vrag_amd.h,
+        vrag_dense_index_search), so for queries that are not bf16-exact the scores of a batch can differ from the
+        single-query scores in the third digit; an f32 shard has no such difference."""
+        n = max(len(x) for x in (dense_queries, sparse_queries, text_queries) if x is not None)
+        dq = list(dense_queries) if dense_queries is not None else [None] * n
+        sq = list(sparse_queries) if sparse_queries is not None else [None] * n
+        tq = list(text_queries) if text_queries is not None else [None] * n
+        if not (len(dq) == len(sq) == len(tq) == n):
+            raise ValueError("query_batch: dense_queries / sparse_queries / text_queries differ in length")
+
+        def single(i):
+            return self.query(dense_query=dq[i], sparse_query=sq[i], text_query=tq[i], top_k=top_k, search_type=search_type,
+                              filter=filter, search_params=search_params, hybrid_weights=hybrid_weights, rrf_k=rrf_k)
+
+        def is_set(q):   # `query` tests vectors by truthiness (milvus_base.py:232,243,254)
+            return q is not None and len(q) > 0
+
+        if hybrid_weights is not None:
+            weights = sanitize_hybrid_weights(hybrid_weights)
+            if "full_text" in weights and not self.enable_full_text:
+                weights = {k: v for k, v in weights.items() if k != "full_text"}
+            d_some, s_some = [q is not None for q in dq], [q is not None for q in sq]
+            uniform = (all(d_some) or not any(d_some)) and (all(s_some) or not any(s_some))
+            use_d, use_s = "dense" in weights and all(d_some), "sparse" in weights and all(s_some)
+            if not weights or not uniform or not (use_d or use_s):
+                return [single(i) for i in range(n)]          # mixed / degenerate batches: the per-query code decides
+            mask = self._mask(filter)
+            rd = self._search_batch("dense", dq, top_k * 2, mask) if use_d else None
+            rs = self._search_batch("sparse", sq, top_k * 2, mask) if use_s else None
+            out = []
+            for i in range(n):
+                rbm = {}
+                if rd is not None:
+                    rbm["dense"] = rd[i]
+                if rs is not None:
+                    rbm["sparse"] = rs[i]
+                if len(rbm) == 1:
+                    out.append(convert_hits_to_results(list(rbm.values())[0][:top_k]))
+                else:
+                    out.append(convert_hits_to_results(merge_hybrid_results(rbm, top_k, weights, rrf_k)))
+            return out
+        if search_type == "dense" and all(is_set(q) for q in dq):
+            mask = self._mask(filter)
+            return [convert_hits_to_results(h) for h in self._search_batch("dense", dq, top_k, mask)]
+        if search_type == "sparse" and all(is_set(q) for q in sq):
+            mask = self._mask(filter)
+            return [convert_hits_to_results(h) for h in self._search_batch("sparse", sq, top_k, mask)]
+        if search_type == "hybrid" and all(is_set(q) for q in dq) and all(is_set(q) for q in sq):
+            mask = self._mask(filter)
+            try:
+                rd = self._search_batch("dense", dq, top_k * 2, mask)
+                rs = self._search_batch("sparse", sq, top_k * 2, mask)
+                return [convert_hits_to_results(merge_hybrid_results({"dense": rd[i], "sparse": rs[i]}, top_k,
+                                                                     {"dense": 0.5, "sparse": 0.5}, rrf_k=rrf_k))
+                        for i in range(n)]
+            except Exception as e:
+                logger.warning("Batched hybrid search failed: %s, answering per query", e)
+        return [single(i) for i in range(n)]
 
     def query(self, dense_query=None, sparse_query=None, text_query=None, top_k: int = 5, search_type: str = "hybrid",
               filter: Optional[str] = None, search_params: Optional[Dict[str, Any]] = None,

@@ -94,3 +94,20 @@ def test_filter_widening_and_rrf_known_answers(store):
                                            filter='metadata["n"] in [0, 1, 2, 3]')] == [4, 4]
     with pytest.raises(ValueError):
         st.query_batch(dense_queries=[dense[0].tolist()], sparse_queries=[{}, {}], search_type="dense")
+
+
+def test_dicts_to_csr_equals_the_per_entry_loop():
+    rng = np.random.default_rng(9)
+    rows = [{int(t): float(v) for t, v in zip(rng.choice(5000, int(n), replace=False), rng.random(int(n)) * 3)}
+            for n in rng.integers(0, 40, 300)]
+    rows[7] = {}
+    rows[11] = {np.int32(4): np.float32(0.1), 2: 1, 4999: 1e-9}
+    indptr, terms, weights = vs.dicts_to_csr(rows)
+    assert indptr.dtype == np.int64 and terms.dtype == np.int32 and weights.dtype == np.float32 and len(indptr) == len(rows) + 1
+    for i, r in enumerate(rows):
+        want = sorted((int(t), float(v)) for t, v in r.items())
+        a, b = int(indptr[i]), int(indptr[i + 1])
+        assert terms[a:b].tolist() == [t for t, _ in want]
+        assert weights[a:b].tolist() == [float(np.float32(v)) for _, v in want]
+    e = vs.dicts_to_csr([])
+    assert e[0].tolist() == [0] and len(e[1]) == 0 and len(e[2]) == 0

@@ -193,17 +193,19 @@ class DenseShard:
 
 
 def dicts_to_csr(rows: Sequence[Dict[int, float]]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    indptr = np.zeros(len(rows) + 1, np.int64)
-    for i, r in enumerate(rows):
-        indptr[i + 1] = indptr[i] + len(r)
-    indices = np.empty(int(indptr[-1]), np.int32)
-    values = np.empty(int(indptr[-1]), np.float32)
-    for i, r in enumerate(rows):
-        a = int(indptr[i])
-        for j, (t, v) in enumerate(sorted(r.items())):
-            indices[a + j] = int(t)
-            values[a + j] = float(v)
-    return indptr, indices, values
+    """`{term: weight}` rows -> CSR (int64 indptr, int32 terms ascending within a row, float32 weights).  One pass of
+    C-level iteration plus a lexsort: a 1 M-document ingest or a 1 000-query batch does not loop in Python per entry."""
+    from itertools import chain
+
+    n = len(rows)
+    lens = np.fromiter((len(r) for r in rows), np.int64, n)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    total = int(indptr[-1])
+    terms = np.fromiter(chain.from_iterable(rows), np.int64, total)                       # iterating a dict yields its keys
+    weights = np.fromiter(chain.from_iterable(r.values() for r in rows), np.float64, total)
+    order = np.lexsort((terms, np.repeat(np.arange(n, dtype=np.int64), lens)))
+    return indptr, terms[order].astype(np.int32), weights[order].astype(np.float32)
 
 
 class SparseShard:
@@ -456,7 +458,7 @@ class GpuVectorStore(VectorStore):
                 nq = float(np.sqrt((q * q).sum(dtype=np.float32)))
                 rows_q[i] = q / nq if nq > 0 else q
             return shard.search(rows_q, k)
-        return shard.search([{int(t): float(v) for t, v in query.items()} for query in queries], k)
+        return shard.search(queries, k)       # dicts_to_csr converts keys / weights to int32 / float32
 
     def _subset(self, kind: str, mask: np.ndarray):
         """A shard holding only the rows that pass `mask` (Milvus filters before it searches, milvus_base.py:240-262, so

@@ -444,8 +444,17 @@ class GpuVectorStore(VectorStore):
         return self._masks[key]
 
     def _hit(self, row: int, score: float) -> dict:
-        return {"id": self._ids[row], "distance": float(score),
-                "entity": {"text": self._texts[row], "enhanced_text": self._enh[row], "metadata": dict(self._meta[row])}}
+        """A search hit in the shape `merge_hybrid_results` works on; the entity (text, metadata copy) is attached
+        by `_results` only to the hits that survive the merge."""
+        return {"id": self._ids[row], "distance": float(score), "_row": row}
+
+    def _results(self, hits: List[dict]) -> List[SearchResult]:
+        full = []
+        for h in hits:
+            row = h["_row"]
+            full.append({"id": h["id"], "distance": h["distance"],
+                         "entity": {"text": self._texts[row], "enhanced_text": self._enh[row], "metadata": dict(self._meta[row])}})
+        return convert_hits_to_results(full)
 
     def _search(self, kind: str, query, limit: int, mask: Optional[np.ndarray]) -> List[dict]:
         return self._search_batch(kind, [query], limit, mask)[0]
@@ -560,22 +569,22 @@ class GpuVectorStore(VectorStore):
                 if rs is not None:
                     rbm["sparse"] = rs[i]
                 if len(rbm) == 1:
-                    out.append(convert_hits_to_results(list(rbm.values())[0][:top_k]))
+                    out.append(self._results(list(rbm.values())[0][:top_k]))
                 else:
-                    out.append(convert_hits_to_results(merge_hybrid_results(rbm, top_k, weights, rrf_k)))
+                    out.append(self._results(merge_hybrid_results(rbm, top_k, weights, rrf_k)))
             return out
         if search_type == "dense" and all(is_set(q) for q in dq):
             mask = self._mask(filter)
-            return [convert_hits_to_results(h) for h in self._search_batch("dense", dq, top_k, mask)]
+            return [self._results(h) for h in self._search_batch("dense", dq, top_k, mask)]
         if search_type == "sparse" and all(is_set(q) for q in sq):
             mask = self._mask(filter)
-            return [convert_hits_to_results(h) for h in self._search_batch("sparse", sq, top_k, mask)]
+            return [self._results(h) for h in self._search_batch("sparse", sq, top_k, mask)]
         if search_type == "hybrid" and all(is_set(q) for q in dq) and all(is_set(q) for q in sq):
             mask = self._mask(filter)
             try:
                 rd = self._search_batch("dense", dq, top_k * 2, mask)
                 rs = self._search_batch("sparse", sq, top_k * 2, mask)
-                return [convert_hits_to_results(merge_hybrid_results({"dense": rd[i], "sparse": rs[i]}, top_k,
+                return [self._results(merge_hybrid_results({"dense": rd[i], "sparse": rs[i]}, top_k,
                                                                      {"dense": 0.5, "sparse": 0.5}, rrf_k=rrf_k))
                         for i in range(n)]
             except Exception as e:
@@ -606,7 +615,7 @@ class GpuVectorStore(VectorStore):
         else:
             raise ValueError(f"Invalid search configuration: type={search_type}, "
                              f"dense={dense_query is not None}, sparse={sparse_query is not None}")
-        return convert_hits_to_results(hits)
+        return self._results(hits)
 
     def _filter_only_query(self, filter: Optional[str], limit: int) -> List[SearchResult]:
         mask = self._mask(filter)
@@ -632,8 +641,8 @@ class GpuVectorStore(VectorStore):
             logger.warning("Hybrid search: no valid methods executed after validation")
             return []
         if len(rbm) == 1:
-            return convert_hits_to_results(list(rbm.values())[0][:top_k])
-        return convert_hits_to_results(merge_hybrid_results(rbm, top_k, hybrid_weights, rrf_k))
+            return self._results(list(rbm.values())[0][:top_k])
+        return self._results(merge_hybrid_results(rbm, top_k, hybrid_weights, rrf_k))
 
     def get_document(self, document_id: str):
         return None

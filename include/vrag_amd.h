@@ -236,7 +236,10 @@ int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/
 /* ------------------------------------------------------------------------------------------
  * Exact dot-product top-k (what the reference delegates to Milvus:
  * verbatim_rag/vector_stores/milvus_base.py:239-259, metric types milvus_local.py:109-129).
- * Order: (score desc, id asc).  Missing hits: id = -1, score = -inf.  1 <= k <= 64.
+ * Order: (score desc, id asc), ties included.  Missing hits: id = -1, score = -inf.  1 <= k <= 1024 for the search
+ * calls (Milvus' `limit`, milvus_base.py:244-277: the reference asks for top_k or 2*top_k): lists of up to 64 come from
+ * one device pass, longer ones as exact pages of 64 (page p+1 admits only keys below the last key of page p) on the
+ * scalar kernels with fp32 queries; `*_run_resident` re-runs a single pass (k <= 64).
  * Dense rows are stored bf16 (dtype 0) or fp32 (dtype 1); COSINE == IP on rows/queries the caller
  * L2-normalised.  ids are row numbers in insertion order (the caller adds its shard base).
  */

@@ -232,3 +232,93 @@ def test_dense_topk_fuzz_shapes(seed):
     rs, ri = T.dense_topk(X, Q, k)
     assert np.array_equal(i, ri), (n, dim, nq, k, dtype)
     assert np.array_equal(s, rs), (n, dim, nq, k, dtype)
+
+
+def test_sparse_ties_order_by_document_id():
+    """Short documents and queries with weights in {0.5, 1}: most hits tie.  The index stores documents sorted by
+    length, so the key must carry the caller's document index for `(score desc, id asc)` to hold."""
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    rng = np.random.default_rng(77)
+    n, vocab = 30000, 300
+    lens = rng.integers(1, 9, n)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    idx = np.concatenate([np.sort(rng.choice(vocab, int(m), replace=False)) for m in lens]).astype(np.int32)
+    val = (rng.integers(1, 3, len(idx)) / 2).astype(np.float32)
+    qp = np.arange(0, 3 * 21, 3)
+    qi = np.concatenate([np.sort(rng.choice(vocab, 3, replace=False)) for _ in range(20)]).astype(np.int32)
+    qv = (rng.integers(1, 3, len(qi)) / 2).astype(np.float32)
+    sh = SparseShard(vocab, indptr, idx, val)
+    try:
+        for k in (5, 17, 64):
+            rs, ri = T.sparse_topk(indptr, idx, val, vocab, qp, qi, qv, k)
+            s, i = sh.search_csr(qp, qi, qv, k)                                   # batched kernel
+            assert np.array_equal(i, ri) and np.array_equal(s, rs), k
+            s1, i1 = sh.search_csr(qp[:2], qi[:3], qv[:3], k)                     # single-query kernel
+            assert np.array_equal(i1, ri[:1]) and np.array_equal(s1, rs[:1]), k
+    finally:
+        sh.close()
+
+
+@pytest.mark.parametrize("dtype,dim,n,nq,k", [("f32", 64, 5000, 5, 100), ("bf16", 768, 20000, 3, 200), ("bf16", 128, 90, 2, 100),
+                                               ("f32", 256, 3000, 1, 1000), ("bf16", 384, 70000, 9, 65)])
+def test_dense_paged_topk_beyond_64(dtype, dim, n, nq, k):
+    """k > 64: exact pages of 64.  Rows are duplicated in runs so that page boundaries fall inside groups of equal
+    scores (the `(score desc, id asc)` order has to carry across pages); n < k leaves -1 / -inf tails."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(n + k)
+    base = _dyadic(rng, (max(1, n // 40), dim))
+    X = base[rng.integers(0, len(base), n)]                   # ~40 copies of every distinct row
+    Q = _dyadic(rng, (nq, dim))
+    sh = DenseShard(dim, n, dtype)
+    sh.add(X)
+    s, i = sh.search(Q, k)
+    s2, i2 = sh.search(Q[:1], 5)                              # a single-pass call afterwards still works
+    sh.close()
+    rs, ri = T.dense_topk(X, Q, min(k, n))
+    assert np.array_equal(i[:, :min(k, n)], ri) and np.array_equal(s[:, :min(k, n)], rs)
+    if n < k:
+        assert (i[:, n:] == -1).all() and np.isneginf(s[:, n:]).all()
+    assert np.array_equal(i2, ri[:1, :5]) and np.array_equal(s2, rs[:1, :5])
+
+
+def test_sparse_paged_topk_beyond_64():
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    rng = np.random.default_rng(5)
+    indptr, idx, val, qp, qi, qv = _sparse_corpus(rng, 20000, 3000, 12, 7, 6)
+    val = (rng.integers(1, 5, len(val)) / 4).astype(np.float32)          # heavy ties
+    qv = (rng.integers(1, 3, len(qv)) / 2).astype(np.float32)
+    sh = SparseShard(3000, indptr, idx, val)
+    try:
+        for k in (65, 150, 1000):
+            rs, ri = T.sparse_topk(indptr, idx, val, 3000, qp, qi, qv, k)
+            s, i = sh.search_csr(qp, qi, qv, k)
+            assert np.array_equal(i, ri) and np.array_equal(s, rs), k
+        rs, ri = T.sparse_topk(indptr, idx, val, 3000, qp, qi, qv, 8)        # back to the batched single pass
+        s, i = sh.search_csr(qp, qi, qv, 8)
+        assert np.array_equal(i, ri) and np.array_equal(s, rs)
+        with pytest.raises(Exception):
+            sh.search_csr(qp, qi, qv, 1025)
+    finally:
+        sh.close()
+
+
+def test_store_returns_more_than_64_hits():
+    from verbatim_rag_amd.vector_stores import GpuVectorStore
+
+    rng = np.random.default_rng(8)
+    n, dim = 500, 64
+    dense = (rng.integers(0, 2, (n, dim)) * 2 - 1).astype(np.float32) / np.float32(8.0)
+    st = GpuVectorStore(dense_dim=dim, enable_sparse=False, sparse_vocab=None, dense_dtype="f32")
+    st.add_vectors([f"id{i}" for i in range(n)], dense.tolist(), None, [f"t{i}" for i in range(n)], [""] * n,
+                   [{"document_id": f"d{i % 2}"} for i in range(n)])
+    r = st.query(dense_query=dense[3].tolist(), top_k=120, search_type="dense")
+    rs, ri = T.dense_topk(dense, dense[3:4], 120)
+    assert [x.id for x in r] == [f"id{j}" for j in ri[0]]
+    r = st.query(dense_query=dense[3].tolist(), top_k=100, search_type="dense", filter='metadata["document_id"] == "d1"')
+    odd = np.arange(1, n, 2)
+    rs, ri = T.dense_topk(dense[odd], dense[3:4], 100)
+    assert [x.id for x in r] == [f"id{odd[j]}" for j in ri[0]]
+    st._dense.close()

@@ -51,7 +51,15 @@ __device__ __forceinline__ u64 make_key(float s, unsigned row) {
   return ((u64)orderable(s) << 32) | (u64)(0xFFFFFFFFu - row);
 }
 
-constexpr int KMAX = 64;  // largest k supported by the device paths
+// Paged search (k > KMAX): page p+1 only admits keys strictly below the last key of page p; keys are unique per
+// (score, row), so the pages are disjoint and their concatenation is the exact top-(pages * KMAX).
+__device__ __forceinline__ u64 make_key_below(float s, unsigned row, u64 bound) {
+  const u64 key = make_key(s, row);
+  return key < bound ? key : 0ull;
+}
+
+constexpr int KMAX = 64;        // list length of one device pass
+constexpr int KPAGED_MAX = 1024;  // largest k of a search call (ceil(k / KMAX) passes)
 
 // Sorted (descending) insert into list[0..k) held in LDS; called by ONE lane.
 __device__ __forceinline__ void insert_key(u64* list, int k, u64 key) {
@@ -75,7 +83,8 @@ constexpr int DENSE_WGS = 1536;  // target grid: 256 CUs x 6 resident workgroups
 template <bool F32, int QT, int DIMC>
 __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict__ rows_v, long long n_rows, int dim,
                                                           const float* __restrict__ queries, int nq, int q0,
-                                                          int k, u64* __restrict__ cand, int rows_per_wg) {
+                                                          int k, u64* __restrict__ cand, int rows_per_wg,
+                                                          const u64* __restrict__ bound) {
   // LDS: queries [QT][dim] fp32, per 16-lane group lists [16 groups][QT][k]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);
@@ -171,8 +180,9 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict_
       }
     if (gl == 0) {
       for (int q = 0; q < nqt; ++q) {
-        insert_key(mylist + q * k, k, make_key(acc[0][q], (unsigned)r));
-        if (has2) insert_key(mylist + q * k, k, make_key(acc[1][q], (unsigned)(r + 16)));
+        const u64 b = bound ? bound[q0 + q] : ~0ull;
+        insert_key(mylist + q * k, k, make_key_below(acc[0][q], (unsigned)r, b));
+        if (has2) insert_key(mylist + q * k, k, make_key_below(acc[1][q], (unsigned)(r + 16), b));
       }
     }
   }
@@ -209,14 +219,14 @@ static int dense_rows_per_wg(long long n) {
 
 template <bool F32>
 static hipError_t dense_launch_pass(const void* rows, long long n, int dim, const float* dq, int nq, int q0, int qt, int k,
-                                    u64* cand, int n_wg, hipStream_t st) {
+                                    u64* cand, int n_wg, hipStream_t st, const u64* bound) {
   static const bool strided = getenv("VRAG_TOPK_STRIDED") != nullptr;
   const int per = (strided && qt == 1) ? 0 : dense_rows_per_wg(n);
   const size_t lds = (size_t)qt * dim * sizeof(float) + (size_t)16 * qt * k * sizeof(u64);
   const int cstr = F32 ? 64 : 128;
   const int dimc = dim % cstr == 0 ? dim / cstr : -1;
 #define VRAG_DENSE_CASE(QT_, DC_)                                                                               \
-  hipLaunchKernelGGL((dense_topk_kernel<F32, QT_, DC_>), dim3(n_wg), dim3(256), lds, st, rows, n, dim, dq, nq, q0, k, cand, per)
+  hipLaunchKernelGGL((dense_topk_kernel<F32, QT_, DC_>), dim3(n_wg), dim3(256), lds, st, rows, n, dim, dq, nq, q0, k, cand, per, bound)
   if (qt == 1) {
     if (dimc == 6) VRAG_DENSE_CASE(1, 6);
     else if (dimc == 3) VRAG_DENSE_CASE(1, 3);
@@ -576,7 +586,8 @@ static int dense_n_wg(int dtype, int dim, int nq, int k, long long size) {
 
 // all passes of one search: query tiles of 4 (a final tile of 1 query uses the register path)
 static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int dim, const float* dq, int nq, int k,
-                                   u64* cand, int n_wg, hipStream_t st, u64* thr, u64* out) {
+                                   u64* cand, int n_wg, hipStream_t st, u64* thr, u64* out, const u64* bound = nullptr) {
+  if (bound && dense_use_mfma(dtype, dim, nq, k)) return hipErrorInvalidValue;   // pages run with k = KMAX: scalar path only
   if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
     static const int dbg_fill = getenv("VRAG_TOPK_DEBUG_NOINSERT") ? 0xff : 0;   // probe: reject every key
     hipError_t me = hipMemsetAsync(thr, dbg_fill, (size_t)nq * sizeof(u64), st);
@@ -637,8 +648,8 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
   }
   for (int q0 = 0; q0 < nq;) {
     const int qt = (nq - q0 == 1) ? 1 : DQT;
-    hipError_t e = dtype == 0 ? dense_launch_pass<false>(rows, n, dim, dq, nq, q0, qt, k, cand, n_wg, st)
-                              : dense_launch_pass<true>(rows, n, dim, dq, nq, q0, qt, k, cand, n_wg, st);
+    hipError_t e = dtype == 0 ? dense_launch_pass<false>(rows, n, dim, dq, nq, q0, qt, k, cand, n_wg, st, bound)
+                              : dense_launch_pass<true>(rows, n, dim, dq, nq, q0, qt, k, cand, n_wg, st, bound);
     if (e != hipSuccess) return e;
     q0 += qt;
   }
@@ -653,7 +664,8 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
                                                             const int* __restrict__ slice_len, int n_slices,
                                                             long long n_docs, const float* __restrict__ qdense, int vocab,
                                                             int nq, int q, int k, int slices_per_wg,
-                                                            u64* __restrict__ cand) {
+                                                            u64* __restrict__ cand, const unsigned* __restrict__ docid,
+                                                            const u64* __restrict__ bound) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: [16 waves][k] lists, then (LDSQ) the dense query vector
   u64* lists = reinterpret_cast<u64*>(smem);
@@ -696,7 +708,8 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
     for (; j < len; ++j) acc = __fmaf_rn(v[(size_t)j * 64], LDSQ ? sq[c[(size_t)j * 64]] : qv[c[(size_t)j * 64]], acc);
     const long long doc = (long long)s * 64 + lane;  // position in nnz-sorted order
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
-    const u64 key = hit ? make_key(acc, (unsigned)doc) : 0ull;
+    // the key carries the caller's document index (not the sorted position): ties order by id ascending
+    const u64 key = hit ? make_key_below(acc, docid[doc], bound ? bound[q] : ~0ull) : 0ull;
     // wave-level filtered insertion
     u64 kth = mylist[k - 1];
     unsigned long long m = __ballot(key > kth);
@@ -748,7 +761,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
                                                                  long long n_docs, const unsigned short* __restrict__ qmap,
                                                                  const float* __restrict__ qw, int vocab, int n_union,
                                                                  int nq, int q0, int k, int slices_per_wg,
-                                                                 u64* __restrict__ cand) {
+                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
@@ -798,10 +811,11 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
       for (int q = 0; q < QB; ++q) acc[q] = __fmaf_rn(v1, tw[q * SUW + uid1], acc[q]);
     }
     const long long doc = (long long)s * 64 + lane;
+    const unsigned did = doc < n_docs ? docid[doc] : 0u;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
-      const u64 key = hit ? make_key(acc[q], (unsigned)doc) : 0ull;
+      const u64 key = hit ? make_key(acc[q], did) : 0ull;
       u64* ml = mylists + q * k;
       const u64 kth = ml[k - 1];
       unsigned long long m = __ballot(key > kth);
@@ -970,8 +984,8 @@ struct vrag_dense_index {
   // scratch (grown on demand)
   float* d_q = nullptr;
   size_t d_q_elems = 0;
-  u64 *d_cand = nullptr, *d_out = nullptr;
-  size_t d_cand_elems = 0, d_out_elems = 0;
+  u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;   // d_bound: per-query page bound (k > KMAX)
+  size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
 };
 
 struct vrag_sparse_index {
@@ -982,13 +996,13 @@ struct vrag_sparse_index {
   float* vals = nullptr;
   long long* slice_off = nullptr;
   int* slice_len = nullptr;
-  std::vector<int64_t> perm;  // sorted position -> caller's document index
+  unsigned* d_docid = nullptr;  // [n_docs] sorted position -> caller's document index (the row field of a key)
   hipStream_t stream = nullptr;
   std::mutex mu;
   float* d_q = nullptr;
   size_t d_q_elems = 0;
-  u64 *d_cand = nullptr, *d_out = nullptr;
-  size_t d_cand_elems = 0, d_out_elems = 0;
+  u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;
+  size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
   unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
@@ -1030,6 +1044,32 @@ void decode_keys(const std::vector<u64>& keys, int nq, int k, int64_t base, cons
       ids[i] = perm ? perm[row] : base + row;
     }
   }
+}
+
+// k > KMAX: ceil(k / KMAX) passes of KMAX; `run_page(bound)` leaves the merged page keys [nq][KMAX] in d_out.
+// After each page the last key of a full page becomes that query's exclusive bound (0 = exhausted: nothing passes).
+template <typename RunPage>
+int paged_search(int nq, int k, u64** d_bound, size_t* d_bound_elems, const u64* d_out, hipStream_t st, RunPage run_page,
+                 float* scores, int64_t* ids) {
+  int rc;
+  if ((rc = grow(d_bound, d_bound_elems, (size_t)nq))) return rc;
+  std::vector<u64> bound((size_t)nq, ~0ull), page((size_t)nq * KMAX), all((size_t)nq * k, 0ull);
+  for (int k0 = 0; k0 < k; k0 += KMAX) {
+    HIP_TRY(hipMemcpyAsync(*d_bound, bound.data(), (size_t)nq * sizeof(u64), hipMemcpyHostToDevice, st));
+    if ((rc = run_page(*d_bound))) return rc;
+    HIP_TRY(hipMemcpyAsync(page.data(), d_out, page.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    bool more = false;
+    for (int q = 0; q < nq; ++q) {
+      const int take = std::min(KMAX, k - k0);
+      for (int j = 0; j < take; ++j) all[(size_t)q * k + k0 + j] = page[(size_t)q * KMAX + j];
+      bound[q] = page[(size_t)q * KMAX + KMAX - 1];   // 0 when the page was not full
+      more = more || bound[q] != 0ull;
+    }
+    if (!more) break;
+  }
+  decode_keys(all, nq, k, 0, nullptr, scores, ids);
+  return VRAG_OK;
 }
 
 }  // namespace
@@ -1079,6 +1119,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_q) (void)hipFree(ix->d_q);
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
+  if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -1115,10 +1156,33 @@ int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
 int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t nq, int32_t k, float* scores,
                             int64_t* ids, void* stream) {
   ARG_CHECK(ix && queries && scores && ids && nq > 0, "bad arguments");
-  ARG_CHECK(k > 0 && k <= KMAX, "k must be in [1, %d] (got %d)", KMAX, k);
+  ARG_CHECK(k > 0 && k <= KPAGED_MAX, "k must be in [1, %d] (got %d)", KPAGED_MAX, k);
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  if (k > KMAX) {   // pages of KMAX on the scalar kernels (fp32 queries; the matrix-core paths stop at k = 16)
+    const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, KMAX, ix->size);
+    int rc;
+    if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
+    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * KMAX))) return rc;
+    if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * KMAX + nq))) return rc;
+    ARG_CHECK((size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * KMAX * sizeof(u64) <= 160 * 1024,
+              "dim too large for the LDS budget");
+    HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, st));
+    if (ix->size == 0) {
+      for (size_t i = 0; i < (size_t)nq * k; ++i) {
+        scores[i] = -INFINITY;
+        ids[i] = -1;
+      }
+      return VRAG_OK;
+    }
+    return paged_search(nq, k, &ix->d_bound, &ix->d_bound_elems, ix->d_out, st, [&](const u64* bound) -> int {
+      HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, KMAX, ix->d_cand, n_wg, st,
+                               ix->d_out + (size_t)nq * KMAX, ix->d_out, bound));
+      HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, KMAX, ix->d_out, st));
+      return VRAG_OK;
+    }, scores, ids);
+  }
   const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
   int rc;
   if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
@@ -1214,8 +1278,11 @@ int vrag_sparse_index_create(int32_t vocab, int64_t n_docs, const int64_t* indpt
   ix->nnz = nnz;
   ix->padded = (int64_t)padded;
   ix->n_slices = n_slices;
-  ix->perm = std::move(perm);
+  std::vector<unsigned> docid(std::max<size_t>(1, (size_t)n_docs));
+  for (int64_t p = 0; p < n_docs; ++p) docid[p] = (unsigned)perm[p];
   hipError_t e = hipMalloc((void**)&ix->cols, cols.size() * sizeof(unsigned short));
+  if (e == hipSuccess) e = hipMalloc((void**)&ix->d_docid, docid.size() * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemcpy(ix->d_docid, docid.data(), docid.size() * sizeof(unsigned), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&ix->vals, vals.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&ix->slice_off, off.size() * sizeof(long long));
   if (e == hipSuccess) e = hipMalloc((void**)&ix->slice_len, std::max<size_t>(1, len.size()) * sizeof(int));
@@ -1246,6 +1313,8 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_qw) (void)hipFree(ix->d_qw);
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
+  if (ix->d_bound) (void)hipFree(ix->d_bound);
+  if (ix->d_docid) (void)hipFree(ix->d_docid);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -1269,7 +1338,7 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
 
 constexpr int SQB = 8;   // queries per pass of the batched sparse kernel (16 when the tables fit the LDS and nq >= 16)
 
-static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out) {
+static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out, const u64* bound = nullptr) {
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   *n_wg_out = n_wg;
@@ -1289,11 +1358,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
       if (QB == 16)
         hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
       else
         hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
@@ -1314,11 +1383,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     if (ldsq)
       hipLaunchKernelGGL((sparse_topk_kernel<true>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                          ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_q, ix->vocab, nq, q, k,
-                         slices_per_wg, ix->d_cand);
+                         slices_per_wg, ix->d_cand, ix->d_docid, bound);
     else
       hipLaunchKernelGGL((sparse_topk_kernel<false>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals,
                          ix->slice_off, ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_q, ix->vocab, nq, q, k,
-                         slices_per_wg, ix->d_cand);
+                         slices_per_wg, ix->d_cand, ix->d_docid, bound);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
@@ -1329,13 +1398,30 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
 int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
                              const float* q_values, int32_t nq, int32_t k, float* scores, int64_t* ids, void* stream) {
   ARG_CHECK(ix && q_indptr && scores && ids && nq > 0, "bad arguments");
-  ARG_CHECK(k > 0 && k <= KMAX, "k must be in [1, %d] (got %d)", KMAX, k);
+  ARG_CHECK(k > 0 && k <= KPAGED_MAX, "k must be in [1, %d] (got %d)", KPAGED_MAX, k);
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   int rc;
+  if (k > KMAX) {   // pages of KMAX on the single-query kernel
+    for (int q = 0; q < nq; ++q)
+      for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
+        ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);
+    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * KMAX))) return rc;
+    if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * KMAX))) return rc;
+    std::vector<float> qd((size_t)nq * ix->vocab, 0.f);
+    for (int q = 0; q < nq; ++q)
+      for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) qd[(size_t)q * ix->vocab + q_indices[j]] = q_values[j];
+    if ((rc = grow(&ix->d_q, &ix->d_q_elems, qd.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_q, qd.data(), qd.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    ix->last_multi = false;
+    return paged_search(nq, k, &ix->d_bound, &ix->d_bound_elems, ix->d_out, st, [&](const u64* bound) -> int {
+      int nwg = 0;
+      return sparse_launch(ix, nq, KMAX, st, &nwg, bound);
+    }, scores, ids);   // the first page's stream sync also keeps `qd` alive until its upload has been consumed
+  }
   if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
   if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k))) return rc;
   // Batched path: two or more queries; per pass of SQB queries the union of their terms gets ids 1 .. SUW-1, the
@@ -1398,7 +1484,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
     std::vector<u64> keys2((size_t)nq * k);
     HIP_TRY(hipMemcpyAsync(keys2.data(), ix->d_out, keys2.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));   // also keeps the host tables alive until the uploads have been consumed
-    decode_keys(keys2, nq, k, 0, ix->perm.data(), scores, ids);
+    decode_keys(keys2, nq, k, 0, nullptr, scores, ids);
     return VRAG_OK;
   }
   std::vector<float> dense((size_t)nq * ix->vocab, 0.f);
@@ -1411,7 +1497,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
   std::vector<u64> keys((size_t)nq * k);
   HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  decode_keys(keys, nq, k, 0, ix->perm.data(), scores, ids);
+  decode_keys(keys, nq, k, 0, nullptr, scores, ids);
   return VRAG_OK;
 }
 

@@ -383,6 +383,7 @@ class GpuVectorStore(VectorStore):
         self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
 
     SUBSET_CACHE = 4
+    K_LIMIT = 1024   # vrag_*_index_search: lists of up to 64 per device pass, longer ones as exact pages of 64
 
     # -------------------------------------------------------------- ingest
     def add_vectors(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
@@ -495,14 +496,14 @@ class GpuVectorStore(VectorStore):
         self._masks.clear()
 
     def _search_batch(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> List[List[dict]]:
-        """Best `limit` (<= 64) rows per query among the rows that pass `mask`, one device pass for the whole batch
+        """Best `limit` (<= 1024) rows per query among the rows that pass `mask`, one device pass for the whole batch
         over the full shard; queries that come up short because filtered / deleted rows took their slots (and every
         query when the filter passes under 1/8 of the rows) get a second pass over the masked subset shard."""
         self._flush()
         n = len(self._ids)
         if n == 0 or len(queries) == 0:
             return [[] for _ in queries]
-        k = min(64, limit)
+        k = min(self.K_LIMIT, limit)
         n_pass = n if mask is None else int(mask.sum())
         if n_pass == 0:
             return [[] for _ in queries]

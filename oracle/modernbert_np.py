@@ -28,8 +28,8 @@ All arithmetic is fp32 (numpy float32), matching the reference's CPU default.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 

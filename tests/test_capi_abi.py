@@ -39,8 +39,6 @@ def test_no_cpu_fallback_without_gpu():
     lib = _lib.load()
     if lib.vrag_device_count() > 0:
         pytest.skip("GPU present")
-    import numpy as np
-
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
     from verbatim_rag_amd.vector_stores import DenseShard, GpuVectorStore
 

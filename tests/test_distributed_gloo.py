@@ -3,7 +3,6 @@ import os
 import sys
 
 import numpy as np
-import pytest
 
 import verbatim_rag_amd  # noqa: F401
 from verbatim_rag_amd.distributed import merge_topk, shard_range

@@ -127,7 +127,6 @@ def main():
     torch.cuda.synchronize()
     total = time.perf_counter() - a
     n_pairs = int((ids >= 0).sum())
-    n_tokens_est = sum(len(v) for v in ext._chunk_cache.values())  # noqa: F841
     print(json.dumps({
         "workload": f"sparse index {n} docs ({int(indptr[-1])} nnz, vocab {V})" + (f" + dense {n} x 768 bf16, RRF of top-{2 * args.k} per method" if args.hybrid else "")
                     + f" + top-{args.k} + span extraction (ModernBERT-{args.model}), {Q} queries",

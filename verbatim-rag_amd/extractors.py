@@ -205,7 +205,7 @@ class GpuModelSpanExtractor(SpanExtractor):
         return GpuModelSpanExtractor._FORMAT_QA_MODEL
 
     def _build_engine(self, model_path: str, dev: int):
-        from .engine import EncoderEngine, strip_prefix
+        from .engine import EncoderEngine
         from .weights import load_safetensors_dir
 
         shape, tensors, _cfg = load_safetensors_dir(model_path)

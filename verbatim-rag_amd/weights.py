@@ -6,7 +6,7 @@ from __future__ import annotations
 import json
 import math
 import os
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(uns
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
 template <int EPI, int MI, int WROWS>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][MI], char* smem, int wave, int lane,
-                                              int mw, int nw, int n0, bool v_block) {
+                                              int mw, int nw, bool v_block) {
   const int hi = lane >> 5, l31 = lane & 31;
   // ------------------------------------------------------------------ epilogues
   // All operand-tile reads are done (the loop ends with a barrier), so the LDS is reused as a
@@ -366,7 +366,6 @@ template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
   static_assert(NS == 2 || NS == 4, "LDS stages");
-  constexpr int NT = WM * WN * 64;            // threads
   constexpr int MI = BM / WM / 32;            // 32-row accumulator tiles per wave
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
   constexpr int A_INSTR = BM / 8 / (WM * WN); // LDS-DMA instructions per wave per stage (8 rows each)
@@ -539,7 +538,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<EPI, MI, WROWS>(p, acc, smem, wave, lane, mw, nw, n0, v_block);
+  gemm_epilogue<EPI, MI, WROWS>(p, acc, smem, wave, lane, mw, nw, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
   }  // tile loop
 }

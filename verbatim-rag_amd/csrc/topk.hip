@@ -1216,7 +1216,6 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
   const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
   ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k + nq, "scratch too small");
-  const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
   HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
                              ix->d_out + (size_t)nq * k, ix->d_out));
   HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));

@@ -111,3 +111,22 @@ def test_dicts_to_csr_equals_the_per_entry_loop():
         assert weights[a:b].tolist() == [float(np.float32(v)) for _, v in want]
     e = vs.dicts_to_csr([])
     assert e[0].tolist() == [0] and len(e[1]) == 0 and len(e[2]) == 0
+
+
+def test_single_comparison_filters_use_the_value_index(store):
+    st, dense, sparse, rng = store
+    q = dense[5].tolist()
+    for flt in ('metadata["document_id"] == "d2"', 'document_id == "d2"', 'metadata["n"] in [7, 8, 300]', 'metadata["n"] == 399',
+                'metadata["missing"] == "None"', 'metadata["document_id"] == "nope"'):
+        pred = vs.parse_filter(flt)
+        assert hasattr(pred, "lookup")
+        want = np.asarray([bool(pred(md)) for md in st._meta])
+        got = st._mask(flt)
+        assert np.array_equal(np.ones(len(want), bool) if got is None else got, want), flt
+        r = st.query(dense_query=q, top_k=5, search_type="dense", filter=flt)
+        assert len(r) == min(5, int(want.sum())) and all(pred(x.metadata) for x in r)
+    for flt in ('metadata["document_id"] != "d2"', 'not (document_id == "d2")', 'document_id == "d1" or n == 5'):
+        assert not hasattr(vs.parse_filter(flt), "lookup")       # general predicates keep the per-row evaluation
+    assert "document_id" in st._value_indexes
+    st.add_vectors(["new"], [dense[0].tolist()], [sparse[0]], ["t"], ["e"], [{"document_id": "d2", "n": 1000}])
+    assert st._value_indexes == {} and st._mask('metadata["n"] == 1000').sum() == 1

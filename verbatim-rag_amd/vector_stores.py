@@ -316,7 +316,11 @@ def parse_filter(expr: str):
         op = take("op")
         if op in ("==", "!="):
             val = take("val")
-            return (lambda md: str(md.get(key)) == val) if op == "==" else (lambda md: str(md.get(key)) != val)
+            if op == "!=":
+                return lambda md: str(md.get(key)) != val
+            f = lambda md: str(md.get(key)) == val   # noqa: E731
+            f.lookup = (key, [val])                  # lets the store answer from a per-key value index
+            return f
         if op == "in":
             take("op", "[")
             vals = [take("val")]
@@ -325,7 +329,9 @@ def parse_filter(expr: str):
                 vals.append(take("val"))
             take("op", "]")
             vs = set(vals)
-            return lambda md: str(md.get(key)) in vs
+            f = lambda md: str(md.get(key)) in vs    # noqa: E731
+            f.lookup = (key, vals)
+            return f
         raise ValueError(f"GpuVectorStore: unsupported operator {op!r} in filter {expr!r}")
 
     def conjunction():
@@ -380,6 +386,7 @@ class GpuVectorStore(VectorStore):
         self._sparse: Optional[SparseShard] = None
         self._dirty = False
         self._masks: Dict[str, Optional[np.ndarray]] = {}
+        self._value_indexes: Dict[str, Dict[str, np.ndarray]] = {}
         self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
 
     SUBSET_CACHE = 4
@@ -405,6 +412,7 @@ class GpuVectorStore(VectorStore):
                 self._sparse_rows.append({int(k): float(v) for k, v in sparse_vectors[i].items()})
         self._dirty = True
         self._drop_subsets()
+        self._value_indexes.clear()
 
     def delete(self, ids: List[str]):
         kill = set(ids)
@@ -438,11 +446,32 @@ class GpuVectorStore(VectorStore):
             alive = np.asarray(self._alive, dtype=bool)
             if filter:
                 pred = parse_filter(filter)
-                alive = alive & np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
+                lookup = getattr(pred, "lookup", None)
+                if lookup is not None:      # one `==` / `in` comparison (the reference's document_id filter, index.py:735-739)
+                    index = self._value_index(lookup[0])
+                    passing = np.zeros(len(self._meta), dtype=bool)
+                    for v in lookup[1]:
+                        rows = index.get(v)
+                        if rows is not None:
+                            passing[rows] = True
+                    alive = alive & passing
+                else:
+                    alive = alive & np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
             if len(self._masks) >= 64:
                 self._masks.clear()
             self._masks[key] = None if alive.all() else alive
         return self._masks[key]
+
+    def _value_index(self, key: str) -> Dict[str, np.ndarray]:
+        """str(metadata[key]) -> rows, built once per key until the next insert: a per-document filter then costs its
+        matches, not a Python predicate call per stored row."""
+        index = self._value_indexes.get(key)
+        if index is None:
+            buckets: Dict[str, List[int]] = {}
+            for i, md in enumerate(self._meta):
+                buckets.setdefault(str(md.get(key)), []).append(i)
+            index = self._value_indexes[key] = {v: np.asarray(rows, dtype=np.int64) for v, rows in buckets.items()}
+        return index
 
     def _hit(self, row: int, score: float) -> dict:
         """A search hit in the shape `merge_hybrid_results` works on; the entity (text, metadata copy) is attached

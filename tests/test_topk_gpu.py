@@ -322,3 +322,58 @@ def test_store_returns_more_than_64_hits():
     rs, ri = T.dense_topk(dense[odd], dense[3:4], 100)
     assert [x.id for x in r] == [f"id{odd[j]}" for j in ri[0]]
     st._dense.close()
+
+
+def test_sparse_edges_max_vocab_empty_queries_and_bad_terms():
+    """u16 term ids: the largest vocabulary is 65 536 (term 65 535 usable); the batched kernel needs vocab <= 65 535
+    and hands such a shard to the single-query kernel.  Queries without terms / without matches give -1 rows."""
+    from verbatim_rag_amd._lib import VragError
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    V = 65536
+    indptr = [0, 2, 3, 3, 5]                              # doc 2 is empty
+    idx = [0, 65535, 65535, 7, 65535]
+    val = [1.0, 2.0, 0.5, 1.0, 0.25]
+    sh = SparseShard(V, indptr, idx, val)
+    try:
+        s, i = sh.search([{65535: 2.0}, {}, {12345: 1.0}, {0: 1.0, 7: 3.0}], 4)
+        rs, ri = T.sparse_topk(np.asarray(indptr), np.asarray(idx, np.int32), np.asarray(val, np.float32), V,
+                               np.asarray([0, 1, 1, 2, 4]), np.asarray([65535, 12345, 0, 7], np.int32),
+                               np.asarray([2.0, 1.0, 1.0, 3.0], np.float32), 4)
+        assert np.array_equal(i, ri) and np.array_equal(s, rs)
+        assert i[0].tolist() == [0, 1, 3, -1] and i[1].tolist() == [-1] * 4 and i[2].tolist() == [-1] * 4 and i[3].tolist() == [3, 0, -1, -1]
+        with pytest.raises(VragError):
+            sh.search([{65536: 1.0}], 1)
+        with pytest.raises(VragError):
+            sh.search([{-1: 1.0}], 1)
+    finally:
+        sh.close()
+    with pytest.raises(VragError):
+        SparseShard(V + 1, [0, 1], [0], [1.0])
+    with pytest.raises(VragError):
+        SparseShard(100, [0, 1], [100], [1.0])            # document term outside the vocabulary
+
+
+def test_dense_edges_dim_limits_and_capacity():
+    from verbatim_rag_amd._lib import VragError
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(4)
+    for dim, dtype in ((8, "f32"), (8, "bf16"), (4096, "bf16")):
+        X, Q = _dyadic(rng, (70, dim)), _dyadic(rng, (3, dim))
+        sh = DenseShard(dim, 70, dtype)
+        sh.add(X[:33])
+        sh.add(X[33:])                                     # incremental adds
+        s, i = sh.search(Q, 7)
+        rs, ri = T.dense_topk(X, Q, 7)
+        assert np.array_equal(i, ri) and np.array_equal(s, rs), (dim, dtype)
+        with pytest.raises(VragError):
+            sh.add(X[:1])                                  # beyond capacity
+        sh.close()
+    for bad in (12, 0, 4104):
+        with pytest.raises(VragError):
+            DenseShard(bad, 10, "bf16")
+    sh = DenseShard(64, 10, "bf16")                        # empty shard: every slot is a miss
+    s, i = sh.search(_dyadic(rng, (2, 64)), 3)
+    sh.close()
+    assert (i == -1).all() and np.isneginf(s).all()

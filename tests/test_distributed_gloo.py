@@ -42,7 +42,26 @@ def _worker(rank, world, port, q):
     st = ShardedTopK(lambda qs, k: T.dense_topk(X[lo:hi], qs, k), shard_base=lo)
     s, i = st.search(Q, 7)
     rs, ri = T.dense_topk(X, Q, 7)
-    q.put((rank, bool(np.array_equal(i, ri) and np.array_equal(s, rs))))
+    ok = bool(np.array_equal(i, ri) and np.array_equal(s, rs))
+    # sparse rows sharded the same way; query 1 matches a single document (one shard returns only -1 rows), k = 70
+    # exceeds one device pass and most queries' hit counts
+    V, n = 200, 1501
+    lens = rng.integers(1, 6, n)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.concatenate([np.sort(rng.choice(V - 1, int(m), replace=False)) for m in lens]).astype(np.int32)
+    val = (rng.integers(1, 5, len(idx)) / 4).astype(np.float32)
+    idx[indptr[1400]] = V - 1                                   # the only document with term V-1
+    qp = np.asarray([0, 3, 4, 6], np.int64)
+    qi = np.asarray([3, 50, 120, V - 1, 7, 9], np.int32)
+    qv = np.asarray([1.0, 0.5, 2.0, 1.0, 0.25, 1.5], np.float32)
+    lo, hi = shard_range(n, rank, world)
+    sub = (indptr[lo:hi + 1] - indptr[lo], idx[indptr[lo]:indptr[hi]], val[indptr[lo]:indptr[hi]])
+    sp = ShardedTopK(lambda qs, k: T.sparse_topk(*sub, V, *qs, k), shard_base=lo)
+    for k in (5, 70):
+        s2, i2 = sp.search((qp, qi, qv), k)
+        rs2, ri2 = T.sparse_topk(indptr, idx, val, V, qp, qi, qv, k)
+        ok = ok and bool(np.array_equal(i2, ri2) and np.array_equal(s2, rs2)) and i2[1, 0] == 1400 and (i2[1, 1:] == -1).all()
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 

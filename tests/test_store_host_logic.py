@@ -130,3 +130,50 @@ def test_single_comparison_filters_use_the_value_index(store):
     assert "document_id" in st._value_indexes
     st.add_vectors(["new"], [dense[0].tolist()], [sparse[0]], ["t"], ["e"], [{"document_id": "d2", "n": 1000}])
     assert st._value_indexes == {} and st._mask('metadata["n"] == 1000').sum() == 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rrf_merge_rows_equals_the_per_query_restatement(seed):
+    """Batch RRF on row numbers vs `merge_hybrid_results` (itself pinned to the reference's hybrid_search.py by
+    test_host_parity.py): overlapping lists, -1 tails, equal contributions (ties keep first-seen order), unequal
+    weights, one method alone."""
+    rng = np.random.default_rng(seed)
+    Q, L1, L2, top_k = 40, int(rng.integers(1, 12)), int(rng.integers(1, 12)), int(rng.integers(1, 14))
+    universe = 18                                   # small id universe -> many overlaps
+
+    def lists(L):
+        out = np.full((Q, L), -1, np.int64)
+        for q in range(Q):
+            m = int(rng.integers(0, L + 1))
+            out[q, :m] = rng.choice(universe, size=m, replace=False)
+        return out
+
+    a, b = lists(L1), lists(L2)
+    for weights in ({"dense": 0.5, "sparse": 0.5}, {"dense": 0.7, "sparse": 0.3}, {"dense": 2.0, "sparse": 1.0, "full_text": 5.0}):
+        for rrf_k in (60, 1):
+            rows, dist = vs.rrf_merge_rows({"dense": a, "sparse": b}, top_k, weights, rrf_k)
+            assert rows.shape == dist.shape == (Q, top_k)
+            for q in range(Q):
+                rbm = {"dense": [{"id": f"r{r}", "n": int(r)} for r in a[q] if r >= 0],
+                       "sparse": [{"id": f"r{r}", "n": int(r)} for r in b[q] if r >= 0]}
+                want = vs.merge_hybrid_results(rbm, top_k, weights, rrf_k)
+                got = [(int(r), float(d)) for r, d in zip(rows[q], dist[q]) if r >= 0]
+                assert got == [(h["n"], h["distance"]) for h in want], (q, weights, rrf_k)
+    rows, dist = vs.rrf_merge_rows({"sparse": b}, top_k, {"sparse": 1.0}, 60)
+    for q in range(Q):
+        want = vs.merge_hybrid_results({"sparse": [{"id": f"r{r}", "n": int(r)} for r in b[q] if r >= 0]}, top_k, {"sparse": 1.0}, 60)
+        assert [(int(r), float(d)) for r, d in zip(rows[q], dist[q]) if r >= 0] == [(h["n"], h["distance"]) for h in want]
+
+
+def test_query_normalisation_is_the_same_row_by_row_or_batched(store):
+    st, dense, sparse, rng = store
+    seen = []
+    st._flush()
+    st._dense.search = lambda q, k, stream=None: (seen.append(np.array(q)), (np.zeros((len(q), k), np.float32), np.full((len(q), k), -1, np.int64)))[1]
+    X = rng.standard_normal((50, 64)).astype(np.float32) * np.float32(3)
+    X[7] = 0
+    st._device_topk("dense", st._dense, X.tolist(), 3)
+    for i in range(len(X)):
+        st._device_topk("dense", st._dense, [X[i].tolist()], 3)
+    want = np.stack([q / float(np.sqrt((q * q).sum(dtype=np.float32))) if q.any() else q for q in X])
+    assert np.array_equal(seen[0], want) and all(np.array_equal(seen[1 + i][0], want[i]) for i in range(len(X)))

@@ -52,7 +52,7 @@ def main():
     import verbatim_rag_amd  # noqa: F401
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
     from verbatim_rag_amd.extractors import GpuModelSpanExtractor
-    from verbatim_rag_amd.vector_stores import DenseShard, SparseShard, merge_hybrid_results
+    from verbatim_rag_amd.vector_stores import DenseShard, SparseShard, rrf_merge_rows
     from verbatim_rag_amd.weights import random_init, random_qa_head
 
     rng = np.random.default_rng(1234)
@@ -99,14 +99,10 @@ def main():
         a = time.perf_counter()
         if dense is None:
             scores, ids = shard.search(queries, args.k)
-        else:   # milvus_base.py:264-295: top-2k per method, equal-weight RRF (hybrid_search.py:73-129) on the host
+        else:   # milvus_base.py:264-295: top-2k per method, equal-weight RRF (hybrid_search.py:73-129) on the host, whole batch at once
             _ss, si = shard.search(queries, 2 * args.k)
             _ds, di = dense.search(dense_queries, 2 * args.k)
-            ids = np.full((Q, args.k), -1, np.int64)
-            for qi in range(Q):
-                rbm = {"dense": [{"id": int(r) + 1} for r in di[qi] if r >= 0], "sparse": [{"id": int(r) + 1} for r in si[qi] if r >= 0]}
-                for j, h in enumerate(merge_hybrid_results(rbm, args.k, {"dense": 0.5, "sparse": 0.5})):
-                    ids[qi, j] = h["id"] - 1                      # ids are offset by 1: the merge skips falsy ids
+            ids, _dist = rrf_merge_rows({"dense": di, "sparse": si}, args.k, {"dense": 0.5, "sparse": 0.5})
         t["search_s"] = time.perf_counter() - a
         a = time.perf_counter()
         results = [[types.SimpleNamespace(text=pool[int(i) % len(pool)]) for i in row if i >= 0] for row in ids]

@@ -127,6 +127,43 @@ def merge_hybrid_results(results_by_method: Dict[str, List[dict]], top_k: int, w
     return merged
 
 
+def rrf_merge_rows(rows_by_method: Dict[str, np.ndarray], top_k: int, weights: Dict[str, float],
+                   rrf_k: int = 60) -> Tuple[np.ndarray, np.ndarray]:
+    """`merge_hybrid_results` for a whole batch of queries on row numbers: `rows_by_method[m]` is `[Q, L]` ranked rows
+    (-1 = no hit, only as a tail) of at most two methods, in the methods' insertion order.  Returns `rows [Q, top_k]`
+    (-1 padded) and `distance [Q, top_k]` (float64, `1 - score`).  Same arithmetic in the same order as the per-query
+    routine -- `score = 0.0 + w_first / (rrf_k + rank + 1) (+ w_second / ...)` in float64, stable descending sort, so
+    equal scores keep first-seen order -- which `tests/test_store_host_logic.py` checks element for element."""
+    methods = list(rows_by_method)
+    if not 1 <= len(methods) <= 2:
+        raise ValueError("rrf_merge_rows merges one or two methods")
+    nw = normalize_weights({m: None for m in methods}, weights)
+    first = np.asarray(rows_by_method[methods[0]], dtype=np.int64)
+    Q, L1 = first.shape
+    contrib1 = nw.get(methods[0], 0.0) * (1.0 / (rrf_k + np.arange(L1, dtype=np.float64) + 1))
+    score1 = np.broadcast_to(0.0 + contrib1, (Q, L1)).copy()
+    if len(methods) == 1:
+        cand_rows, cand_score = first, score1
+    else:
+        second = np.asarray(rows_by_method[methods[1]], dtype=np.int64)
+        L2 = second.shape[1]
+        contrib2 = nw.get(methods[1], 0.0) * (1.0 / (rrf_k + np.arange(L2, dtype=np.float64) + 1))
+        same = (first[:, :, None] == second[:, None, :]) & (first[:, :, None] >= 0)          # [Q, L1, L2]: at most one per row / column
+        score1 += (same * contrib2[None, None, :]).sum(axis=2)                             # a + b (one non-zero term) or a + 0.0
+        only2 = ~same.any(axis=1)                                                            # second-method rows not seen before
+        cand_rows = np.concatenate([first, np.where(only2, second, -1)], axis=1)
+        cand_score = np.concatenate([score1, np.broadcast_to(0.0 + contrib2, (Q, L2))], axis=1)
+    key = np.where(cand_rows >= 0, -cand_score, np.inf)
+    order = np.argsort(key, axis=1, kind="stable")[:, :top_k]
+    rows = np.take_along_axis(cand_rows, order, axis=1)
+    dist = 1.0 - np.take_along_axis(cand_score, order, axis=1)
+    if rows.shape[1] < top_k:
+        pad = top_k - rows.shape[1]
+        rows = np.pad(rows, ((0, 0), (0, pad)), constant_values=-1)
+        dist = np.pad(dist, ((0, 0), (0, pad)))
+    return rows, dist
+
+
 def convert_hits_to_results(hits: List[dict], dynamic_fields: Optional[List[str]] = None) -> List[SearchResult]:
     """hybrid_search.py:132-175."""
     dynamic_fields = dynamic_fields or []
@@ -387,6 +424,7 @@ class GpuVectorStore(VectorStore):
         self._dirty = False
         self._masks: Dict[str, Optional[np.ndarray]] = {}
         self._value_indexes: Dict[str, Dict[str, np.ndarray]] = {}
+        self._all_ids_truthy: Optional[bool] = None
         self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
 
     SUBSET_CACHE = 4
@@ -413,6 +451,7 @@ class GpuVectorStore(VectorStore):
         self._dirty = True
         self._drop_subsets()
         self._value_indexes.clear()
+        self._all_ids_truthy = None
 
     def delete(self, ids: List[str]):
         kill = set(ids)
@@ -490,13 +529,10 @@ class GpuVectorStore(VectorStore):
         return self._search_batch(kind, [query], limit, mask)[0]
 
     def _device_topk(self, kind: str, shard, queries: Sequence[Any], k: int):
-        if kind == "dense":
-            rows_q = np.empty((len(queries), self.dense_dim), np.float32)
-            for i, query in enumerate(queries):
-                q = np.asarray(query, dtype=np.float32)
-                nq = float(np.sqrt((q * q).sum(dtype=np.float32)))
-                rows_q[i] = q / nq if nq > 0 else q
-            return shard.search(rows_q, k)
+        if kind == "dense":   # COSINE: unit queries against the unit rows (fp32 norm, one row at a time or all at once: same bits)
+            rows_q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(len(queries), self.dense_dim))
+            norms = np.sqrt((rows_q * rows_q).sum(axis=1, dtype=np.float32))
+            return shard.search(rows_q / np.where(norms > 0, norms, np.float32(1.0))[:, None], k)
         return shard.search(queries, k)       # dicts_to_csr converts keys / weights to int32 / float32
 
     def _subset(self, kind: str, mask: np.ndarray):
@@ -524,35 +560,74 @@ class GpuVectorStore(VectorStore):
         self._subsets.clear()
         self._masks.clear()
 
-    def _search_batch(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> List[List[dict]]:
-        """Best `limit` (<= 1024) rows per query among the rows that pass `mask`, one device pass for the whole batch
-        over the full shard; queries that come up short because filtered / deleted rows took their slots (and every
-        query when the filter passes under 1/8 of the rows) get a second pass over the masked subset shard."""
+    def _topk_rows(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+        """Best `limit` (<= 1024) rows per query among the rows that pass `mask`: `rows [Q, limit]` (-1 = no hit, tail
+        only) and their fp32 scores.  One device pass for the whole batch over the full shard; queries that come up
+        short because filtered / deleted rows took their slots (and every query when the filter passes under 1/8 of
+        the rows) get a second pass over the masked subset shard."""
         self._flush()
-        n = len(self._ids)
-        if n == 0 or len(queries) == 0:
-            return [[] for _ in queries]
+        n, Q = len(self._ids), len(queries)
+        rows_out = np.full((Q, limit), -1, np.int64)
+        score_out = np.zeros((Q, limit), np.float32)
         k = min(self.K_LIMIT, limit)
         n_pass = n if mask is None else int(mask.sum())
-        if n_pass == 0:
-            return [[] for _ in queries]
+        if n == 0 or Q == 0 or n_pass == 0:
+            return rows_out, score_out
         want = min(k, n_pass)
-        out: List[Optional[List[dict]]] = [None] * len(queries)
+        short = np.ones(Q, dtype=bool)
         if mask is None or n_pass * 8 >= n:
             scores, rows = self._device_topk(kind, self._dense if kind == "dense" else self._sparse, queries, k)
-            for i in range(len(queries)):
-                hits = [(int(r), float(s)) for r, s in zip(rows[i], scores[i]) if r >= 0 and (mask is None or mask[r])]
-                # a sparse query can have fewer than `want` rows sharing a term: then the full pass, which returned
-                # fewer than k candidates, has already seen every match
-                if len(hits) >= want or mask is None or int((rows[i] >= 0).sum()) < k:
-                    out[i] = [self._hit(r, s) for r, s in hits[:limit]]
-        short = [i for i, o in enumerate(out) if o is None]
-        if short:
+            found = rows >= 0
+            valid = found if mask is None else found & mask[np.where(found, rows, 0)]
+            count = valid.sum(axis=1)
+            # a sparse query can have fewer than `want` rows sharing a term: then the full pass, which returned fewer
+            # than k candidates, has already seen every match
+            done = (count >= want) | (found.sum(axis=1) < k) if mask is not None else np.ones(Q, dtype=bool)
+            order = np.argsort(~valid, axis=1, kind="stable")                   # passing hits first, ranking kept
+            rows_c = np.take_along_axis(rows, order, axis=1)
+            scores_c = np.take_along_axis(scores, order, axis=1)
+            rows_c[np.arange(k)[None, :] >= count[:, None]] = -1
+            rows_out[done, :k] = rows_c[done]
+            score_out[done, :k] = scores_c[done]
+            short = ~done
+        if short.any():
             shard, idx = self._subset(kind, mask)
-            scores, rows = self._device_topk(kind, shard, [queries[i] for i in short], want)
-            for j, i in enumerate(short):
-                out[i] = [self._hit(int(idx[r]), float(s)) for r, s in zip(rows[j], scores[j]) if r >= 0][:limit]
+            which = np.nonzero(short)[0]
+            scores, rows = self._device_topk(kind, shard, [queries[i] for i in which], want)
+            found = rows >= 0
+            rows_out[which, :want] = np.where(found, idx[np.where(found, rows, 0)], -1)
+            score_out[which, :want] = scores
+        return rows_out, score_out
+
+    def _search_batch(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> List[List[dict]]:
+        rows, scores = self._topk_rows(kind, queries, limit, mask)
+        return [[self._hit(int(r), float(v)) for r, v in zip(rows[i], scores[i]) if r >= 0] for i in range(len(queries))]
+
+    def _results_rows(self, rows: np.ndarray, distances: np.ndarray) -> List[SearchResult]:
+        return self._results([{"id": self._ids[r], "distance": float(d), "_row": int(r)} for r, d in zip(rows, distances) if r >= 0])
+
+    RRF_VECTOR_MAX = 64   # candidate lists up to this long are merged for the whole batch at once (an [Q, L, L] compare)
+
+    def _hybrid_batch(self, dq, sq, top_k, mask, weights, rrf_k) -> List[List[SearchResult]]:
+        """Both methods for all queries, then weighted RRF: vectorised over the batch, or the per-query restatement of
+        hybrid_search.py when the lists are long or an id is falsy (`merge_hybrid_results` skips such hits)."""
+        limit = top_k * 2
+        rows_d, sc_d = self._topk_rows("dense", dq, limit, mask)
+        rows_s, sc_s = self._topk_rows("sparse", sq, limit, mask)
+        if limit <= self.RRF_VECTOR_MAX and self._ids_truthy():
+            rows, dist = rrf_merge_rows({"dense": rows_d, "sparse": rows_s}, top_k, weights, rrf_k)
+            return [self._results_rows(rows[i], dist[i]) for i in range(len(dq))]
+        out = []
+        for i in range(len(dq)):
+            rbm = {"dense": [self._hit(int(r), float(v)) for r, v in zip(rows_d[i], sc_d[i]) if r >= 0],
+                   "sparse": [self._hit(int(r), float(v)) for r, v in zip(rows_s[i], sc_s[i]) if r >= 0]}
+            out.append(self._results(merge_hybrid_results(rbm, top_k, weights, rrf_k)))
         return out
+
+    def _ids_truthy(self) -> bool:
+        if self._all_ids_truthy is None:
+            self._all_ids_truthy = all(bool(x) for x in self._ids)
+        return self._all_ids_truthy
 
     def query_batch(self, dense_queries: Optional[Sequence[Any]] = None, sparse_queries: Optional[Sequence[Any]] = None,
                     text_queries: Optional[Sequence[Optional[str]]] = None, top_k: int = 5, search_type: str = "hybrid",
@@ -589,34 +664,22 @@ class GpuVectorStore(VectorStore):
             if not weights or not uniform or not (use_d or use_s):
                 return [single(i) for i in range(n)]          # mixed / degenerate batches: the per-query code decides
             mask = self._mask(filter)
-            rd = self._search_batch("dense", dq, top_k * 2, mask) if use_d else None
-            rs = self._search_batch("sparse", sq, top_k * 2, mask) if use_s else None
-            out = []
-            for i in range(n):
-                rbm = {}
-                if rd is not None:
-                    rbm["dense"] = rd[i]
-                if rs is not None:
-                    rbm["sparse"] = rs[i]
-                if len(rbm) == 1:
-                    out.append(self._results(list(rbm.values())[0][:top_k]))
-                else:
-                    out.append(self._results(merge_hybrid_results(rbm, top_k, weights, rrf_k)))
-            return out
+            if use_d and use_s:
+                return self._hybrid_batch(dq, sq, top_k, mask, weights, rrf_k)
+            rows, scores = self._topk_rows("dense" if use_d else "sparse", dq if use_d else sq, top_k * 2, mask)
+            return [self._results_rows(rows[i, :top_k], scores[i, :top_k]) for i in range(n)]   # one method: its first top_k
         if search_type == "dense" and all(is_set(q) for q in dq):
             mask = self._mask(filter)
-            return [self._results(h) for h in self._search_batch("dense", dq, top_k, mask)]
+            rows, scores = self._topk_rows("dense", dq, top_k, mask)
+            return [self._results_rows(rows[i], scores[i]) for i in range(n)]
         if search_type == "sparse" and all(is_set(q) for q in sq):
             mask = self._mask(filter)
-            return [self._results(h) for h in self._search_batch("sparse", sq, top_k, mask)]
+            rows, scores = self._topk_rows("sparse", sq, top_k, mask)
+            return [self._results_rows(rows[i], scores[i]) for i in range(n)]
         if search_type == "hybrid" and all(is_set(q) for q in dq) and all(is_set(q) for q in sq):
             mask = self._mask(filter)
             try:
-                rd = self._search_batch("dense", dq, top_k * 2, mask)
-                rs = self._search_batch("sparse", sq, top_k * 2, mask)
-                return [self._results(merge_hybrid_results({"dense": rd[i], "sparse": rs[i]}, top_k,
-                                                                     {"dense": 0.5, "sparse": 0.5}, rrf_k=rrf_k))
-                        for i in range(n)]
+                return self._hybrid_batch(dq, sq, top_k, mask, {"dense": 0.5, "sparse": 0.5}, rrf_k)
             except Exception as e:
                 logger.warning("Batched hybrid search failed: %s, answering per query", e)
         return [single(i) for i in range(n)]

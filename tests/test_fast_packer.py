@@ -129,3 +129,42 @@ def test_two_handles_give_the_single_handle_result(tokenizer):
     two = GpuModelSpanExtractor(engine=a, extra_engines=[b], tokenizer=tokenizer, threshold=0.5)
     assert two.extract_spans_batch(questions, results) == one.extract_spans_batch(questions, results)
     assert a.sent and b.sent and len(a.sent) + len(b.sent) == len(one.engine.sent)
+
+
+class TokenHeadEngine:
+    """Stand-in for the v2 (token-classification) engine: logits are a function of the token id alone."""
+    max_seqs, max_tokens, max_ranges = 6, 700, 64
+    token_labels, qa_labels = 2, 0
+    shape = types.SimpleNamespace()
+
+    def __init__(self):
+        self.batches = 0
+
+    def load_batch(self, seqs):
+        self.ids = np.concatenate([np.asarray(s) for s in seqs])
+        self.batches += 1
+
+    def run(self):
+        pass
+
+    def run_token_head(self):
+        pass
+
+    def read_token_logits(self):
+        v = (self.ids.astype(np.int64) * 7919 % 13) / 13.0
+        return np.stack([0.5 - v, v - 0.5], 1).astype(np.float32)
+
+
+def test_highlighter_cross_query_batching_host_logic(tokenizer):
+    eng = TokenHeadEngine()
+    ext = GpuModelSpanExtractor(engine=eng, tokenizer=tokenizer, model_format="highlighter", threshold=0.45, max_length=128,
+                                doc_stride=16, min_span_chars=5, merge_gap_chars=3)
+    ctxs = [" ".join([f"The tall iron tower number {i} in paris was built for the world fair."] * (5 + 7 * i)) for i in range(4)]
+    qs = ["Where is the tower?", "Who built it?", "When was the fair?"]
+    rs = [[types.SimpleNamespace(text=c) for c in ctxs], [types.SimpleNamespace(text=ctxs[2]), types.SimpleNamespace(text="")],
+          [types.SimpleNamespace(text=c) for c in ctxs[::-1]]]
+    got = ext.extract_spans_batch(qs, rs)
+    n_batched = eng.batches
+    want = [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
+    assert got == want and got[1][""] == [] and eng.batches - n_batched >= n_batched > 1
+    assert all(s in c for d in got for c, spans in d.items() for s in spans) and any(v for d in got for v in d.values())

@@ -139,3 +139,26 @@ def test_highlighter_windows_long_context(setup):
     out = ext.extract_spans("Where is the tower?", [types.SimpleNamespace(text=ctx), types.SimpleNamespace(text=" ")])
     assert set(out) == {ctx, " "} and out[" "] == []
     assert all(s in ctx and len(s) >= 5 for s in out[ctx])
+
+
+def test_highlighter_cross_query_batching_equals_per_query_calls(setup):
+    """extract_spans_batch on the v2 (token-classification) format: the windows of all queries share GPU batches and
+    element i equals the single-query call."""
+    import types
+
+    from tokenizers import Tokenizer
+
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    cfg, w, z, eng = setup
+    tok = Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+    ext = GpuModelSpanExtractor(engine=eng, tokenizer=tok, model_format="highlighter", threshold=0.45, max_length=128,
+                                doc_stride=16, min_span_chars=5, merge_gap_chars=3)
+    ctxs = [" ".join([f"The tall iron tower number {i} in paris was built for the world fair."] * (5 + 7 * i)) for i in range(4)]
+    qs = ["Where is the tower?", "Who built it?", "When was the fair?"]
+    rs = [[types.SimpleNamespace(text=c) for c in ctxs], [types.SimpleNamespace(text=ctxs[2]), types.SimpleNamespace(text="")],
+          [types.SimpleNamespace(text=c) for c in ctxs[::-1]]]
+    got = ext.extract_spans_batch(qs, rs)
+    want = [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
+    assert got == want and list(got[1]) == [ctxs[2], ""] and got[1][""] == []
+    assert any(len(v) > 0 for d in got for v in d.values())

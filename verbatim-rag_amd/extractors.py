@@ -321,9 +321,9 @@ class GpuModelSpanExtractor(SpanExtractor):
                             results_per_question: Sequence[Sequence[Any]]) -> List[Dict[str, List[str]]]:
         """Cross-query batching: all (question_i, chunk_ij) pairs of several concurrent
         queries go through the GPU as shared padding-free batches.  Element i of the result equals
-        `extract_spans(questions[i], results_per_question[i])` (legacy qa_model format)."""
+        `extract_spans(questions[i], results_per_question[i])` (both model formats)."""
         if self._format != self._FORMAT_QA_MODEL:
-            return [self.extract_spans(q, r) for q, r in zip(questions, results_per_question)]
+            return self._extract_highlighter_batch(questions, results_per_question)
         out: List[Dict[str, List[str]]] = []
         budget = self.qa_max_length - 2
         cur: list = []   # (query index, text, sentences, ids int32[], starts int64[], ends int64[])
@@ -430,20 +430,29 @@ class GpuModelSpanExtractor(SpanExtractor):
         return windows, offsets, len(ctx_ids)
 
     def _extract_highlighter(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
-        relevant: Dict[str, List[str]] = {}
-        jobs = []
-        for result in search_results:
-            context = getattr(result, "text", "")
-            relevant[context] = []
-            if not context.strip():
-                continue
-            try:
-                windows, offsets, n_ctx = self._encode_windows(question, context)
-                jobs.append((context, windows, offsets, n_ctx))
-            except Exception as exc:
-                logger.error("Highlighter extraction failed: %s", exc)
-        flat = [(ji, w) for ji, job in enumerate(jobs) for w in job[1]]
-        probs = [np.zeros(job[3], dtype=np.float32) for job in jobs]
+        return self._extract_highlighter_batch([question], [search_results])[0]
+
+    def _extract_highlighter_batch(self, questions: Sequence[str],
+                                   results_per_question: Sequence[Sequence[Any]]) -> List[Dict[str, List[str]]]:
+        """v2 path for several queries at once: the windows of every (question, chunk) pair share padding-free GPU
+        batches (windows never see each other, so element i equals the single-query call)."""
+        out: List[Dict[str, List[str]]] = []
+        jobs = []   # (query index, context, windows, offsets, context tokens)
+        for qi, (question, search_results) in enumerate(zip(questions, results_per_question)):
+            relevant: Dict[str, List[str]] = {}
+            out.append(relevant)
+            for result in search_results:
+                context = getattr(result, "text", "")
+                relevant[context] = []
+                if not context.strip():
+                    continue
+                try:
+                    windows, offsets, n_ctx = self._encode_windows(question, context)
+                    jobs.append((qi, context, windows, offsets, n_ctx))
+                except Exception as exc:
+                    logger.error("Highlighter extraction failed: %s", exc)
+        flat = [(ji, w) for ji, job in enumerate(jobs) for w in job[2]]
+        probs = [np.zeros(job[4], dtype=np.float32) for job in jobs]
         with self._lock:
             start = 0
             while start < len(flat):
@@ -469,10 +478,10 @@ class GpuModelSpanExtractor(SpanExtractor):
                 except Exception as exc:
                     logger.error("Highlighter extraction failed: %s", exc)
                 start = end
-        for (context, _w, offsets, _n), p in zip(jobs, probs):
-            relevant[context] = token_spans_to_char_spans(p, offsets, context, self.threshold, self.min_span_chars,
-                                                          self.merge_gap_chars)
-        return relevant
+        for (qi, context, _w, offsets, _n), p in zip(jobs, probs):
+            out[qi][context] = token_spans_to_char_spans(p, offsets, context, self.threshold, self.min_span_chars,
+                                                         self.merge_gap_chars)
+        return out
 
 
 class CoalescingSpanExtractor(SpanExtractor):

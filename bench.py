@@ -167,6 +167,44 @@ def cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, budget_s: float):
     }, logits
 
 
+def topk_recall_check(seed: int = 1234):
+    """Second half of BASELINE.json's metric ("top-k recall vs CPU ref"): a small dense and a small sparse shard on the
+    GPU against the exact CPU top-k (oracle/topk_ref.c -- the checker, like the cpu_baseline leg).  Never raises."""
+    try:
+        from oracle import topk_ref as T
+        from verbatim_rag_amd.vector_stores import DenseShard, SparseShard
+
+        rng = np.random.default_rng(seed)
+        n, dim, vocab, nq, k = 20000, 128, 3000, 16, 10
+        X = (rng.integers(-64, 65, size=(n, dim)) / 64.0).astype(np.float32)
+        Q = (rng.integers(-64, 65, size=(nq, dim)) / 64.0).astype(np.float32)
+        sh = DenseShard(dim, n, "bf16")
+        sh.add(X)
+        _s, di = sh.search(Q, k)
+        sh.close()
+        _rs, dri = T.dense_topk(X, Q, k)
+        lens = rng.integers(1, 40, n)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        idx = np.concatenate([np.sort(rng.choice(vocab, int(m), replace=False)) for m in lens]).astype(np.int32)
+        val = (rng.integers(1, 193, len(idx)) / 64.0).astype(np.float32)
+        qp = np.arange(0, 8 * (nq + 1), 8).astype(np.int64)
+        qi = np.concatenate([np.sort(rng.choice(vocab, 8, replace=False)) for _ in range(nq)]).astype(np.int32)
+        qv = (rng.integers(1, 193, len(qi)) / 64.0).astype(np.float32)
+        sp = SparseShard(vocab, indptr, idx, val)
+        _s2, si = sp.search_csr(qp, qi, qv, k)
+        sp.close()
+        _rs2, sri = T.sparse_topk(indptr, idx, val, vocab, qp, qi, qv, k)
+
+        def recall(got, ref):
+            return float(np.mean([len(set(g[g >= 0]) & set(r[r >= 0])) / max(1, int((r >= 0).sum())) for g, r in zip(got, ref)]))
+
+        return {"k": k, "dense_recall": recall(di, dri), "sparse_recall": recall(si, sri),
+                "indices_equal": bool(np.array_equal(di, dri) and np.array_equal(si, sri)),
+                "sample": f"{nq} queries over {n} x {dim} bf16 rows and {n} sparse docs (vocab {vocab}), exact CPU top-k as reference"}
+    except Exception as exc:  # the bench line must not depend on this check
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,8 +363,9 @@ def main() -> None:
             }
             if iso_obj:
                 roof["breakdown_ms_per_step"] = iso_obj["breakdown_ms_per_step"]
-        cpu, parity = None, None
+        cpu, parity, recall = None, None, None
         if world == 1 and args.cpu_budget > 0:
+            recall = topk_recall_check()
             cpu, ref_logits = cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, args.cpu_budget)
             ref = np.concatenate(ref_logits, axis=0)
             parity = float(np.abs(logits[: ref.shape[0]] - ref).max())
@@ -343,6 +382,7 @@ def main() -> None:
             "model_tflops": value * chunk_flops(shape) / 1e12,
             "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roof, "cpu_baseline": cpu, "parity_max_abs_err_vs_oracle": parity,
+            "topk_recall_vs_cpu_ref": recall,
             "breakdown": breakdown,
         }
         print(json.dumps(out))

@@ -177,3 +177,55 @@ def test_query_normalisation_is_the_same_row_by_row_or_batched(store):
         st._device_topk("dense", st._dense, [X[i].tolist()], 3)
     want = np.stack([q / float(np.sqrt((q * q).sum(dtype=np.float32))) if q.any() else q for q in X])
     assert np.array_equal(seen[0], want) and all(np.array_equal(seen[1 + i][0], want[i]) for i in range(len(X)))
+
+
+def test_concurrent_queries_inserts_and_deletes(store, monkeypatch):
+    """asyncio.to_thread callers: searches on several threads while another thread inserts and deletes.  A shard that
+    was replaced (flush) or evicted (subset cache) must never be closed under a search that still holds it."""
+    import threading
+
+    st, dense, sparse, rng = store
+
+    class Guarded(_Dense):
+        def search(self, queries, k, stream=None):
+            assert not getattr(self, "closed", False), "search on a closed shard"
+            return super().search(queries, k, stream)
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(vs, "DenseShard", Guarded)
+    monkeypatch.setattr(st, "SUBSET_CACHE", 1)
+    st._dirty = True                                   # rebuild the main shard with the guarded class
+    errors, stop = [], threading.Event()
+
+    def reader(seed):
+        r = np.random.default_rng(seed)
+        try:
+            while not stop.is_set():
+                q = dense[int(r.integers(0, 300))].tolist()
+                flt = [None, 'metadata["document_id"] == "d1"', 'metadata["n"] in [1, 2, 3, 4, 5, 6]', 'document_id == "d2"'][int(r.integers(0, 4))]
+                out = st.query(dense_query=q, sparse_query=sparse[int(r.integers(0, 300))], top_k=4, search_type="hybrid", filter=flt)
+                assert len(out) <= 4 and all(x.id for x in out)
+                outs = st.query_batch(dense_queries=[q, q], top_k=3, search_type="dense", filter=flt)
+                assert [x.id for x in outs[0]] == [x.id for x in outs[1]]
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    def writer():
+        try:
+            for j in range(25):
+                st.add_vectors([f"w{j}"], [dense[j].tolist()], [sparse[j]], [f"w text {j}"], [""], [{"document_id": "d1", "n": 1000 + j}])
+                st.delete([f"id{j}", f"w{j - 3}"])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=reader, args=(s,)) for s in range(4)] + [threading.Thread(target=writer)]
+    for t in threads:
+        t.start()
+    threads[-1].join(120)
+    stop.set()
+    for t in threads[:-1]:
+        t.join(120)
+    assert errors == []
+    assert len(st._ids) == 425 and st.query(dense_query=dense[24].tolist(), top_k=3, search_type="dense")[0].id == "w24"

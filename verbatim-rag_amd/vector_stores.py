@@ -15,6 +15,7 @@ import ctypes as C
 import json
 import logging
 import re
+import threading
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -422,6 +423,11 @@ class GpuVectorStore(VectorStore):
         self._dense: Optional[DenseShard] = None
         self._sparse: Optional[SparseShard] = None
         self._dirty = False
+        # Callers arrive from asyncio.to_thread workers (index.py:552-655 under api/): inserts, deletes, the flush and the
+        # cache fills are serialised by this lock; searches run outside it on the shard objects they captured, and a shard
+        # that has been replaced or evicted is released by its last user (DenseShard / SparseShard.__del__), never closed
+        # under a running search.
+        self._mu = threading.RLock()
         self._masks: Dict[str, Optional[np.ndarray]] = {}
         self._value_indexes: Dict[str, Dict[str, np.ndarray]] = {}
         self._all_ids_truthy: Optional[bool] = None
@@ -436,6 +442,10 @@ class GpuVectorStore(VectorStore):
             raise ValueError("Dense vectors required but not provided")          # milvus_base.py:101-104
         if self.enable_sparse and (sparse_vectors is None or len(sparse_vectors) == 0):
             raise ValueError("Sparse vectors required but not provided")
+        with self._mu:
+            self._add_locked(ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas)
+
+    def _add_locked(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
         for i in range(len(ids)):
             self._ids.append(ids[i])
             self._texts.append(texts[i])
@@ -455,32 +465,43 @@ class GpuVectorStore(VectorStore):
 
     def delete(self, ids: List[str]):
         kill = set(ids)
-        for i, x in enumerate(self._ids):
-            if x in kill:
-                self._alive[i] = False
-        self._drop_subsets()
+        with self._mu:
+            for i, x in enumerate(self._ids):
+                if x in kill:
+                    self._alive[i] = False
+            self._drop_subsets()
 
     def _flush(self):
-        if not self._dirty:
-            return
-        n = len(self._ids)
-        if self.enable_dense:
-            if self._dense is not None:
-                self._dense.close()
-            self._dense = DenseShard(self.dense_dim, max(n, 1), self.dense_dtype, self.device)
-            if n:
-                self._dense.add(np.stack(self._dense_rows))
-        if self.enable_sparse:
-            if self._sparse is not None:
-                self._sparse.close()
-            self._sparse = SparseShard(self.sparse_vocab, *dicts_to_csr(self._sparse_rows), device=self.device) if n else None
-        self._dirty = False
+        with self._mu:
+            if not self._dirty:
+                return
+            n = len(self._ids)
+            if self.enable_dense:
+                self._dense = None                      # released now unless a search on another thread still holds it
+                dense = DenseShard(self.dense_dim, max(n, 1), self.dense_dtype, self.device)
+                if n:
+                    dense.add(np.stack(self._dense_rows))
+                self._dense = dense
+            if self.enable_sparse:
+                self._sparse = None
+                self._sparse = SparseShard(self.sparse_vocab, *dicts_to_csr(self._sparse_rows), device=self.device) if n else None
+            self._dirty = False
+
+    def _main_shard(self, kind: str):
+        """(shard, rows it holds) after a flush, captured under the lock."""
+        with self._mu:
+            self._flush()
+            return (self._dense if kind == "dense" else self._sparse), len(self._ids)
 
     # -------------------------------------------------------------- search
     def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
         """Rows a query may return (alive and passing `filter`), or None for all; cached per filter string until the
         next insert / delete (one Python predicate call per row otherwise, on every query)."""
         key = filter or ""
+        with self._mu:
+            return self._mask_locked(key, filter)
+
+    def _mask_locked(self, key: str, filter: Optional[str]) -> Optional[np.ndarray]:
         if key not in self._masks:
             alive = np.asarray(self._alive, dtype=bool)
             if filter:
@@ -504,13 +525,14 @@ class GpuVectorStore(VectorStore):
     def _value_index(self, key: str) -> Dict[str, np.ndarray]:
         """str(metadata[key]) -> rows, built once per key until the next insert: a per-document filter then costs its
         matches, not a Python predicate call per stored row."""
-        index = self._value_indexes.get(key)
-        if index is None:
-            buckets: Dict[str, List[int]] = {}
-            for i, md in enumerate(self._meta):
-                buckets.setdefault(str(md.get(key)), []).append(i)
-            index = self._value_indexes[key] = {v: np.asarray(rows, dtype=np.int64) for v, rows in buckets.items()}
-        return index
+        with self._mu:
+            index = self._value_indexes.get(key)
+            if index is None:
+                buckets: Dict[str, List[int]] = {}
+                for i, md in enumerate(self._meta):
+                    buckets.setdefault(str(md.get(key)), []).append(i)
+                index = self._value_indexes[key] = {v: np.asarray(rows, dtype=np.int64) for v, rows in buckets.items()}
+            return index
 
     def _hit(self, row: int, score: float) -> dict:
         """A search hit in the shape `merge_hybrid_results` works on; the entity (text, metadata copy) is attached
@@ -541,42 +563,44 @@ class GpuVectorStore(VectorStore):
         from the host copies, cached per (kind, mask) until the next insert / delete; subset row j is global row idx[j],
         idx ascending, so the kernels' `(score desc, id asc)` order carries over."""
         key = (kind, mask.tobytes())
-        hit = self._subsets.get(key)
-        if hit is None:
-            idx = np.nonzero(mask)[0]
-            if kind == "dense":
-                shard = DenseShard(self.dense_dim, len(idx), self.dense_dtype, self.device)
-                shard.add(np.stack([self._dense_rows[i] for i in idx]))
-            else:
-                shard = SparseShard(self.sparse_vocab, *dicts_to_csr([self._sparse_rows[i] for i in idx]), device=self.device)
-            while len(self._subsets) >= self.SUBSET_CACHE:
-                self._subsets.pop(next(iter(self._subsets)))[0].close()
-            hit = self._subsets[key] = (shard, idx)
-        return hit
+        with self._mu:
+            hit = self._subsets.get(key)
+            if hit is None:
+                idx = np.nonzero(mask)[0]
+                if kind == "dense":
+                    shard = DenseShard(self.dense_dim, len(idx), self.dense_dtype, self.device)
+                    shard.add(np.stack([self._dense_rows[i] for i in idx]))
+                else:
+                    shard = SparseShard(self.sparse_vocab, *dicts_to_csr([self._sparse_rows[i] for i in idx]), device=self.device)
+                while len(self._subsets) >= self.SUBSET_CACHE:
+                    self._subsets.pop(next(iter(self._subsets)))          # freed when its last user lets go
+                hit = self._subsets[key] = (shard, idx)
+            return hit
 
     def _drop_subsets(self):
-        for shard, _idx in self._subsets.values():
-            shard.close()
-        self._subsets.clear()
-        self._masks.clear()
+        with self._mu:
+            self._subsets.clear()
+            self._masks.clear()
 
     def _topk_rows(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
         """Best `limit` (<= 1024) rows per query among the rows that pass `mask`: `rows [Q, limit]` (-1 = no hit, tail
         only) and their fp32 scores.  One device pass for the whole batch over the full shard; queries that come up
         short because filtered / deleted rows took their slots (and every query when the filter passes under 1/8 of
         the rows) get a second pass over the masked subset shard."""
-        self._flush()
-        n, Q = len(self._ids), len(queries)
+        main, n = self._main_shard(kind)
+        if mask is not None and len(mask) != n:     # rows were inserted after the caller built its mask
+            mask = np.concatenate([mask, np.zeros(n - len(mask), dtype=bool)]) if len(mask) < n else mask[:n]
+        Q = len(queries)
         rows_out = np.full((Q, limit), -1, np.int64)
         score_out = np.zeros((Q, limit), np.float32)
         k = min(self.K_LIMIT, limit)
         n_pass = n if mask is None else int(mask.sum())
-        if n == 0 or Q == 0 or n_pass == 0:
+        if n == 0 or Q == 0 or n_pass == 0 or main is None:
             return rows_out, score_out
         want = min(k, n_pass)
         short = np.ones(Q, dtype=bool)
         if mask is None or n_pass * 8 >= n:
-            scores, rows = self._device_topk(kind, self._dense if kind == "dense" else self._sparse, queries, k)
+            scores, rows = self._device_topk(kind, main, queries, k)
             found = rows >= 0
             valid = found if mask is None else found & mask[np.where(found, rows, 0)]
             count = valid.sum(axis=1)

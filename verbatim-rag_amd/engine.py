@@ -9,6 +9,7 @@ reference (packages/core/verbatim_core/extractors.py:176-181).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -150,6 +151,9 @@ class EncoderEngine:
         self._init_state()
 
     def _init_state(self) -> None:
+        # load_batch -> run -> head -> read is a sequence on ONE workspace: every wrapper that drives this handle
+        # (extractor, providers, reranker) holds this lock around its sequence, so two of them can share a handle.
+        self.lock = threading.RLock()
         self.qa_labels = 0
         self.token_labels = 0
         self.has_mlm = False

@@ -181,7 +181,8 @@ class GpuModelSpanExtractor(SpanExtractor):
         # between them from worker threads, so one handle's upload / read-back / host turnaround hides behind the
         # other's kernels (measured 0.42 -> 0.33 s for 5000 pairs, DESIGN.md "Serving shape").
         self.engines = [self.engine] + list(extra_engines)
-        self._locks = [self._lock] + [threading.Lock() for _ in self.engines[1:]]
+        self._locks = [getattr(e, "lock", None) or threading.Lock() for e in self.engines]   # a handle's own lock: wrappers may share it
+        self._lock = self._locks[0]
         self.tokenizer = tokenizer
         self._tok = TokenizerAdapter(tokenizer, sep_token_id=getattr(self.engine.shape, "sep_token_id", None)
                                      if not hasattr(tokenizer, "sep_token_id") else None,

@@ -72,7 +72,7 @@ class GpuCrossEncoderReranker(BaseReranker):
             raise ValueError("engine has no pair head (BertForSequenceClassification weights)")
         self.engine, self.tokenizer = engine, tokenizer
         self.max_length = min(max_length, engine.max_seq_len)
-        self._lock = threading.Lock()
+        self._lock = getattr(engine, "lock", None) or threading.Lock()   # the handle's own lock: wrappers may share it
 
     def _ids(self, text: str) -> List[int]:
         enc = self.tokenizer.encode(text, add_special_tokens=False)

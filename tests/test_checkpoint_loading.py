@@ -1,0 +1,170 @@
+"""Local HF checkpoint directories (config.json + *.safetensors) through the product's loaders, on CPU: tiny random-init
+`transformers` models are saved with `save_pretrained`, read back by `weights.load_*_safetensors_dir`, and the loaded
+tensors must (a) carry the shapes / names the engines ask for and (b) reproduce the `transformers` forward when fed to the
+numpy oracle -- i.e. the tensor-name mapping of every supported model family is right end to end."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import verbatim_rag_amd  # noqa: F401
+from oracle import bert_np as B
+from oracle import modernbert_np as O
+from verbatim_rag_amd.engine import BertShape, ModernBertShape, strip_prefix
+from verbatim_rag_amd.weights import bert_canonical, load_bert_safetensors_dir, load_safetensors_dir
+
+torch = pytest.importorskip("torch")
+transformers = pytest.importorskip("transformers")
+
+IDS = [1, 17, 45, 99, 3, 250, 7, 2]
+
+
+def _bert_cfg(**kw):
+    return dict(vocab_size=300, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=96,
+                max_position_embeddings=40, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **kw)
+
+
+def _jitter(model, seed):
+    """LayerNorm gains / biases away from their 1 / 0 defaults so a swapped or dropped tensor shows."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def test_bert_masked_lm_directory(tmp_path):
+    torch.manual_seed(0)
+    m = transformers.BertForMaskedLM(transformers.BertConfig(**_bert_cfg())).eval()
+    _jitter(m, 1)
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    shape, W, cfg = load_bert_safetensors_dir(str(tmp_path))
+    assert isinstance(shape, BertShape) and (shape.model_type, shape.hidden_size, shape.num_hidden_layers, shape.vocab_size,
+                                             shape.max_position_embeddings) == ("bert", 64, 2, 300, 40)
+    assert W["l1.wqkv"].shape == (192, 64) and W["mlm.dec.b"].shape == (300,) and "mlm.dec.w" not in W   # decoder tied
+    ocfg = B.BertConfig(vocab_size=300, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=96,
+                        max_position_embeddings=40)
+    with torch.no_grad():
+        out = m(torch.tensor([IDS]), output_hidden_states=True)
+    hid = B.encoder_forward(ocfg, W, IDS)
+    assert np.abs(hid - out.hidden_states[-1][0].numpy()).max() < 2e-5
+    assert np.abs(B.mlm_logits(ocfg, W, hid) - out.logits[0].numpy()).max() < 2e-4
+    oracle_names = B.canonical_from_hf({k: v.numpy() for k, v in m.state_dict().items()})
+    assert all(np.array_equal(W[k], oracle_names[k]) for k in W if k in oracle_names) and set(W) <= set(oracle_names) | {"emb.types"}
+
+
+def test_distilbert_masked_lm_directory(tmp_path):
+    torch.manual_seed(1)
+    c = transformers.DistilBertConfig(vocab_size=300, dim=64, n_layers=2, n_heads=1, hidden_dim=96, max_position_embeddings=40,
+                                      dropout=0.0, attention_dropout=0.0)
+    m = transformers.DistilBertForMaskedLM(c).eval()
+    _jitter(m, 2)
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    shape, W, cfg = load_bert_safetensors_dir(str(tmp_path))
+    assert (shape.model_type, shape.hidden_size, shape.intermediate_size, shape.num_hidden_layers) == ("distilbert", 64, 96, 2)
+    assert "emb.type0" not in W
+    ocfg = B.BertConfig(vocab_size=300, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=96,
+                        max_position_embeddings=40)
+    with torch.no_grad():
+        out = m(torch.tensor([IDS]), output_hidden_states=True)
+    hid = B.encoder_forward(ocfg, W, IDS)
+    assert np.abs(hid - out.hidden_states[-1][0].numpy()).max() < 2e-5
+    assert np.abs(B.mlm_logits(ocfg, W, hid) - out.logits[0].numpy()).max() < 2e-4
+
+
+def test_bert_cross_encoder_directory(tmp_path):
+    torch.manual_seed(2)
+    m = transformers.BertForSequenceClassification(transformers.BertConfig(num_labels=1, **_bert_cfg())).eval()
+    _jitter(m, 3)
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    shape, W, cfg = load_bert_safetensors_dir(str(tmp_path))
+    assert W["emb.types"].shape == (2, 64) and W["pooler.w"].shape == (64, 64) and W["cls.w"].shape == (1, 64)
+    ocfg = B.BertConfig(vocab_size=300, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=96,
+                        max_position_embeddings=40)
+    types = [0, 0, 0, 0, 0, 1, 1, 1]
+    with torch.no_grad():
+        out = m(torch.tensor([IDS]), token_type_ids=torch.tensor([types]))
+    hid = B.encoder_forward(ocfg, W, IDS, type_ids=types)
+    assert np.abs(B.pair_logits(ocfg, W, hid) - out.logits[0].numpy()).max() < 2e-5
+
+
+def test_bert_directory_errors(tmp_path):
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump({"model_type": "roberta"}, f)
+    with pytest.raises(ValueError, match="not bert / distilbert"):
+        load_bert_safetensors_dir(str(tmp_path))
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump({"model_type": "bert"}, f)
+    with pytest.raises(FileNotFoundError):
+        load_bert_safetensors_dir(str(tmp_path))
+    with pytest.raises(KeyError):
+        bert_canonical({"embeddings.word_embeddings.weight": np.zeros((3, 4), np.float32)})
+
+
+def test_modernbert_qa_model_directory(tmp_path):
+    """The reference's QAModel checkpoints name the encoder `bert.*` and add `classifier.*`
+    (extractor_models/model.py:18,51,54)."""
+    from safetensors.numpy import save_file
+
+    torch.manual_seed(3)
+    hc = transformers.ModernBertConfig(vocab_size=300, hidden_size=64, num_hidden_layers=4, num_attention_heads=1, intermediate_size=96,
+                                       max_position_embeddings=256, pad_token_id=0, cls_token_id=1, sep_token_id=2, bos_token_id=1,
+                                       eos_token_id=2, local_attention=8, global_attn_every_n_layers=3)
+    m = transformers.ModernBertModel(hc).eval()
+    _jitter(m, 4)
+    sd = {"bert." + k: v.numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(0)
+    sd["classifier.weight"], sd["classifier.bias"] = rng.standard_normal((2, 64)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    hc.save_pretrained(tmp_path)
+    shape, tensors, cfg = load_safetensors_dir(str(tmp_path))
+    assert isinstance(shape, ModernBertShape)
+    assert (shape.hidden_size, shape.num_hidden_layers, shape.local_attention, shape.global_attn_every_n_layers, shape.sep_token_id) == (64, 4, 8, 3, 2)
+    W = strip_prefix(tensors)
+    assert "layers.0.attn_norm.weight" not in W and W["layers.3.mlp.Wi.weight"].shape == (192, 64) and W["classifier.weight"].shape == (2, 64)
+    ocfg = O.EncoderConfig(vocab_size=300, hidden_size=64, num_hidden_layers=4, num_attention_heads=1, intermediate_size=96,
+                           pad_token_id=0, cls_token_id=1, sep_token_id=2, local_attention=shape.local_attention,
+                           global_attn_every_n_layers=3, global_rope_theta=shape.global_rope_theta, local_rope_theta=shape.local_rope_theta)
+    ids = list(np.random.default_rng(1).integers(3, 300, 40))
+    with torch.no_grad():
+        ref = m(torch.tensor([ids])).last_hidden_state[0].numpy()
+    assert np.abs(O.encoder_forward(ocfg, W, ids) - ref).max() < 5e-5
+    assert os.path.exists(tmp_path / "config.json")
+
+
+def test_modernbert_token_classification_directory(tmp_path):
+    """HF task-model naming (`model.*`, `head.*`, `classifier.*`): what the v2 highlighter path loads
+    (extractors.py:151-166 builds an AutoModel whose head is ModernBertForTokenClassification's)."""
+    torch.manual_seed(4)
+    hc = transformers.ModernBertConfig(vocab_size=300, hidden_size=64, num_hidden_layers=3, num_attention_heads=1, intermediate_size=96,
+                                       max_position_embeddings=256, pad_token_id=0, cls_token_id=1, sep_token_id=2, bos_token_id=1,
+                                       eos_token_id=2, local_attention=8, num_labels=2, classifier_dropout=0.0, mlp_dropout=0.0)
+    m = transformers.ModernBertForTokenClassification(hc).eval()
+    _jitter(m, 5)
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    shape, tensors, cfg = load_safetensors_dir(str(tmp_path))
+    for name in ("head.dense.weight", "head.norm.weight", "classifier.weight", "classifier.bias", "model.embeddings.tok_embeddings.weight"):
+        assert name in tensors, name
+    W = strip_prefix(tensors)
+    ocfg = O.EncoderConfig(vocab_size=300, hidden_size=64, num_hidden_layers=3, num_attention_heads=1, intermediate_size=96,
+                           pad_token_id=0, cls_token_id=1, sep_token_id=2, local_attention=shape.local_attention,
+                           global_attn_every_n_layers=shape.global_attn_every_n_layers, global_rope_theta=shape.global_rope_theta,
+                           local_rope_theta=shape.local_rope_theta)
+    ids = list(np.random.default_rng(2).integers(3, 300, 30))
+    with torch.no_grad():
+        ref = m(torch.tensor([ids])).logits[0].numpy()
+    hid = O.encoder_forward(ocfg, W, ids)
+    got = O.token_logits(hid, W["head.dense.weight"], W["head.norm.weight"], W["classifier.weight"], W["classifier.bias"], ocfg.norm_eps)
+    assert np.abs(got - ref).max() < 1e-4
+
+
+def test_format_detection_on_saved_directories(tmp_path):
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor as E
+
+    cfg = {"model_type": "modernbert", "architectures": ["ModernBertModel"], "hidden_size": 64}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    assert E._detect_format(str(tmp_path)) == E._FORMAT_QA_MODEL
+    cfg["auto_map"] = {"AutoModel": "modeling_highlighter.VerbatimHighlighterModel"}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    assert E._detect_format(str(tmp_path)) == E._FORMAT_HIGHLIGHTER

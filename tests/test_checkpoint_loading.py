@@ -168,3 +168,67 @@ def test_format_detection_on_saved_directories(tmp_path):
     cfg["auto_map"] = {"AutoModel": "modeling_highlighter.VerbatimHighlighterModel"}
     json.dump(cfg, open(tmp_path / "config.json", "w"))
     assert E._detect_format(str(tmp_path)) == E._FORMAT_HIGHLIGHTER
+
+
+def make_qa_checkpoint_dir(path, seed=5):
+    """A directory shaped like the reference's v1 QA checkpoints: `bert.*` ModernBERT tensors + `classifier.*`,
+    config.json and tokenizer.json (TINY geometry of the GPU tests: head_dim 64).  Returns (hf model, classifier W, b)."""
+    import shutil
+
+    from safetensors.numpy import save_file
+
+    torch.manual_seed(seed)
+    hc = transformers.ModernBertConfig(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
+                                       max_position_embeddings=8192, pad_token_id=0, cls_token_id=1, sep_token_id=2, bos_token_id=1,
+                                       eos_token_id=2)
+    m = transformers.ModernBertModel(hc).eval()
+    _jitter(m, seed)
+    rng = np.random.default_rng(seed)
+    Wc, bc = rng.standard_normal((2, 128)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
+    sd = {"bert." + k: v.numpy() for k, v in m.state_dict().items()}
+    sd["classifier.weight"], sd["classifier.bias"] = Wc, bc
+    save_file(sd, os.path.join(path, "model.safetensors"))
+    hc.save_pretrained(path)
+    shutil.copy(os.path.join(os.path.dirname(__file__), "golden", "tokenizer.json"), os.path.join(path, "tokenizer.json"))
+    return m, Wc, bc
+
+
+def test_extractor_constructor_from_a_model_directory(tmp_path, monkeypatch):
+    """`GpuModelSpanExtractor(model_path)` -- the drop-in form of `ModelSpanExtractor(model_path=...)`: reads the
+    directory, picks the format, hands the encoder tensors and the right head to the engine, loads the tokenizer.  The
+    engine is replaced by a recorder here; tests/test_extractor_gpu.py builds the real one from the same directory."""
+    import types
+
+    from verbatim_rag_amd import engine as eng_mod
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    made = []
+
+    class Recorder:
+        max_seqs, max_tokens, max_ranges, qa_labels, token_labels = 64, 8192, 1024, 0, 0
+
+        def __init__(self, shape, weights, **kw):
+            self.shape, self.weights, self.kw = shape, weights, kw
+            made.append(self)
+
+        def set_qa_head(self, w, b):
+            self.qa_labels, self.head = len(b), (w, b)
+
+        def set_token_head(self, *a):
+            self.token_labels, self.head = 2, a
+
+    monkeypatch.setattr(eng_mod, "EncoderEngine", Recorder)
+    with pytest.raises(FileNotFoundError):
+        GpuModelSpanExtractor(model_path=str(tmp_path / "missing"))
+    m, Wc, bc = make_qa_checkpoint_dir(str(tmp_path))
+    ext = GpuModelSpanExtractor(model_path=str(tmp_path), threshold=0.5, n_engines=2)
+    assert ext._format == ext._FORMAT_QA_MODEL and len(made) == 2 and len(ext.engines) == 2
+    rec = made[0]
+    assert rec.shape.hidden_size == 128 and rec.shape.sep_token_id == 2 and rec.kw["max_seq_len"] == 512
+    assert np.array_equal(rec.head[0], Wc) and np.array_equal(rec.head[1], bc)
+    assert np.array_equal(strip_prefix(rec.weights)["layers.2.attn.Wqkv.weight"], m.state_dict()["layers.2.attn.Wqkv.weight"].numpy())
+    assert ext._tok.sep_token_id == 2 and ext._tok.ids("tower", add_special_tokens=True, max_length=16)[0] == 1
+    # the packer runs on the directory's tokenizer
+    sents, samples = ext.pack_qa("Where is the tower?", ["The tower is tall. It is in paris."])
+    assert sents == [["The tower is tall.", "It is in paris."]] and len(samples[0].sentence_boundaries) == 2
+    assert types  # keep the import used

@@ -282,3 +282,37 @@ def test_concurrent_threads_on_separate_and_shared_handles(setup):
         e.close()
     shared.close()
     assert not errors, errors[:3]
+
+
+def test_constructor_from_a_model_directory(tmp_path):
+    """`GpuModelSpanExtractor(model_path)`: config.json + model.safetensors (`bert.*` + `classifier.*`) + tokenizer.json
+    on disk -> the same spans as the engine= route on the same tensors, and logits within 1e-3 of the fp32 oracle."""
+    from test_checkpoint_loading import make_qa_checkpoint_dir
+    from tokenizers import Tokenizer
+
+    from verbatim_rag_amd.engine import EncoderEngine
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    m, Wc, bc = make_qa_checkpoint_dir(str(tmp_path))
+    ext = GpuModelSpanExtractor(model_path=str(tmp_path), threshold=0.5)
+    W = {k: v.numpy() for k, v in m.state_dict().items()}
+    eng = EncoderEngine(ext.engine.shape, W, max_tokens=8192, max_seqs=64, max_seq_len=512, max_ranges=1024)
+    try:
+        eng.set_qa_head(Wc, bc)
+        ext2 = GpuModelSpanExtractor(engine=eng, tokenizer=Tokenizer.from_file(os.path.join(G, "tokenizer.json")), threshold=0.5)
+        texts = ["The tall iron tower is in paris. It was built for the world fair. Millions of visitors climb it every year.",
+                 "A stone bridge crosses the river. The engineer opened it at night.", " "]
+        results = [types.SimpleNamespace(text=t) for t in texts]
+        q = "Where is the tall iron tower?"
+        got = ext.extract_spans(q, results)
+        assert got == ext2.extract_spans(q, results) and list(got) == texts and got[" "] == []
+        assert all(s in t for t, spans in got.items() for s in spans)
+        sents, samples = ext.pack_qa(q, texts[:1])
+        vb = [tuple(b) for b in samples[0].sentence_boundaries]
+        lg = ext.engine.qa_logits([samples[0].input_ids], [vb])[0]
+        cfg = O.EncoderConfig(**TINY)
+        ref = O.qa_sentence_logits(O.encoder_forward(cfg, W, samples[0].input_ids), vb, Wc, bc)
+        assert np.abs(lg - ref).max() < 1e-3
+    finally:
+        eng.close()
+        ext.engine.close()

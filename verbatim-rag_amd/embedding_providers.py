@@ -55,8 +55,7 @@ class _EncoderProvider:
         self.engine = engine
         self.tokenizer = tokenizer
         self.max_length = min(max_length, engine.max_seq_len)
-        self._tok = TokenizerAdapter(tokenizer, sep_token_id=engine.shape.sep_token_id if not hasattr(tokenizer, "sep_token_id") else None,
-                                     cls_token_id=engine.shape.cls_token_id if not hasattr(tokenizer, "cls_token_id") else None)
+        self._tok = TokenizerAdapter.for_model(tokenizer, engine.shape)
         self._lock = getattr(engine, "lock", None) or threading.Lock()   # the handle's own lock: wrappers may share it
 
     def _encode(self, texts: Sequence[str]) -> List[List[int]]:

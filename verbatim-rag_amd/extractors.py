@@ -184,10 +184,7 @@ class GpuModelSpanExtractor(SpanExtractor):
         self._locks = [getattr(e, "lock", None) or threading.Lock() for e in self.engines]   # a handle's own lock: wrappers may share it
         self._lock = self._locks[0]
         self.tokenizer = tokenizer
-        self._tok = TokenizerAdapter(tokenizer, sep_token_id=getattr(self.engine.shape, "sep_token_id", None)
-                                     if not hasattr(tokenizer, "sep_token_id") else None,
-                                     cls_token_id=getattr(self.engine.shape, "cls_token_id", None)
-                                     if not hasattr(tokenizer, "cls_token_id") else None)
+        self._tok = TokenizerAdapter.for_model(tokenizer, self.engine.shape)
         logger.info("GpuModelSpanExtractor ready: format=%s device=%s", self._format, self.device)
 
     # ------------------------------------------------------------------ loading

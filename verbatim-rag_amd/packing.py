@@ -48,6 +48,16 @@ class TokenizerAdapter:
             cid = tokenizer.token_to_id("[CLS]") if self._raw else getattr(tokenizer, "cls_token_id", None)
         self.cls_token_id = None if cid is None else int(cid)
 
+    @classmethod
+    def for_model(cls, tokenizer: Any, shape: Any) -> "TokenizerAdapter":
+        """Special-token ids from the tokenizer when it defines them, otherwise from the model's config.json (`shape`): a
+        raw `tokenizers.Tokenizer`, or an HF fast tokenizer loaded from a directory that holds only tokenizer.json,
+        knows the template but not which ids are [CLS] / [SEP]."""
+        def override(name):
+            return None if isinstance(getattr(tokenizer, name, None), int) else getattr(shape, name, None)
+
+        return cls(tokenizer, sep_token_id=override("sep_token_id"), cls_token_id=override("cls_token_id"))
+
     def ids(self, text: str, add_special_tokens: bool, max_length: int) -> List[int]:
         if self._raw:
             # `[CLS] $A [SEP]` template applied here so that truncation keeps the special tokens

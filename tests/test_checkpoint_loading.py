@@ -232,3 +232,45 @@ def test_extractor_constructor_from_a_model_directory(tmp_path, monkeypatch):
     sents, samples = ext.pack_qa("Where is the tower?", ["The tower is tall. It is in paris."])
     assert sents == [["The tower is tall.", "It is in paris."]] and len(samples[0].sentence_boundaries) == 2
     assert types  # keep the import used
+
+
+def test_extractor_constructor_from_a_highlighter_directory(tmp_path, monkeypatch):
+    """v2 checkpoints: `auto_map` names a *Highlighter* class, tensors follow ModernBertForTokenClassification."""
+    import shutil
+
+    from verbatim_rag_amd import engine as eng_mod
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    made = []
+
+    class Recorder:
+        max_seqs, max_tokens, max_ranges, qa_labels, token_labels = 64, 8192, 1024, 0, 0
+
+        def __init__(self, shape, weights, **kw):
+            self.shape, self.weights, self.kw = shape, weights, kw
+            made.append(self)
+
+        def set_qa_head(self, w, b):
+            raise AssertionError("a highlighter checkpoint must not get the sentence head")
+
+        def set_token_head(self, dense, norm, cls_w, cls_b):
+            self.token_labels, self.head = len(cls_b), (dense, norm, cls_w, cls_b)
+
+    monkeypatch.setattr(eng_mod, "EncoderEngine", Recorder)
+    torch.manual_seed(6)
+    hc = transformers.ModernBertConfig(vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=192,
+                                       max_position_embeddings=8192, pad_token_id=0, cls_token_id=1, sep_token_id=2, bos_token_id=1,
+                                       eos_token_id=2, num_labels=2)
+    m = transformers.ModernBertForTokenClassification(hc).eval()
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    cfg = json.load(open(tmp_path / "config.json"))
+    cfg["auto_map"] = {"AutoModel": "modeling_verbatim.VerbatimHighlighterModel"}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    shutil.copy(os.path.join(os.path.dirname(__file__), "golden", "tokenizer.json"), tmp_path / "tokenizer.json")
+    ext = GpuModelSpanExtractor(model_path=str(tmp_path), threshold=0.5, max_length=1024)
+    rec = made[0]
+    assert ext._format == ext._FORMAT_HIGHLIGHTER and rec.kw["max_seq_len"] == 1024 and rec.token_labels == 2
+    sd = m.state_dict()
+    assert np.array_equal(rec.head[0], sd["head.dense.weight"].numpy()) and np.array_equal(rec.head[2], sd["classifier.weight"].numpy())
+    windows, offsets, n_ctx = ext._encode_windows("Where is the tower?", "The tall iron tower is in paris. " * 400)
+    assert len(windows) > 1 and all(len(w[0]) <= 1024 for w in windows) and n_ctx == len(offsets)

@@ -274,3 +274,85 @@ def test_extractor_constructor_from_a_highlighter_directory(tmp_path, monkeypatc
     assert np.array_equal(rec.head[0], sd["head.dense.weight"].numpy()) and np.array_equal(rec.head[2], sd["classifier.weight"].numpy())
     windows, offsets, n_ctx = ext._encode_windows("Where is the tower?", "The tall iron tower is in paris. " * 400)
     assert len(windows) > 1 and all(len(w[0]) <= 1024 for w in windows) and n_ctx == len(offsets)
+
+
+class _BertRecorder:
+    """Stands in for BertEncoderEngine: keeps what the directory loader hands over."""
+    max_seqs, max_tokens, max_ranges = 64, 8192, 1024
+
+    def __init__(self, shape, weights, **kw):
+        self.shape, self.weights, self.kw = shape, weights, kw
+        self.max_seq_len = min(kw.get("max_seq_len", 512), shape.max_position_embeddings)
+        self.has_mlm = "mlm.dense.w" in weights
+        self.pair_labels = int(weights["cls.w"].shape[0]) if "cls.w" in weights and "pooler.w" in weights else 0
+
+
+def _save_tokenizer(path):
+    import shutil
+
+    shutil.copy(os.path.join(os.path.dirname(__file__), "golden", "tokenizer.json"), os.path.join(path, "tokenizer.json"))
+
+
+def test_provider_and_reranker_constructors_from_directories(tmp_path, monkeypatch):
+    """`from_directory`: the local-files form of `SpladeProvider(model_name)` / `SentenceTransformersProvider(model_name)` /
+    `SentenceTransformersReranker(model_name)` (embedding_providers.py:55-71,120-133, rerankers.py:109-134)."""
+    from verbatim_rag_amd import engine as eng_mod
+    from verbatim_rag_amd.embedding_providers import GpuDenseProvider, GpuSpladeProvider
+    from verbatim_rag_amd.rerankers import GpuCrossEncoderReranker
+
+    monkeypatch.setattr(eng_mod, "BertEncoderEngine", _BertRecorder)
+    torch.manual_seed(7)
+    splade_dir, dense_dir, ce_dir = tmp_path / "splade", tmp_path / "dense", tmp_path / "ce"
+    transformers.BertForMaskedLM(transformers.BertConfig(**_bert_cfg())).save_pretrained(splade_dir, safe_serialization=True)
+    transformers.DistilBertModel(transformers.DistilBertConfig(vocab_size=300, dim=64, n_layers=2, n_heads=1, hidden_dim=96,
+                                                               max_position_embeddings=40)).save_pretrained(dense_dir, safe_serialization=True)
+    transformers.BertForSequenceClassification(transformers.BertConfig(num_labels=1, **_bert_cfg())).save_pretrained(ce_dir, safe_serialization=True)
+    for d in (splade_dir, dense_dir, ce_dir):
+        _save_tokenizer(d)
+    os.makedirs(dense_dir / "1_Pooling")
+    json.dump({"word_embedding_dimension": 64, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True}, open(dense_dir / "1_Pooling" / "config.json", "w"))
+
+    sp = GpuSpladeProvider.from_directory(str(splade_dir), max_length=128)
+    assert sp.get_dimension() == 300 and sp.engine.has_mlm and sp.max_length == 40 and sp.engine.shape.model_type == "bert"
+    dn = GpuDenseProvider.from_directory(str(dense_dir))
+    assert dn.pooling == "mean" and dn.get_dimension() == 64 and dn.engine.shape.model_type == "distilbert"
+    assert GpuDenseProvider.from_directory(str(splade_dir)).pooling == "cls"               # no 1_Pooling directory: the default
+    with pytest.raises(ValueError, match="no MLM head"):
+        GpuSpladeProvider.from_directory(str(dense_dir))
+    rr = GpuCrossEncoderReranker.from_directory(str(ce_dir), rerank_k=7)
+    assert rr.rerank_k == 7 and rr.engine.pair_labels == 1
+    with pytest.raises(ValueError, match="no pair head"):
+        GpuCrossEncoderReranker.from_directory(str(dense_dir))
+    json.dump({"model_type": "roberta"}, open(tmp_path / "config.json", "w"))
+    with pytest.raises(ValueError, match="not bert / distilbert / modernbert"):
+        GpuSpladeProvider.from_directory(str(tmp_path))
+    # the provider tokenises with the directory's tokenizer, special ids resolved (tokenizer or config)
+    ids = sp._encode(["the tall tower"])[0]
+    assert ids[0] == sp._tok.cls_token_id and ids[-1] == sp._tok.sep_token_id and len(ids) >= 3
+
+
+def test_modernbert_masked_lm_directory_gets_the_mlm_head(tmp_path, monkeypatch):
+    from verbatim_rag_amd import engine as eng_mod
+    from verbatim_rag_amd.embedding_providers import GpuSpladeProvider
+
+    class Recorder:
+        max_seqs, max_tokens, max_ranges, has_mlm = 64, 8192, 1024, False
+
+        def __init__(self, shape, weights, **kw):
+            self.shape, self.weights, self.max_seq_len = shape, weights, kw.get("max_seq_len", 512)
+
+        def set_mlm_head(self, dense_w, norm_w, decoder_b, decoder_w=None):
+            self.has_mlm, self.head = True, (dense_w, norm_w, decoder_b, decoder_w)
+
+    monkeypatch.setattr(eng_mod, "EncoderEngine", Recorder)
+    torch.manual_seed(8)
+    hc = transformers.ModernBertConfig(vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=192,
+                                       max_position_embeddings=8192, pad_token_id=0, cls_token_id=1, sep_token_id=2, bos_token_id=1, eos_token_id=2)
+    m = transformers.ModernBertForMaskedLM(hc).eval()
+    m.save_pretrained(tmp_path, safe_serialization=True)
+    _save_tokenizer(tmp_path)
+    sp = GpuSpladeProvider.from_directory(str(tmp_path))
+    sd = m.state_dict()
+    assert sp.engine.has_mlm and np.array_equal(sp.engine.head[0], sd["head.dense.weight"].numpy())
+    assert np.array_equal(sp.engine.head[2], sd["decoder.bias"].numpy()) and sp.engine.head[3] is None      # decoder tied: not stored
+    assert sp.get_dimension() == 512 and sp._tok.sep_token_id == 2

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import threading
 from abc import ABC, abstractmethod
-from typing import Any, Dict, List, Sequence
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -75,6 +75,60 @@ class _EncoderProvider:
             start = end
 
 
+def load_encoder_directory(model_path: str, device: int = 0, max_tokens: int = 65536, max_seqs: int = 512,
+                           max_seq_len: int = 512, **engine_kw):
+    """(engine, tokenizer, raw config) from a local HF checkpoint directory -- the local-files counterpart of the model
+    names the reference hands to sentence-transformers (`SpladeProvider(model_name)`, embedding_providers.py:117-133;
+    `SentenceTransformersProvider(model_name)`, :52-71).  BERT / DistilBERT checkpoints get a `BertEncoderEngine` (MLM
+    and pair heads attached when the tensors are there), ModernBERT checkpoints an `EncoderEngine` (+ MLM head)."""
+    import json
+    import os
+
+    from . import engine as engine_mod
+    from .weights import load_bert_safetensors_dir, load_safetensors_dir
+
+    with open(os.path.join(model_path, "config.json")) as f:
+        model_type = json.load(f).get("model_type")
+    kw = dict(max_tokens=max_tokens, max_seqs=max_seqs, max_seq_len=max_seq_len, max_ranges=max(max_seqs, 64), device=device, **engine_kw)
+    if model_type in ("bert", "distilbert"):
+        shape, weights, cfg = load_bert_safetensors_dir(model_path)
+        eng = engine_mod.BertEncoderEngine(shape, weights, **kw)
+    elif model_type == "modernbert":
+        shape, tensors, cfg = load_safetensors_dir(model_path)
+        eng = engine_mod.EncoderEngine(shape, tensors, **kw)
+        if "head.dense.weight" in tensors and "decoder.bias" in tensors:        # ModernBertForMaskedLM: tied decoder
+            eng.set_mlm_head(tensors["head.dense.weight"], tensors["head.norm.weight"], tensors["decoder.bias"],
+                             tensors.get("decoder.weight"))
+    else:
+        raise ValueError(f"{model_path}: model_type {model_type!r} is not bert / distilbert / modernbert")
+    try:
+        from transformers import AutoTokenizer
+
+        tokenizer = AutoTokenizer.from_pretrained(model_path)
+    except Exception:
+        from tokenizers import Tokenizer
+
+        tokenizer = Tokenizer.from_file(os.path.join(model_path, "tokenizer.json"))
+    return eng, tokenizer, cfg
+
+
+def _st_pooling_mode(model_path: str, default: str = "cls") -> str:
+    """sentence-transformers checkpoints say how they pool in `1_Pooling/config.json` (bge: CLS, MiniLM: mean)."""
+    import json
+    import os
+
+    try:
+        with open(os.path.join(model_path, "1_Pooling", "config.json")) as f:
+            pc = json.load(f)
+    except OSError:
+        return default
+    if pc.get("pooling_mode_mean_tokens"):
+        return "mean"
+    if pc.get("pooling_mode_cls_token"):
+        return "cls"
+    raise ValueError(f"{model_path}: only CLS and mean pooling are implemented (1_Pooling/config.json: {pc})")
+
+
 class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
     """SpladeProvider (embedding_providers.py:117-169) on the HIP encoder + fused SPLADE head."""
 
@@ -83,6 +137,12 @@ class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
         self.sparse_cap = int(sparse_cap)
         if not engine.has_mlm:
             raise ValueError("engine has no MLM head (EncoderEngine.set_mlm_head)")
+
+    @classmethod
+    def from_directory(cls, model_path: str, device: int = 0, max_length: int = 512, **kw) -> "GpuSpladeProvider":
+        """`SpladeProvider(model_name, device)` (embedding_providers.py:120-133) for a checkpoint on disk."""
+        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length)
+        return cls(engine, tokenizer, max_length=max_length, **kw)
 
     def _rows(self, texts: Sequence[str]) -> np.ndarray:
         seqs = self._encode(texts)
@@ -142,6 +202,14 @@ class GpuDenseProvider(_EncoderProvider, DenseEmbeddingProvider):
         if pooling not in ("cls", "mean"):
             raise ValueError("pooling must be 'cls' or 'mean'")
         self.pooling, self.normalize = pooling, normalize
+
+    @classmethod
+    def from_directory(cls, model_path: str, device: int = 0, max_length: int = 512, pooling: Optional[str] = None,
+                       normalize: bool = True) -> "GpuDenseProvider":
+        """`SentenceTransformersProvider(model_name, device)` (embedding_providers.py:55-71) for a checkpoint on disk;
+        the pooling mode comes from the checkpoint's `1_Pooling/config.json` unless given."""
+        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length)
+        return cls(engine, tokenizer, pooling=pooling or _st_pooling_mode(model_path), normalize=normalize, max_length=max_length)
 
     def _rows(self, texts: Sequence[str]) -> np.ndarray:
         seqs = self._encode(texts)

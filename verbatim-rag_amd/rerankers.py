@@ -74,6 +74,15 @@ class GpuCrossEncoderReranker(BaseReranker):
         self.max_length = min(max_length, engine.max_seq_len)
         self._lock = getattr(engine, "lock", None) or threading.Lock()   # the handle's own lock: wrappers may share it
 
+    @classmethod
+    def from_directory(cls, model_path: str, device: int = 0, rerank_k: int = 50, max_length: int = 512, **kw) -> "GpuCrossEncoderReranker":
+        """`SentenceTransformersReranker(model_name)` (rerankers.py:109-134) for a `BertForSequenceClassification`
+        checkpoint on disk (e.g. a downloaded `cross-encoder/ms-marco-MiniLM-L-6-v2`)."""
+        from .embedding_providers import load_encoder_directory
+
+        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length)
+        return cls(engine, tokenizer, rerank_k=rerank_k, max_length=max_length, **kw)
+
     def _ids(self, text: str) -> List[int]:
         enc = self.tokenizer.encode(text, add_special_tokens=False)
         return list(enc.ids if hasattr(enc, "ids") else enc)

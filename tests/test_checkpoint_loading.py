@@ -197,8 +197,6 @@ def test_extractor_constructor_from_a_model_directory(tmp_path, monkeypatch):
     """`GpuModelSpanExtractor(model_path)` -- the drop-in form of `ModelSpanExtractor(model_path=...)`: reads the
     directory, picks the format, hands the encoder tensors and the right head to the engine, loads the tokenizer.  The
     engine is replaced by a recorder here; tests/test_extractor_gpu.py builds the real one from the same directory."""
-    import types
-
     from verbatim_rag_amd import engine as eng_mod
     from verbatim_rag_amd.extractors import GpuModelSpanExtractor
 
@@ -231,7 +229,6 @@ def test_extractor_constructor_from_a_model_directory(tmp_path, monkeypatch):
     # the packer runs on the directory's tokenizer
     sents, samples = ext.pack_qa("Where is the tower?", ["The tower is tall. It is in paris."])
     assert sents == [["The tower is tall.", "It is in paris."]] and len(samples[0].sentence_boundaries) == 2
-    assert types  # keep the import used
 
 
 def test_extractor_constructor_from_a_highlighter_directory(tmp_path, monkeypatch):

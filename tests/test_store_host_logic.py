@@ -229,3 +229,27 @@ def test_concurrent_queries_inserts_and_deletes(store, monkeypatch):
         t.join(120)
     assert errors == []
     assert len(st._ids) == 425 and st.query(dense_query=dense[24].tolist(), top_k=3, search_type="dense")[0].id == "w24"
+
+
+def test_save_load_round_trip_on_stand_ins(store, tmp_path):
+    """The store's on-disk format (vectors.npz + rows.json): same hits after a reload, deleted rows stay out."""
+    st, dense, sparse, rng = store
+    st.delete(["id3", "id17"])
+    st.save(str(tmp_path / "idx"))
+    st2 = vs.GpuVectorStore.load(str(tmp_path / "idx"))
+    assert len(st2._ids) == 398 and "id17" not in st2._ids and st2.dense_dim == 64 and st2.sparse_vocab == 300
+    for kw in (dict(dense_query=dense[5].tolist(), top_k=6, search_type="dense"),
+               dict(sparse_query=sparse[9], top_k=5, search_type="sparse"),
+               dict(dense_query=dense[40].tolist(), sparse_query=sparse[40], top_k=4, search_type="hybrid"),
+               dict(dense_query=dense[5].tolist(), top_k=5, search_type="dense", filter='metadata["document_id"] == "d1"')):
+        a, b = st.query(**kw), st2.query(**kw)
+        assert [(x.id, x.score, x.text, x.metadata) for x in a] == [(x.id, x.score, x.text, x.metadata) for x in b]
+    with open(tmp_path / "idx" / "rows.json") as f:
+        import json
+
+        rows = json.load(f)
+    rows["format"] = 99
+    with open(tmp_path / "idx" / "rows.json", "w") as f:
+        json.dump(rows, f)
+    with pytest.raises(ValueError, match="unknown GpuVectorStore format"):
+        vs.GpuVectorStore.load(str(tmp_path / "idx"))

@@ -1,0 +1,101 @@
+"""The drop-in claim, executed: the REFERENCE's own `VerbatimIndex` and `VerbatimRAG` (imported from /root/reference,
+build container only -- skipped elsewhere) drive this package's store / providers / extractor, and the result equals
+this package's restatement of the same pipeline (`HotPathIndex` + `StaticVerbatimPipeline`).  Device classes are
+replaced by CPU stand-ins (oracle-backed shards, a logit function of the token ids): what is under test is every
+Python-level seam between the two code bases -- argument names, return types, `SearchResult` fields, dict keys."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+import verbatim_rag_amd  # noqa: F401
+from test_fast_packer import RecordingEngine
+from test_store_host_logic import _Dense, _Sparse
+from verbatim_rag_amd import vector_stores as vs
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture()
+def reference(tmp_path, monkeypatch):
+    stubs = tmp_path / "stubs"
+    (stubs / "rapidfuzz").mkdir(parents=True)
+    (stubs / "rapidfuzz" / "__init__.py").write_text("")
+    (stubs / "rapidfuzz" / "fuzz.py").write_text("def partial_ratio_alignment(*a, **k):\n    raise RuntimeError('stub')\n")
+    (stubs / "openai").mkdir()
+    (stubs / "openai" / "__init__.py").write_text("class OpenAI:\n    def __init__(self, *a, **k): pass\nclass AsyncOpenAI(OpenAI):\n    pass\n")
+    for p in (str(stubs), os.path.join(REF, "packages", "core"), REF):
+        monkeypatch.syspath_prepend(p)
+    from verbatim_rag.core import VerbatimRAG
+    from verbatim_rag.index import VerbatimIndex
+
+    return VerbatimIndex, VerbatimRAG
+
+
+class Dense:
+    def embed_text(self, t):
+        v = np.zeros(64, np.float32)
+        v[len(t) % 64] = 1.0
+        v[(len(t) * 7) % 64] += 0.5
+        return v.tolist()
+
+    def embed_batch(self, ts):
+        return [self.embed_text(t) for t in ts]
+
+    def get_dimension(self):
+        return 64
+
+
+class Sparse:
+    def embed_text(self, t):
+        return {(len(w) * 13 + ord(w[0])) % 300: 1.0 + 0.25 * (len(w) % 3) for w in t.split()[:12]}
+
+    def embed_batch(self, ts):
+        return [self.embed_text(t) for t in ts]
+
+    def get_dimension(self):
+        return 300
+
+
+def test_reference_pipeline_runs_on_this_packages_classes(reference, monkeypatch):
+    from tokenizers import Tokenizer
+
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+    from verbatim_rag_amd.index import HotPathIndex
+    from verbatim_rag_amd.pipeline import StaticVerbatimPipeline
+
+    VerbatimIndex, VerbatimRAG = reference
+    monkeypatch.setattr(vs._lib, "load", lambda: None)
+    monkeypatch.setattr(vs._lib, "require_gpu", lambda: None)
+    monkeypatch.setattr(vs, "DenseShard", _Dense)
+    monkeypatch.setattr(vs, "SparseShard", _Sparse)
+    docs = [f"The tower number {i} is tall. It stands in city {i % 4}. Visitors climb {i + 3} stairs! Was it built in {1800 + i}?" for i in range(30)]
+    store = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    dense, sparse = Dense(), Sparse()
+    ours = HotPathIndex(store, dense_provider=dense, sparse_provider=sparse)
+    ours.add_chunks([f"c{i}" for i in range(30)], docs, metadatas=[{"document_id": f"d{i % 3}", "title": f"Doc {i}", "source": f"s{i}.md"} for i in range(30)])
+    ext = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=Tokenizer.from_file(os.path.join(G, "tokenizer.json")), threshold=0.5)
+
+    theirs = VerbatimIndex(vector_store=store, dense_provider=dense, sparse_provider=sparse)
+    for kw in (dict(text="Where is the tall tower?", k=5), dict(text="Visitors climb stairs", k=3, search_type="sparse"),
+               dict(text="city", k=4, search_type="dense", filter='metadata["document_id"] == "d1"'),
+               dict(text="Where is it?", k=5, hybrid_weights={"dense": 0.7, "sparse": 0.3}, rrf_k=20)):
+        a, b = theirs.query(**kw), ours.query(**kw)
+        assert [(x.id, x.score, x.text, x.metadata) for x in a] == [(x.id, x.score, x.text, x.metadata) for x in b] and 0 < len(a) <= kw["k"]
+
+    rag = VerbatimRAG(index=theirs, k=5, extractor=ext, template_mode="static", llm_client=types.SimpleNamespace())
+    pipe = StaticVerbatimPipeline(ours, ext, k=5)
+    for question in ("Where is the tall tower?", "How many stairs do visitors climb?"):
+        resp = rag.query(question)
+        mine = pipe.query(question)
+        assert resp.model_dump() == mine.model_dump()
+        assert len(resp.documents) == 5 and any(d.highlights for d in resp.documents)
+        for d in resp.documents:
+            assert all(d.content[h.start:h.end] == h.text for h in d.highlights)
+    assert [r.model_dump() for r in pipe.query_batch(["Where is the tall tower?", "How many stairs do visitors climb?"])] == \
+        [rag.query(q).model_dump() for q in ("Where is the tall tower?", "How many stairs do visitors climb?")]
+    assert "verbatim_rag.index" in sys.modules

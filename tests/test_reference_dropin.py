@@ -99,3 +99,60 @@ def test_reference_pipeline_runs_on_this_packages_classes(reference, monkeypatch
     assert [r.model_dump() for r in pipe.query_batch(["Where is the tall tower?", "How many stairs do visitors climb?"])] == \
         [rag.query(q).model_dump() for q in ("Where is the tall tower?", "How many stairs do visitors climb?")]
     assert "verbatim_rag.index" in sys.modules
+
+
+def test_reference_async_transform_and_reranker_seams(reference, monkeypatch):
+    """`VerbatimRAG.query_async` (-> `extract_spans_async`, extractors.py:48-54), `VerbatimTransform.transform` (dict
+    contexts, transform.py:86-112) and the `reranker=` hook (core.py:125-140) with this package's classes plugged in."""
+    import asyncio
+
+    from tokenizers import Tokenizer
+    from verbatim_core.transform import VerbatimTransform
+
+    from verbatim_rag_amd.extractors import CoalescingSpanExtractor, GpuModelSpanExtractor
+    from verbatim_rag_amd.index import HotPathIndex
+    from verbatim_rag_amd.pipeline import StaticVerbatimPipeline
+    from verbatim_rag_amd.rerankers import GpuCrossEncoderReranker
+
+    VerbatimIndex, VerbatimRAG = reference
+    monkeypatch.setattr(vs._lib, "load", lambda: None)
+    monkeypatch.setattr(vs._lib, "require_gpu", lambda: None)
+    monkeypatch.setattr(vs, "DenseShard", _Dense)
+    monkeypatch.setattr(vs, "SparseShard", _Sparse)
+    docs = [f"The tower number {i} is tall. It stands in city {i % 4}. Visitors climb {i + 3} stairs! Was it built in {1800 + i}?" for i in range(20)]
+    store = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    ours = HotPathIndex(store, dense_provider=Dense(), sparse_provider=Sparse())
+    ours.add_chunks([f"c{i}" for i in range(20)], docs, metadatas=[{"title": f"Doc {i}", "source": f"s{i}.md"} for i in range(20)])
+    tok = Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+    ext = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=tok, threshold=0.5)
+    theirs = VerbatimIndex(vector_store=store, dense_provider=ours.dense_provider, sparse_provider=ours.sparse_provider)
+    question = "Where is the tall tower?"
+
+    rag = VerbatimRAG(index=theirs, k=4, extractor=ext, template_mode="static", llm_client=types.SimpleNamespace())
+    sync = rag.query(question).model_dump()
+    assert asyncio.run(rag.query_async(question)).model_dump() == sync
+
+    co = CoalescingSpanExtractor(ext, max_wait_ms=1.0)          # the per-query interface in front of the batch path
+    try:
+        rag_co = VerbatimRAG(index=theirs, k=4, extractor=co, template_mode="static", llm_client=types.SimpleNamespace())
+        assert asyncio.run(rag_co.query_async(question)).model_dump() == sync
+    finally:
+        co.close()
+
+    tr = VerbatimTransform(llm_client=types.SimpleNamespace(), extractor=ext, template_mode="static")
+    out = tr.transform(question, [{"content": docs[0], "title": "T0", "source": "s0"}, {"text": docs[1]}])
+    assert [d.content for d in out.documents] == docs[:2] and out.documents[0].title == "T0"
+    assert all(d.content[h.start:h.end] == h.text for d in out.documents for h in d.highlights)
+
+    class PairEngine:                                           # cross-encoder stand-in: score = overlap with the question
+        max_seqs, max_tokens, max_seq_len, pair_labels = 64, 8192, 512, 1
+        shape = types.SimpleNamespace(cls_token_id=1, sep_token_id=2)
+
+        def pair_logits(self, seqs, types_):
+            return np.asarray([[float(sum(t) % 17)] for t in seqs], np.float32)
+
+    rr = GpuCrossEncoderReranker(PairEngine(), tok, rerank_k=3)
+    with_rr = VerbatimRAG(index=theirs, k=4, extractor=ext, template_mode="static", llm_client=types.SimpleNamespace(), reranker=rr)
+    mine = StaticVerbatimPipeline(ours, ext, k=4, reranker=rr)
+    a, b = with_rr.query(question).model_dump(), mine.query(question).model_dump()
+    assert a == b and [d["content"] for d in a["documents"]] != [d["content"] for d in sync["documents"]]

@@ -156,3 +156,41 @@ def test_reference_async_transform_and_reranker_seams(reference, monkeypatch):
     mine = StaticVerbatimPipeline(ours, ext, k=4, reranker=rr)
     a, b = with_rr.query(question).model_dump(), mine.query(question).model_dump()
     assert a == b and [d["content"] for d in a["documents"]] != [d["content"] for d in sync["documents"]]
+
+
+def test_reference_streaming_over_this_packages_classes(reference, monkeypatch):
+    """`StreamingRAG.stream_query` (streaming.py:24-177): documents, then highlights (extract_spans in a worker thread),
+    then the answer -- reads `doc.metadata.get(...)` and the extractor's dict directly."""
+    import asyncio
+
+    from tokenizers import Tokenizer
+    from verbatim_rag.streaming import StreamingRAG
+
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+    from verbatim_rag_amd.index import HotPathIndex
+
+    VerbatimIndex, VerbatimRAG = reference
+    monkeypatch.setattr(vs._lib, "load", lambda: None)
+    monkeypatch.setattr(vs._lib, "require_gpu", lambda: None)
+    monkeypatch.setattr(vs, "DenseShard", _Dense)
+    monkeypatch.setattr(vs, "SparseShard", _Sparse)
+    docs = [f"The tower number {i} is tall. It stands in city {i % 4}. Visitors climb {i + 3} stairs!" for i in range(12)]
+    store = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    HotPathIndex(store, dense_provider=Dense(), sparse_provider=Sparse()).add_chunks(
+        [f"c{i}" for i in range(12)], docs, metadatas=[{"title": f"Doc {i}", "source": f"s{i}.md"} for i in range(12)])
+    ext = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=Tokenizer.from_file(os.path.join(G, "tokenizer.json")), threshold=0.5)
+    rag = VerbatimRAG(index=VerbatimIndex(vector_store=store, dense_provider=Dense(), sparse_provider=Sparse()), k=3, extractor=ext,
+                      template_mode="static", llm_client=types.SimpleNamespace())
+
+    async def collect():
+        return [ev async for ev in StreamingRAG(rag).stream_query("Where is the tall tower?")]
+
+    events = asyncio.run(collect())
+    kinds = [e.get("type") for e in events]
+    assert "error" not in kinds and kinds[0] == "documents" and "highlights" in kinds and kinds[-1] == "answer", kinds
+    final = rag.query("Where is the tall tower?")
+    assert events[-1]["done"] is True and events[-1]["data"] == final.model_dump()
+    docs_ev = next(e for e in events if e["type"] == "documents")["data"]
+    assert [d["content"] for d in docs_ev] == [d.content for d in final.documents] and all(d["highlights"] == [] for d in docs_ev)
+    hl_ev = next(e for e in events if e["type"] == "highlights")["data"]
+    assert [[h["text"] for h in d["highlights"]] for d in hl_ev] == [[h.text for h in d.highlights] for d in final.documents]

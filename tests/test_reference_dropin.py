@@ -194,3 +194,30 @@ def test_reference_streaming_over_this_packages_classes(reference, monkeypatch):
     assert [d["content"] for d in docs_ev] == [d.content for d in final.documents] and all(d["highlights"] == [] for d in docs_ev)
     hl_ev = next(e for e in events if e["type"] == "highlights")["data"]
     assert [[h["text"] for h in d["highlights"]] for d in hl_ev] == [[h.text for h in d.highlights] for d in final.documents]
+
+
+def test_reference_ingest_path_fills_this_packages_store(reference, monkeypatch, tmp_path):
+    """`VerbatimIndex.add_documents` (index.py:318-411: the reference's chunker, `_prepare_chunk_metadata`,
+    `_generate_embeddings`, `_store_chunks` -> `store.add_vectors(ids=, dense_vectors=, sparse_vectors=, texts=,
+    enhanced_texts=, metadatas=)`), then queries, a `document_id` filter built the reference's way, save / load."""
+    from verbatim_rag.schema import DocumentSchema
+
+    VerbatimIndex, _VerbatimRAG = reference
+    monkeypatch.setattr(vs._lib, "load", lambda: None)
+    monkeypatch.setattr(vs._lib, "require_gpu", lambda: None)
+    monkeypatch.setattr(vs, "DenseShard", _Dense)
+    monkeypatch.setattr(vs, "SparseShard", _Sparse)
+    store = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    idx = VerbatimIndex(vector_store=store, dense_provider=Dense(), sparse_provider=Sparse())
+    docs = [DocumentSchema(content=f"# Title {i}\n\nThe tower number {i} is tall. It stands in city {i}.\n\n## Section\n\nVisitors climb {i + 3} stairs!",
+                           title=f"Doc {i}", source=f"s{i}.md") for i in range(6)]
+    idx.add_documents(docs)
+    assert len(store._ids) >= 6 and all(isinstance(v, (str, int, float, bool, type(None), list, dict)) for md in store._meta for v in md.values())
+    hits = idx.query(text="The tower is tall", k=4)
+    assert len(hits) == 4 and all(h.metadata["title"].startswith("Doc ") and h.text for h in hits)
+    doc_id = hits[0].metadata["document_id"]
+    only = idx.query(text="The tower is tall", k=10, filter=f'metadata["document_id"] == "{doc_id}"')
+    assert only and all(h.metadata["document_id"] == doc_id for h in only)
+    store.save(str(tmp_path / "idx"))
+    again = VerbatimIndex(vector_store=vs.GpuVectorStore.load(str(tmp_path / "idx")), dense_provider=Dense(), sparse_provider=Sparse())
+    assert [(h.id, h.score) for h in again.query(text="The tower is tall", k=4)] == [(h.id, h.score) for h in hits]

@@ -253,3 +253,25 @@ def test_save_load_round_trip_on_stand_ins(store, tmp_path):
         json.dump(rows, f)
     with pytest.raises(ValueError, match="unknown GpuVectorStore format"):
         vs.GpuVectorStore.load(str(tmp_path / "idx"))
+
+
+def test_metadata_is_stored_the_way_the_json_column_sees_it(store, tmp_path):
+    """vector_stores/utils.py:10-29 (`json_serialize_safe`): enums -> values, datetimes -> ISO strings, keys -> str."""
+    import enum
+    from datetime import datetime
+
+    class Kind(enum.Enum):
+        TXT = "txt"
+
+    st, dense, sparse, rng = store
+    md = {"document_id": "dX", "content_type": Kind.TXT, "created": datetime(2026, 1, 2, 3, 4, 5), 7: "seven",
+          "nested": {"k": [Kind.TXT, {"d": datetime(2020, 5, 6)}]}}
+    st.add_vectors(["x1"], [dense[0].tolist()], [sparse[0]], ["t"], ["e"], [md])
+    got = st._meta[-1]
+    assert got == {"document_id": "dX", "content_type": "txt", "created": "2026-01-02T03:04:05", "7": "seven",
+                   "nested": {"k": ["txt", {"d": "2020-05-06T00:00:00"}]}}
+    assert md["content_type"] is Kind.TXT                                   # the caller's dict is left alone
+    r = st.query(dense_query=dense[0].tolist(), top_k=2, search_type="dense", filter='content_type == "txt"')
+    assert [x.id for x in r] == ["x1"] and r[0].metadata["created"] == "2026-01-02T03:04:05"
+    st.save(str(tmp_path / "s"))                                           # json.dump would reject the raw objects
+    assert vs.GpuVectorStore.load(str(tmp_path / "s"))._meta[-1] == got

@@ -297,6 +297,24 @@ class SparseShard:
             pass
 
 
+def json_serialize_safe(obj: Any) -> Any:
+    """What the reference's store does to metadata before the insert (vector_stores/utils.py:10-29): datetimes become
+    ISO strings, enums their values, dict keys strings, recursively through dicts and lists -- the JSON column's view of
+    the caller's objects, which is what searches return and filters compare against."""
+    from datetime import datetime
+    from enum import Enum
+
+    if isinstance(obj, datetime):
+        return obj.isoformat()
+    if isinstance(obj, Enum):
+        return getattr(obj, "value", str(obj))
+    if isinstance(obj, dict):
+        return {str(k): json_serialize_safe(v) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [json_serialize_safe(item) for item in obj]
+    return obj
+
+
 # ---------------------------------------------------------------------------- the store
 _FILTER_TOKEN = re.compile(r"""\s*(?:(?P<meta>metadata\[\s*["'](?P<mkey>[^"']+)["']\s*\])|(?P<str>"[^"]*"|'[^']*')|(?P<num>-?\d+(?:\.\d+)?)"""
                            r"""|(?P<op>==|!=|&&|\|\||[()\[\],])|(?P<word>\w+))""")
@@ -450,7 +468,7 @@ class GpuVectorStore(VectorStore):
             self._ids.append(ids[i])
             self._texts.append(texts[i])
             self._enh.append(enhanced_texts[i])
-            self._meta.append(dict(metadatas[i] or {}))
+            self._meta.append(json_serialize_safe(dict(metadatas[i] or {})))   # milvus_base.py:108-109
             self._alive.append(True)
             if self.enable_dense:
                 v = np.asarray(dense_vectors[i], dtype=np.float32)

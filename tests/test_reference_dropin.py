@@ -218,6 +218,16 @@ def test_reference_ingest_path_fills_this_packages_store(reference, monkeypatch,
     doc_id = hits[0].metadata["document_id"]
     only = idx.query(text="The tower is tall", k=10, filter=f'metadata["document_id"] == "{doc_id}"')
     assert only and all(h.metadata["document_id"] == doc_id for h in only)
+    # accessors the reference builds on filter-only / vector-less queries (index.py:657-760) and the document records
+    assert len(idx.get_all_chunks(limit=5)) == 5
+    listed = idx.get_all_documents(limit=3)
+    assert len(listed) == 3 and all(d["title"].startswith("Doc ") and d["content_type"] for d in listed)
+    by_doc = idx.get_chunks_by_document(doc_id)
+    assert by_doc and all(h.metadata["document_id"] == doc_id for h in by_doc)
+    assert idx.inspect()["total_documents"] == 6
+    rec = idx.get_document(doc_id)
+    assert rec is not None and rec["id"] == doc_id and rec["title"].startswith("Doc ") and idx.get_document("nope") is None
     store.save(str(tmp_path / "idx"))
     again = VerbatimIndex(vector_store=vs.GpuVectorStore.load(str(tmp_path / "idx")), dense_provider=Dense(), sparse_provider=Sparse())
     assert [(h.id, h.score) for h in again.query(text="The tower is tall", k=4)] == [(h.id, h.score) for h in hits]
+    assert again.get_document(doc_id) == rec

@@ -449,6 +449,7 @@ class GpuVectorStore(VectorStore):
         self._masks: Dict[str, Optional[np.ndarray]] = {}
         self._value_indexes: Dict[str, Dict[str, np.ndarray]] = {}
         self._all_ids_truthy: Optional[bool] = None
+        self._documents: Dict[str, Dict[str, Any]] = {}      # document records (add_documents / get_document)
         self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
 
     SUBSET_CACHE = 4
@@ -779,8 +780,28 @@ class GpuVectorStore(VectorStore):
             return self._results(list(rbm.values())[0][:top_k])
         return self._results(merge_hybrid_results(rbm, top_k, hybrid_weights, rrf_k))
 
-    def get_document(self, document_id: str):
-        return None
+    def add_documents(self, documents: List[Dict[str, Any]]):
+        """Document records beside the chunk rows (milvus_base.py:129-165; probed with `hasattr` by
+        VerbatimIndex._store_document_metadata, index.py:299-316): id, title, source, content_type, raw_content,
+        metadata, plus the promoted filter fields when the metadata carries them."""
+        with self._mu:
+            for doc in documents or []:
+                metadata = doc.get("metadata", {})
+                row = {"id": doc.get("id", ""), "title": doc.get("title") or "", "source": doc.get("source") or "",
+                       "content_type": json_serialize_safe(doc.get("doc_type") or doc.get("content_type") or ""),
+                       "raw_content": doc.get("raw_content", ""),
+                       "metadata": json_serialize_safe(metadata) if isinstance(metadata, dict) else metadata}
+                if isinstance(metadata, dict):
+                    for key in ("user_id", "dataset_id", "document_id"):
+                        if key in metadata:
+                            row[key] = metadata.get(key)
+                self._documents[row["id"]] = row
+
+    def get_document(self, document_id: str) -> Optional[Dict[str, Any]]:
+        """milvus_base.py:173-187: the stored record (a copy) or None."""
+        with self._mu:
+            row = self._documents.get(document_id)
+            return dict(row) if row is not None else None
 
     # -------------------------------------------------------------- persistence (SURVEY 8f-4)
     def save(self, path: str) -> None:
@@ -805,7 +826,8 @@ class GpuVectorStore(VectorStore):
                        "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse,
                        "dense_dtype": self.dense_dtype, "ids": [self._ids[i] for i in keep],
                        "texts": [self._texts[i] for i in keep], "enhanced_texts": [self._enh[i] for i in keep],
-                       "metadatas": [self._meta[i] for i in keep]}, f, ensure_ascii=False)
+                       "metadatas": [self._meta[i] for i in keep], "documents": list(self._documents.values())},
+                      f, ensure_ascii=False)
 
     @classmethod
     def load(cls, path: str, device: int = 0) -> "GpuVectorStore":
@@ -822,6 +844,7 @@ class GpuVectorStore(VectorStore):
         n = len(rows["ids"])
         st._ids, st._texts, st._enh = list(rows["ids"]), list(rows["texts"]), list(rows["enhanced_texts"])
         st._meta = [dict(m) for m in rows["metadatas"]]
+        st._documents = {d.get("id", ""): dict(d) for d in rows.get("documents", [])}
         st._alive = [True] * n
         if st.enable_dense:
             d = z["dense"]

@@ -144,6 +144,14 @@ def test_reference_async_transform_and_reranker_seams(reference, monkeypatch):
     assert [d.content for d in out.documents] == docs[:2] and out.documents[0].title == "T0"
     assert all(d.content[h.start:h.end] == h.text for d in out.documents for h in d.highlights)
 
+    # RAG-agnostic adapters (providers.py:40-84): SearchResult -> context dicts -> transform
+    from verbatim_rag.providers import IndexProvider
+
+    ctx = IndexProvider(theirs).retrieve(question, k=3)
+    assert len(ctx) == 3 and all(c["content"] in docs and c["title"].startswith("Doc ") for c in ctx)
+    assert [d.content for d in tr.transform(question, ctx).documents] == [c["content"] for c in ctx]
+    assert asyncio.run(IndexProvider(theirs).retrieve_async(question, k=3)) == ctx
+
     class PairEngine:                                           # cross-encoder stand-in: score = overlap with the question
         max_seqs, max_tokens, max_seq_len, pair_labels = 64, 8192, 512, 1
         shape = types.SimpleNamespace(cls_token_id=1, sep_token_id=2)

@@ -244,6 +244,8 @@ def test_filter_expression_subset():
     assert sel('year == 2021 or document_id == "d3"') == ["d2", "d3"]
     assert sel('not (lang == "en") || year == 2020') == ["d1", "d2"]
     assert sel('(year == 2020 || year == 2021) && lang == "de"') == ["d2"]
-    for bad in ("a > 3", 'metadata["x"] like "y%"', 'document_id == ', 'document_id == "d1" extra', "", '== "d1"'):
+    assert sel("year > 2020") == ["d2"] and sel('metadata["year"] <= 2020 and lang >= "en"') == ["d1"]   # numbers / text order
+    assert sel('year < "3000"') == [] and sel("lang < 5") == []          # a bound only matches metadata of its own kind
+    for bad in ("a >", "a >> 3", "a > [1]", 'metadata["x"] like "y%"', 'document_id == ', 'document_id == "d1" extra', "", '== "d1"'):
         with pytest.raises(ValueError):
             parse_filter(bad)

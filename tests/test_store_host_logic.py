@@ -127,6 +127,8 @@ def test_single_comparison_filters_use_the_value_index(store):
         assert len(r) == min(5, int(want.sum())) and all(pred(x.metadata) for x in r)
     for flt in ('metadata["document_id"] != "d2"', 'not (document_id == "d2")', 'document_id == "d1" or n == 5'):
         assert not hasattr(vs.parse_filter(flt), "lookup")       # general predicates keep the per-row evaluation
+    r = st.query(dense_query=q, top_k=50, search_type="dense", filter='metadata["n"] >= 390 and document_id != "d0"')
+    assert sorted(x.metadata["n"] for x in r) == [n for n in range(390, 400) if n % 3 != 0]                # range comparison
     assert "document_id" in st._value_indexes
     st.add_vectors(["new"], [dense[0].tolist()], [sparse[0]], ["t"], ["e"], [{"document_id": "d2", "n": 1000}])
     assert st._value_indexes == {} and st._mask('metadata["n"] == 1000').sum() == 1

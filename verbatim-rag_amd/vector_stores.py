@@ -317,12 +317,13 @@ def json_serialize_safe(obj: Any) -> Any:
 
 # ---------------------------------------------------------------------------- the store
 _FILTER_TOKEN = re.compile(r"""\s*(?:(?P<meta>metadata\[\s*["'](?P<mkey>[^"']+)["']\s*\])|(?P<str>"[^"]*"|'[^']*')|(?P<num>-?\d+(?:\.\d+)?)"""
-                           r"""|(?P<op>==|!=|&&|\|\||[()\[\],])|(?P<word>\w+))""")
+                           r"""|(?P<op>==|!=|<=|>=|<|>|&&|\|\||[()\[\],])|(?P<word>\w+))""")
 
 
 def parse_filter(expr: str):
     """Compiles the subset of Milvus boolean expressions the store supports into `predicate(metadata: dict) -> bool`:
-    comparisons `field == value`, `field != value`, `field in [v, ...]` (field = `metadata["key"]`, the Local dialect,
+    comparisons `field == value`, `field != value`, `field in [v, ...]`, `field < / <= / > / >= value` (numbers against
+    numeric metadata, quoted strings against text metadata) (field = `metadata["key"]`, the Local dialect,
     or a bare `key`, the Cloud dialect: index.py:735-739; values = quoted strings or numbers, compared as strings like
     the JSON-path match on string metadata), combined with `and` / `&&`, `or` / `||`, `not` and parentheses.
     Anything else raises ValueError -- a filter is never silently ignored."""
@@ -339,7 +340,7 @@ def parse_filter(expr: str):
         elif m.group("str"):
             toks.append(("val", m.group("str")[1:-1]))
         elif m.group("num"):
-            toks.append(("val", m.group("num")))
+            toks.append(("num", m.group("num")))
         elif m.group("op"):
             toks.append(("op", m.group("op")))
         else:
@@ -353,6 +354,8 @@ def parse_filter(expr: str):
     def take(kind=None, value=None):
         nonlocal i
         k, v = peek()
+        if kind == "val" and k == "num":      # a number where a value is expected (compared as text by == / != / in)
+            k = "val"
         if k is None or (kind and k != kind) or (value and v != value):
             raise ValueError(f"GpuVectorStore: unsupported filter {expr!r}")
         i += 1
@@ -388,6 +391,16 @@ def parse_filter(expr: str):
             f = lambda md: str(md.get(key)) in vs    # noqa: E731
             f.lookup = (key, vals)
             return f
+        if op in ("<", "<=", ">", ">="):
+            import operator
+
+            cmp = {"<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}[op]
+            kind, raw = peek()
+            take("val")
+            if kind == "num":       # numeric bound: only numeric metadata values can pass (JSON numbers; bools are not)
+                bound = float(raw)
+                return lambda md: isinstance(md.get(key), (int, float)) and not isinstance(md.get(key), bool) and cmp(md.get(key), bound)
+            return lambda md: isinstance(md.get(key), str) and cmp(md.get(key), raw)   # quoted bound: text order
         raise ValueError(f"GpuVectorStore: unsupported operator {op!r} in filter {expr!r}")
 
     def conjunction():

@@ -1,6 +1,6 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import verbatim_rag_amd
+import verbatim_rag_amd  # noqa: F401  (registers the hyphenated package directory)
 from verbatim_rag_amd import _lib
 lib = _lib.load()
 for (M, N, K) in [(16384, 4096, 4096), (131072, 2304, 768), (131072, 2304, 1536), (32768, 2304, 768)]:

@@ -205,6 +205,52 @@ def topk_recall_check(seed: int = 1234):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def sharded_retrieval_leg(rank: int, world: int, device: int, rows_per_rank: int = 200_000, dim: int = 768, nq: int = 64,
+                          k: int = 10, reps: int = 5):
+    """The exchange step of the path on N > 1 ranks (BASELINE configs[3] at reduced size; north_star: "RCCL all-gather
+    of per-shard top-k for the final merge"): every rank searches its own fp32 row shard on its GPU, ONE
+    all_gather_into_tensor carries the [Q, k] lists, `vrag_topk_merge` merges them on every GPU.  Outside the timed
+    region of the headline metric; returns a small report on rank 0 (never raises)."""
+    try:
+        import torch.distributed as dist
+
+        from verbatim_rag_amd.distributed import ShardedTopK, merge_topk
+        from verbatim_rag_amd.vector_stores import DenseShard
+
+        rng = np.random.default_rng(77 + rank)
+        X = (rng.integers(-64, 65, size=(rows_per_rank, dim)) / 64.0).astype(np.float32)       # dyadic grid: exact sums
+        Q = (np.random.default_rng(5).integers(-64, 65, size=(nq, dim)) / 64.0).astype(np.float32)
+        shard = DenseShard(dim, rows_per_rank, "f32", device)
+        shard.add(X)
+        local = {}
+
+        def search(qs, kk):
+            local["lists"] = shard.search(qs, kk)
+            return local["lists"]
+
+        topk = ShardedTopK(search, shard_base=rank * rows_per_rank, device=device)
+        s, i = topk.search(Q, k)                                                                 # warm-up + the checked result
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            topk.search(Q, k)
+        dist.barrier()
+        dt = (time.perf_counter() - t0) / reps
+        ls, li = local["lists"]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ls, np.where(li >= 0, li + rank * rows_per_rank, -1)))
+        shard.close()
+        if rank != 0:
+            return None
+        hs, hi = merge_topk(np.stack([g[0] for g in gathered]), np.stack([g[1] for g in gathered]).astype(np.int64), k)
+        return {"rows_total": rows_per_rank * world, "dim": dim, "rows_dtype": "f32", "queries": nq, "k": k,
+                "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
+                "collective": f"one all_gather_into_tensor of {nq * k * 12} B per rank ({dist.get_backend()}), merge on every GPU",
+                "merged_equals_host_merge_of_shard_lists": bool(np.array_equal(hi, i) and np.array_equal(hs, s))}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,11 +264,23 @@ def main() -> None:
                     help="base = BASELINE configs[1] (the metric); large = ModernBERT-large geometry (configs[4] extractor), informational")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher the driver would have used (one rank per GPU)
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]])
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # VRAG_BENCH_BACKEND=gloo: harness self-test on a box with fewer GPUs than ranks (ranks share devices, the
@@ -304,6 +362,8 @@ def main() -> None:
         iso = eng.read_profile(reset=True)
         eng.set_concurrency(2)
 
+    sharded = sharded_retrieval_leg(rank, world, local_rank) if world > 1 else None
+
     if rank == 0:
         total_chunks = world * n_chunks * args.steps
         value = total_chunks / elapsed
@@ -311,58 +371,56 @@ def main() -> None:
         roof = None
         breakdown = {k: {"ms_per_step": v[0] / max(1, args.steps), "launches_per_step": v[1] / max(1, args.steps)}
                      for k, v in prof.items() if v[1] > 0}
-        def tflops(pr, steps):
+        # Kernel classes by rocprofv3 kernel name: both residual GEMMs (attention Wo, mlp Wo) are ONE instantiation.
+        classes = {
+            "vrag::gemm_bf16_kernel<EPI_QKV_ROPE> (Wqkv + RoPE + V^T)": ["gemm_qkv"],
+            "vrag::gemm_bf16_kernel<EPI_RESIDUAL> (attn Wo + mlp Wo, fp32 residual RMW)": ["gemm_wo", "gemm_wo_mlp"],
+            "vrag::gemm_bf16_kernel<EPI_GEGLU> (Wi + GeGLU)": ["gemm_wi"],
+        }
+
+        def class_stats(pr, steps):
             out = {}
-            for k, f in fl.items():
-                ms, n = pr.get(k, (0.0, 0))
+            for name, keys in classes.items():
+                ms = sum(pr.get(k, (0.0, 0))[0] for k in keys)
+                n = sum(pr.get(k, (0.0, 0))[1] for k in keys)
+                fl_tot = sum(fl[k] for k in keys) * steps
                 if n > 0 and ms > 0:
-                    out[k] = f * steps / (ms * 1e-3) / 1e12
+                    out[name] = {"tflops": fl_tot / (ms * 1e-3) / 1e12, "avg_launch_ms": ms / n, "ms_per_step": ms / steps,
+                                 "flop_per_launch": fl_tot / n}
             return out
 
-        gemm_tf = tflops(prof, args.steps)
-        kname = {"gemm_qkv": "vrag::gemm_bf16_kernel<5, 256, 256, 2, 4, 0> (EPI_QKV_ROPE)",
-                 "gemm_wo": "vrag::gemm_bf16_kernel<3, 256, 256, 2, 4, 0> (EPI_RESIDUAL)",
-                 "gemm_wi": "vrag::gemm_bf16_kernel<4, 256, 256, 2, 4, 0> (EPI_GEGLU)",
-                 "gemm_wo_mlp": "vrag::gemm_bf16_kernel<3, 256, 256, 2, 4, 0> (EPI_RESIDUAL)"}
-        if gemm_tf:
-            # dominant GEMM class = largest summed time in the single-stream pass (stable run to run; the two-stream
-            # event times of the timed region include cross-stream waiting and reshuffle between runs)
-            rank_src = iso if iso else prof
-            dom = max(fl.keys(), key=lambda k: rank_src.get(k, (0.0, 0))[0])
-            ms, n = prof[dom]
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tpath):
+        timed_cls = class_stats(prof, args.steps)
+        if timed_cls:
+            dom = max(timed_cls, key=lambda c: timed_cls[c]["ms_per_step"])       # largest summed time in the TIMED region
+            t = timed_cls[dom]
+            traffic, traffic_src = None, None
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+            if cands:      # PMC passes cannot run inside this process: the newest committed summary of tools/profile_round.sh
                 try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                    tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+                    keys = classes[dom]
+                    vals = [tj[k]["hbm_bytes_per_launch"] for k in keys if k in tj and tj[k].get("hbm_bytes_per_launch")]
+                    if vals:
+                        traffic, traffic_src = float(np.mean(vals)), cands[-1]
                 except Exception:
                     traffic = None
-            timed = {
-                "achieved": gemm_tf[dom], "frac": gemm_tf[dom] / PEAK_BF16_TFLOPS, "avg_launch_ms": ms / n,
-                "all_gemm_tflops": gemm_tf,
-                "note": "HIP events on the launch streams over the timed region: the micro-batches alternate between two "
-                        "streams there, so an event pair also spans the time a launch waits for / shares CUs with the "
-                        "other stream's kernel (rocprofv3 dispatch durations exclude the wait)",
-            }
-            src, src_ms, src_n, src_tf, phase = timed, ms, n, gemm_tf, "timed region (two streams)"
-            iso_obj = None
-            if iso:
-                iso_tf = tflops(iso, 2)
-                ims, inn = iso[dom]
-                iso_obj = {"achieved": iso_tf[dom], "frac": iso_tf[dom] / PEAK_BF16_TFLOPS, "avg_launch_ms": ims / inn,
-                           "all_gemm_tflops": iso_tf,
-                           "breakdown_ms_per_step": {k: v[0] / 2 for k, v in iso.items() if v[1] > 0}}
-                src, src_tf = iso_obj, iso_tf
-                phase = ("single-stream pass of the same step and micro-batches, run by bench.py right after the timed "
-                         "region (events bracket the kernel alone; matches the rocprofv3 dispatch durations of that pass)")
             roof = {
-                "bound": "mfma", "kernel": kname[dom], "achieved": src["achieved"], "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": src["frac"], "traffic": traffic,
-                "avg_launch_ms": src["avg_launch_ms"], "flop_per_launch": fl[dom] * args.steps / n,
-                "all_gemm_tflops": src_tf, "phase": phase, "timed_region": timed,
+                "bound": "mfma", "kernel": dom, "achieved": t["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": t["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": t["avg_launch_ms"], "flop_per_launch": t["flop_per_launch"],
+                "phase": "timed region: HIP events recorded on the launch stream around every launch of the class "
+                         "(vrag_encoder_set_profiling), averaged over the timed steps",
+                "all_classes_timed_region": {c: {"tflops": v["tflops"], "frac": v["tflops"] / PEAK_BF16_TFLOPS,
+                                                 "avg_launch_ms": v["avg_launch_ms"]} for c, v in timed_cls.items()},
             }
-            if iso_obj:
-                roof["breakdown_ms_per_step"] = iso_obj["breakdown_ms_per_step"]
+            if iso:
+                iso_cls = class_stats(iso, 2)
+                roof["isolated_pass"] = {
+                    "note": "same step, micro-batches serialised on one stream, run right after the timed region",
+                    "classes": {c: {"tflops": v["tflops"], "frac": v["tflops"] / PEAK_BF16_TFLOPS,
+                                    "avg_launch_ms": v["avg_launch_ms"]} for c, v in iso_cls.items()},
+                    "breakdown_ms_per_step": {k: v[0] / 2 for k, v in iso.items() if v[1] > 0}}
         cpu, parity, recall = None, None, None
         if world == 1 and args.cpu_budget > 0:
             recall = topk_recall_check()
@@ -382,7 +440,7 @@ def main() -> None:
             "model_tflops": value * chunk_flops(shape) / 1e12,
             "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roof, "cpu_baseline": cpu, "parity_max_abs_err_vs_oracle": parity,
-            "topk_recall_vs_cpu_ref": recall,
+            "topk_recall_vs_cpu_ref": recall, "sharded_topk": sharded,
             "breakdown": breakdown,
         }
         print(json.dumps(out))

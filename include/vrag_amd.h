@@ -37,7 +37,7 @@ extern "C" {
 #define VRAG_ERR_CAPACITY (-3)/* batch does not fit the workspace the handle was created with */
 #define VRAG_ERR_NO_DEVICE (-4)
 
-#define VRAG_ABI_VERSION 2
+#define VRAG_ABI_VERSION 3
 
 typedef struct vrag_encoder vrag_encoder;
 
@@ -264,6 +264,17 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
                              const float* q_values, int32_t nq, int32_t k, float* scores /*[nq,k]*/,
                              int64_t* ids /*[nq,k]*/, void* stream);
 int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k, void* stream);
+
+/* Cross-shard merge of per-shard top-k lists (the reference has no sharding -- this is the step after the
+ * all-gather of `[n_lists][nq][k_in]` (fp32 score, global row id) lists, each sorted by (score desc, id asc) with
+ * id = -1 entries as a tail).  Writes the first k_out entries of the merged order per query (-inf / -1 padded).
+ * Global ids must be < 2^32 and unique across lists.  `*_list_stride`: bytes between consecutive lists (0 = dense,
+ * nq*k_in elements) -- lets the gathered buffer of one packed all-gather ([ids | scores] per rank) be merged in
+ * place.  on_device = 1: all four pointers are device memory on `device` and the kernel is only enqueued on
+ * `stream`; on_device = 0: host pointers, the call copies in and out and synchronises. */
+int vrag_topk_merge(const float* scores, const int64_t* ids, int32_t n_lists, int32_t nq, int32_t k_in, int32_t k_out,
+                    int64_t score_list_stride, int64_t id_list_stride, float* out_scores, int64_t* out_ids,
+                    int32_t on_device, int32_t device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,8 @@
-"""N>1 path on CPU: world_size 2, gloo.  Sharding + ONE all-gather of per-shard top-k + merge."""
+"""N>1 path on CPU: world_size 2, gloo.  Sharding + ONE all-gather of per-shard top-k + merge, first on the bare
+`ShardedTopK` wrapper, then through a row-sharded `GpuVectorStore` (the reference's `VectorStore.query` call site,
+verbatim_rag/index.py:552-655 -> vector_stores/milvus_base.py:236-280).  No GPU here: the local searches are CPU
+stand-ins answering from the exact oracle and the merge is the host statement `merge_topk`; tests/test_sharded_gpu.py
+runs the same store test with the HIP shards and the device-side merge."""
 import os
 import sys
 
@@ -23,59 +27,111 @@ def test_merge_topk_total_order():
     i = np.array([[[7, 9, -1]], [[4, 8, 2]]], np.int64)
     ms, mi = merge_topk(s, i, 4)
     assert mi.tolist() == [[4, 7, 8, 9]] and ms.tolist() == [[3.0, 3.0, 2.5, 2.0]]   # tie 3.0 -> id asc
+    ms, mi = merge_topk(s, i, 7)                                                     # more than there is: -1 / -inf tail
+    assert mi.tolist() == [[4, 7, 8, 9, 2, -1, -1]] and ms[0, 5:].tolist() == [-np.inf, -np.inf]
+
+
+def test_merge_topk_matches_a_per_query_sort():
+    rng = np.random.default_rng(5)
+    W, Q, k = 5, 37, 9
+    s = (rng.integers(-8, 9, (W, Q, k)) / 8).astype(np.float32)
+    i = np.stack([rng.permutation(1000)[: Q * k].reshape(Q, k) + 1000 * w for w in range(W)]).astype(np.int64)
+    i[rng.random((W, Q, k)) < 0.2] = -1
+    ms, mi = merge_topk(s, i, 12)
+    for q in range(Q):
+        pairs = sorted(((-float(s[w, q, j]), int(i[w, q, j])) for w in range(W) for j in range(k) if i[w, q, j] >= 0))[:12]
+        assert [p[1] for p in pairs] == [int(x) for x in mi[q] if x >= 0]
+        assert [-p[0] for p in pairs] == [float(x) for x, y in zip(ms[q], mi[q]) if y >= 0]
 
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
-    import torch.distributed as dist
+    try:
+        import torch.distributed as dist
 
-    import verbatim_rag_amd  # noqa: F401
-    from oracle import topk_ref as T
-    from verbatim_rag_amd.distributed import ShardedTopK, shard_range
+        import verbatim_rag_amd  # noqa: F401
+        from oracle import topk_ref as T
+        from verbatim_rag_amd.distributed import ShardedTopK, merge_topk, shard_range
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(0)
-    X = rng.integers(-64, 65, size=(3001, 64)).astype(np.float32) / 64     # dyadic grid: sums exact in any order
-    Q = rng.integers(-64, 65, size=(5, 64)).astype(np.float32) / 64
-    lo, hi = shard_range(len(X), rank, world)
-    st = ShardedTopK(lambda qs, k: T.dense_topk(X[lo:hi], qs, k), shard_base=lo)
-    s, i = st.search(Q, 7)
-    rs, ri = T.dense_topk(X, Q, 7)
-    ok = bool(np.array_equal(i, ri) and np.array_equal(s, rs))
-    # sparse rows sharded the same way; query 1 matches a single document (one shard returns only -1 rows), k = 70
-    # exceeds one device pass and most queries' hit counts
-    V, n = 200, 1501
-    lens = rng.integers(1, 6, n)
-    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    idx = np.concatenate([np.sort(rng.choice(V - 1, int(m), replace=False)) for m in lens]).astype(np.int32)
-    val = (rng.integers(1, 5, len(idx)) / 4).astype(np.float32)
-    idx[indptr[1400]] = V - 1                                   # the only document with term V-1
-    qp = np.asarray([0, 3, 4, 6], np.int64)
-    qi = np.asarray([3, 50, 120, V - 1, 7, 9], np.int32)
-    qv = np.asarray([1.0, 0.5, 2.0, 1.0, 0.25, 1.5], np.float32)
-    lo, hi = shard_range(n, rank, world)
-    sub = (indptr[lo:hi + 1] - indptr[lo], idx[indptr[lo]:indptr[hi]], val[indptr[lo]:indptr[hi]])
-    sp = ShardedTopK(lambda qs, k: T.sparse_topk(*sub, V, *qs, k), shard_base=lo)
-    for k in (5, 70):
-        s2, i2 = sp.search((qp, qi, qv), k)
-        rs2, ri2 = T.sparse_topk(indptr, idx, val, V, qp, qi, qv, k)
-        ok = ok and bool(np.array_equal(i2, ri2) and np.array_equal(s2, rs2)) and i2[1, 0] == 1400 and (i2[1, 1:] == -1).all()
-    q.put((rank, ok))
-    dist.barrier()
-    dist.destroy_process_group()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rng = np.random.default_rng(0)
+        X = rng.integers(-64, 65, size=(3001, 64)).astype(np.float32) / 64     # dyadic grid: sums exact in any order
+        Q = rng.integers(-64, 65, size=(5, 64)).astype(np.float32) / 64
+        lo, hi = shard_range(len(X), rank, world)
+        st = ShardedTopK(lambda qs, k: T.dense_topk(X[lo:hi], qs, k), shard_base=lo, merge=merge_topk)
+        s, i = st.search(Q, 7)
+        rs, ri = T.dense_topk(X, Q, 7)
+        ok = bool(np.array_equal(i, ri) and np.array_equal(s, rs))
+        # sparse rows sharded the same way; query 1 matches a single document (one shard returns only -1 rows), k = 70
+        # exceeds one device pass and most queries' hit counts
+        V, n = 200, 1501
+        lens = rng.integers(1, 6, n)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        idx = np.concatenate([np.sort(rng.choice(V - 1, int(m), replace=False)) for m in lens]).astype(np.int32)
+        val = (rng.integers(1, 5, len(idx)) / 4).astype(np.float32)
+        idx[indptr[1400]] = V - 1                                   # the only document with term V-1
+        qp = np.asarray([0, 3, 4, 6], np.int64)
+        qi = np.asarray([3, 50, 120, V - 1, 7, 9], np.int32)
+        qv = np.asarray([1.0, 0.5, 2.0, 1.0, 0.25, 1.5], np.float32)
+        lo, hi = shard_range(n, rank, world)
+        sub = (indptr[lo:hi + 1] - indptr[lo], idx[indptr[lo]:indptr[hi]], val[indptr[lo]:indptr[hi]])
+        sp = ShardedTopK(lambda qs, k: T.sparse_topk(*sub, V, *qs, k), shard_base=lo, merge=merge_topk)
+        for k in (5, 70):
+            s2, i2 = sp.search((qp, qi, qv), k)
+            rs2, ri2 = T.sparse_topk(indptr, idx, val, V, qp, qi, qv, k)
+            ok = ok and bool(np.array_equal(i2, ri2) and np.array_equal(s2, rs2)) and i2[1, 0] == 1400 and (i2[1, 1:] == -1).all()
+        q.put((rank, ok))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:   # never leave the parent waiting for its timeout
+        import traceback
+
+        q.put((rank, f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
 
 
-def test_sharded_topk_world2_gloo():
+def _run_world(target, world=2, timeout=240):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, True), (1, True)]
+    return sorted(res)
+
+
+def test_sharded_topk_world2_gloo():
+    assert _run_world(_worker) == [(0, True), (1, True)]
+
+
+def _store_worker(rank, world, port, q):
+    """A row-sharded GpuVectorStore (stand-in shards, host merge) must answer exactly like a single-rank store."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    try:
+        import torch.distributed as dist
+
+        import verbatim_rag_amd  # noqa: F401
+        from tests.sharded_store_cases import build_and_query, cpu_stand_ins
+        from verbatim_rag_amd.distributed import ShardComm, merge_topk
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with cpu_stand_ins():
+            sharded = build_and_query(comm=ShardComm(merge=merge_topk))
+            single = build_and_query(comm=None)
+        q.put((rank, sharded == single or "sharded store answers differ from the single-rank store"))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
+
+
+def test_sharded_store_world2_gloo_equals_single_rank():
+    assert _run_world(_store_worker) == [(0, True), (1, True)]

@@ -10,36 +10,7 @@ from oracle import topk_ref as T
 from verbatim_rag_amd import vector_stores as vs
 
 
-class _Dense:
-    def __init__(self, dim, capacity, dtype="bf16", device=0):
-        self.rows = np.zeros((0, dim), np.float32)
-
-    def add(self, rows):
-        self.rows = np.concatenate([self.rows, np.asarray(rows, np.float32)])
-
-    def search(self, queries, k, stream=None):
-        kk = min(k, len(self.rows))
-        s, i = T.dense_topk(self.rows, np.asarray(queries, np.float32), kk)
-        pad = k - kk
-        return np.pad(s, ((0, 0), (0, pad))), np.pad(i, ((0, 0), (0, pad)), constant_values=-1)
-
-    def close(self):
-        pass
-
-
-class _Sparse:
-    def __init__(self, vocab, indptr, indices, values, device=0):
-        self.vocab, self.csr = vocab, (indptr, indices, values)
-
-    def search(self, queries, k, stream=None):
-        n = len(self.csr[0]) - 1
-        kk = min(k, n)
-        s, i = T.sparse_topk(*self.csr, self.vocab, *vs.dicts_to_csr(list(queries)), kk)
-        pad = k - kk
-        return np.pad(s, ((0, 0), (0, pad))), np.pad(i, ((0, 0), (0, pad)), constant_values=-1)
-
-    def close(self):
-        pass
+from tests.sharded_store_cases import CpuDense as _Dense, CpuSparse as _Sparse  # noqa: E402
 
 
 @pytest.fixture()
@@ -174,9 +145,9 @@ def test_query_normalisation_is_the_same_row_by_row_or_batched(store):
     st._dense.search = lambda q, k, stream=None: (seen.append(np.array(q)), (np.zeros((len(q), k), np.float32), np.full((len(q), k), -1, np.int64)))[1]
     X = rng.standard_normal((50, 64)).astype(np.float32) * np.float32(3)
     X[7] = 0
-    st._device_topk("dense", st._dense, X.tolist(), 3)
+    st._device_topk("dense", st._dense, st._main_rows, X.tolist(), 3)
     for i in range(len(X)):
-        st._device_topk("dense", st._dense, [X[i].tolist()], 3)
+        st._device_topk("dense", st._dense, st._main_rows, [X[i].tolist()], 3)
     want = np.stack([q / float(np.sqrt((q * q).sum(dtype=np.float32))) if q.any() else q for q in X])
     assert np.array_equal(seen[0], want) and all(np.array_equal(seen[1 + i][0], want[i]) for i in range(len(X)))
 
@@ -277,3 +248,37 @@ def test_metadata_is_stored_the_way_the_json_column_sees_it(store, tmp_path):
     assert [x.id for x in r] == ["x1"] and r[0].metadata["created"] == "2026-01-02T03:04:05"
     st.save(str(tmp_path / "s"))                                           # json.dump would reject the raw objects
     assert vs.GpuVectorStore.load(str(tmp_path / "s"))._meta[-1] == got
+
+
+def test_a_failed_insert_leaves_the_store_unchanged(store):
+    """a short or malformed vector list must not leave ids one row ahead of the vectors."""
+    st, dense, sparse, rng = store
+    before = (len(st._ids), len(st._dense_rows), len(st._sparse_rows), len(st._owned))
+    with pytest.raises(ValueError):
+        st.add_vectors(["b", "c"], [dense[1].tolist()], [sparse[1], sparse[2]], ["tb", "tc"], ["eb", "ec"], [{}, {}])
+    with pytest.raises(ValueError):
+        st.add_vectors(["b"], [dense[1][:10].tolist()], [sparse[1]], ["tb"], ["eb"], [{}])          # wrong dimension
+    with pytest.raises(ValueError):
+        st.add_vectors(["b"], [dense[1].tolist()], [{99999: 1.0}], ["tb"], ["eb"], [{}])             # term outside the vocabulary
+    assert (len(st._ids), len(st._dense_rows), len(st._sparse_rows), len(st._owned)) == before
+    st.add_vectors(["d"], [dense[3].tolist()], [sparse[3]], ["td"], ["ed"], [{"document_id": "dd"}])
+    r = st.query(dense_query=dense[3].tolist(), top_k=2, search_type="dense")
+    assert {x.id for x in r} == {"id3", "d"} and all(abs(x.score - 1.0) < 1e-6 for x in r)
+    with pytest.raises(ValueError, match="at most 1024"):
+        st.query(dense_query=dense[3].tolist(), top_k=2000, search_type="dense")
+
+
+def test_filter_comparisons_are_typed_like_json(store):
+    st, dense, sparse, rng = store
+    st.add_vectors(["x1", "x2", "x3"], dense[:3].tolist(), sparse[:3], ["a", "b", "c"], ["a", "b", "c"],
+                   [{"year": 2020, "flag": True, "tag": "5"}, {"year": 2020.0, "flag": False, "tag": 5}, {"other": 1}])
+    ids = lambda flt: sorted(st._ids[i] for i in np.nonzero(st._mask(flt))[0] if st._ids[i].startswith("x"))   # noqa: E731
+    assert ids('metadata["year"] == 2020.0') == ["x1", "x2"]           # int 2020 equals 2020.0
+    assert ids('metadata["year"] == 2.02e3') == ["x1", "x2"]           # exponent literal
+    assert ids('metadata["tag"] == "5"') == ["x1"] and ids('metadata["tag"] == 5') == ["x2"]
+    assert ids('metadata["flag"] == true') == ["x1"] and ids('flag == false') == ["x2"]
+    assert ids('metadata["year"] == "None"') == []                     # a missing key equals nothing
+    assert ids('metadata["year"] != 2020') == ["x3"]
+    assert ids('metadata["tag"] in ["5", 5]') == ["x1", "x2"]
+    with pytest.raises(ValueError):
+        vs.parse_filter('metadata["flag"] > true')

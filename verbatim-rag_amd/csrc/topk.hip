@@ -953,6 +953,51 @@ static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u6
   return hipGetLastError();
 }
 
+// Cross-shard merge (the step after the all-gather of per-shard top-k lists).  One wave per query: lane w
+// walks list w (sorted by (score desc, id asc), -1 ids as a tail); every round the largest head wins and advances.
+// `ids` are GLOBAL row ids (< 2^32), so keys of different shards never collide.
+__global__ __launch_bounds__(64) void topk_merge_shards_kernel(const char* __restrict__ scores, const char* __restrict__ ids,
+                                                               int n_lists, int nq, int k_in, int k_out,
+                                                               long long score_stride, long long id_stride,   // bytes between lists
+                                                               float* __restrict__ out_scores, long long* __restrict__ out_ids) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  // lists beyond 64 are folded round-robin: lane w owns lists w, w+64, ... and merges them as it goes
+  int head[4] = {0, 0, 0, 0};
+  auto key_at = [&](int list, int pos) -> u64 {
+    if (list >= n_lists || pos >= k_in) return 0ull;
+    const size_t at = (size_t)q * k_in + pos;
+    const long long id = reinterpret_cast<const long long*>(ids + (size_t)list * id_stride)[at];
+    return id < 0 ? 0ull : make_key(reinterpret_cast<const float*>(scores + (size_t)list * score_stride)[at], (unsigned)id);
+  };
+  for (int i = 0; i < k_out; ++i) {
+    u64 best = 0ull;
+    int slot = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u64 v = key_at(lane + 64 * s, head[s]);
+      if (v > best) {
+        best = v;
+        slot = s;
+      }
+    }
+    u64 win = best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const u64 other = __shfl_xor(win, o, 64);
+      win = other > win ? other : win;
+    }
+    if (win != 0ull && best == win) {   // global ids are unique: exactly one lane owns the winning key
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (s == slot) ++head[s];
+    }
+    if (lane == 0) {
+      out_scores[(size_t)q * k_out + i] = win ? unorderable((unsigned)(win >> 32)) : -INFINITY;
+      out_ids[(size_t)q * k_out + i] = win ? (long long)(0xFFFFFFFFu - (unsigned)(win & 0xFFFFFFFFu)) : -1ll;
+    }
+  }
+}
+
 }  // namespace vrag
 
 using namespace vrag;
@@ -1510,6 +1555,56 @@ int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k,
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
   int n_wg = 0;
   return sparse_launch(ix, nq, k, st, &n_wg);
+}
+
+// Device-side merge of per-shard top-k lists (the step after the all-gather).
+int vrag_topk_merge(const float* scores, const int64_t* ids, int32_t n_lists, int32_t nq, int32_t k_in, int32_t k_out,
+                    int64_t score_list_stride, int64_t id_list_stride, float* out_scores, int64_t* out_ids, int32_t on_device,
+                    int32_t device, void* stream) {
+  ARG_CHECK(scores && ids && out_scores && out_ids, "null argument");
+  ARG_CHECK(n_lists >= 1 && n_lists <= 256 && nq >= 1 && k_in >= 1 && k_out >= 1, "bad list geometry (1 <= n_lists <= 256)");
+  if (vrag_device_count() <= device) {
+    set_error("no HIP device %d visible (no CPU fallback)", device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t per = (size_t)nq * k_in, n_out = (size_t)nq * k_out;
+  const long long ss = score_list_stride > 0 ? score_list_stride : (long long)per * 4;
+  const long long is = id_list_stride > 0 ? id_list_stride : (long long)per * 8;
+  ARG_CHECK(ss >= (long long)per * 4 && ss % 4 == 0 && is >= (long long)per * 8 && is % 8 == 0, "bad list strides");
+  if (on_device) {
+    hipLaunchKernelGGL(topk_merge_shards_kernel, dim3(nq), dim3(64), 0, st, reinterpret_cast<const char*>(scores),
+                       reinterpret_cast<const char*>(ids), n_lists, nq, k_in, k_out, ss, is, out_scores,
+                       reinterpret_cast<long long*>(out_ids));
+    HIP_TRY(hipGetLastError());
+    return VRAG_OK;
+  }
+  for (int l = 0; l < n_lists; ++l) {
+    const int64_t* li = reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids) + (size_t)l * is);
+    for (size_t i = 0; i < per; ++i)
+      ARG_CHECK(li[i] < 0xFFFFFFFFll, "row id %lld does not fit the 32-bit key field", (long long)li[i]);
+  }
+  char* buf = nullptr;
+  const size_t in_i = (size_t)(n_lists - 1) * is + per * 8, in_s = (size_t)(n_lists - 1) * ss + per * 4;
+  const size_t off_oi = (in_i + 7) / 8 * 8, off_s = off_oi + n_out * 8, off_os = off_s + (in_s + 7) / 8 * 8;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), off_os + n_out * 4));
+  char* d_ids = buf;
+  long long* d_oids = reinterpret_cast<long long*>(buf + off_oi);
+  char* d_sc = buf + off_s;
+  float* d_osc = reinterpret_cast<float*>(buf + off_os);
+  hipError_t e = hipMemcpyAsync(d_ids, ids, in_i, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_sc, scores, in_s, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(topk_merge_shards_kernel, dim3(nq), dim3(64), 0, st, d_sc, d_ids, n_lists, nq, k_in, k_out, ss, is, d_osc, d_oids);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_oids, n_out * 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_osc, n_out * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  HIP_TRY(e);
+  return VRAG_OK;
 }
 
 }  // extern "C"

@@ -2,15 +2,17 @@
 
 * Extraction / embedding: every (question, chunk) pair is independent -> `shard_range` splits the
   units contiguously over ranks, full weight replica per GPU, NO data-path collective.
-* Retrieval: the corpus is row-sharded (rank r owns rows [base_r, base_r + n_r)); queries are
-  replicated; each rank computes its local top-k; ONE all-gather per query batch carries
-  `[Q, k]` (fp32 score, i64 id) pairs over RCCL/xGMI (a few KB..MB: latency-bound), then every
-  rank merges the world_size lists with the total order (score desc, id asc).
+* Retrieval: the corpus is row-sharded; queries are replicated (every rank runs the same call, SPMD);
+  each rank computes its local top-k on its own GPU; ONE all-gather per query batch carries the
+  `[Q, k]` (global row id, fp32 score) lists over RCCL/xGMI (a few KB..MB: latency-bound), then every
+  rank merges the world_size sorted lists ON ITS GPU (`vrag_topk_merge`, include/vrag_amd.h) with the
+  total order (score desc, id asc).
 The reference has no distributed code at all; this is new, not a translation.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes as C
+from typing import Callable, Optional, Tuple
 
 import numpy as np
 
@@ -23,46 +25,125 @@ def shard_range(n_units: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def merge_topk(scores: np.ndarray, ids: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
-    """scores/ids: [W, Q, k] per-shard lists (id -1 = empty) -> [Q, k] merged by (score desc, id asc)."""
+    """Host statement of the merge (tests and CPU-only tooling; the product merges on the GPU):
+    scores/ids `[W, Q, k_in]` per-shard lists (id -1 = empty) -> `[Q, k]` by (score desc, id asc).  One lexsort for the
+    whole batch, no per-query Python loop."""
     W, Q, kk = scores.shape
-    s = scores.transpose(1, 0, 2).reshape(Q, W * kk)
-    i = ids.transpose(1, 0, 2).reshape(Q, W * kk)
-    out_s = np.full((Q, k), -np.inf, np.float32)
-    out_i = np.full((Q, k), -1, np.int64)
-    for q in range(Q):
-        valid = i[q] >= 0
-        sq, iq = s[q][valid], i[q][valid]
-        order = np.lexsort((iq, -sq.astype(np.float64)))[:k]
-        out_s[q, : len(order)] = sq[order]
-        out_i[q, : len(order)] = iq[order]
+    s = np.ascontiguousarray(scores.transpose(1, 0, 2)).reshape(Q, W * kk).astype(np.float32)
+    i = np.ascontiguousarray(ids.transpose(1, 0, 2)).reshape(Q, W * kk).astype(np.int64)
+    empty = i < 0
+    sort_s = np.where(empty, -np.inf, s).astype(np.float64)
+    sort_i = np.where(empty, np.iinfo(np.int64).max, i)
+    order = np.lexsort((sort_i, -sort_s), axis=1)[:, :k]      # last key is primary: score desc, then id asc; empties last
+    out_s = np.take_along_axis(np.where(empty, -np.inf, s).astype(np.float32), order, axis=1)
+    out_i = np.take_along_axis(np.where(empty, -1, i), order, axis=1)
+    if out_s.shape[1] < k:
+        pad = k - out_s.shape[1]
+        out_s = np.pad(out_s, ((0, 0), (0, pad)), constant_values=-np.inf)
+        out_i = np.pad(out_i, ((0, 0), (0, pad)), constant_values=-1)
     return out_s, out_i
 
 
-class ShardedTopK:
-    """Wraps a local search callable `local(queries, k) -> (scores[Q,k], local_ids[Q,k])`."""
+def merge_topk_device(scores: np.ndarray, ids: np.ndarray, k: int, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """`merge_topk` on the GPU from host arrays (`vrag_topk_merge`, on_device = 0)."""
+    from . import _lib
 
-    def __init__(self, local_search, shard_base: int, group=None, device: Optional[str] = None):
+    lib = _lib.load()
+    W, Q, kk = scores.shape
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    i = np.ascontiguousarray(ids, dtype=np.int64)
+    out_s = np.empty((Q, k), np.float32)
+    out_i = np.empty((Q, k), np.int64)
+    _lib.check("vrag_topk_merge", lib.vrag_topk_merge(
+        s.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p), W, Q, kk, k, 0, 0,
+        out_s.ctypes.data_as(C.c_void_p), out_i.ctypes.data_as(C.c_void_p), 0, device, None))
+    return out_s, out_i
+
+
+class ShardComm:
+    """The exchange step of sharded retrieval: one all-gather of packed `[Q, k]` lists + the merge.
+
+    `group`: a torch.distributed process group (None = the default group; torch.distributed must be initialised).
+    backend "nccl" (= RCCL on ROCm): the payload and the gathered lists stay in HBM and `vrag_topk_merge` runs on them
+    in place; backend "gloo" (CPU tests, or ranks sharing one GPU): host tensors, the merge still runs on the GPU
+    unless `merge` is given (CPU-only test boxes pass `merge=merge_topk`)."""
+
+    def __init__(self, group=None, device: int = 0, merge: Optional[Callable] = None):
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("ShardComm needs an initialised torch.distributed process group")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        self.device = device
+        self._merge = merge
+
+    def allgather_merge(self, scores: np.ndarray, ids: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Local lists `[Q, k_in]` (GLOBAL ids, -1 = empty) of every rank -> merged `[Q, k]`, identical on all ranks."""
+        import torch
+        import torch.distributed as dist
+
+        Q, kk = scores.shape
+        n = Q * kk
+        nbytes = (n * 12 + 7) // 8 * 8                          # [ids i64 x n | scores f32 x n | pad]
+        payload = np.zeros(nbytes, np.uint8)
+        payload[: n * 8] = np.ascontiguousarray(ids, dtype=np.int64).view(np.uint8).reshape(-1)
+        payload[n * 8: n * 12] = np.ascontiguousarray(scores, dtype=np.float32).view(np.uint8).reshape(-1)
+        on_gpu = self.backend == "nccl"
+        t = torch.from_numpy(payload)
+        if on_gpu:
+            t = t.to(torch.device("cuda", self.device), non_blocking=True)
+        flat = torch.empty(self.world * nbytes, dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(flat, t, group=self.group)          # THE collective of the retrieval path
+        gathered = flat.view(self.world, nbytes)
+        if self._merge is not None:
+            g = gathered.cpu().numpy()
+            all_i = np.stack([g[w, : n * 8].view(np.int64).reshape(Q, kk) for w in range(self.world)])
+            all_s = np.stack([g[w, n * 8: n * 12].view(np.float32).reshape(Q, kk) for w in range(self.world)])
+            return self._merge(all_s, all_i, k)
+        from . import _lib
+
+        lib = _lib.load()
+        out_s = np.empty((Q, k), np.float32)
+        out_i = np.empty((Q, k), np.int64)
+        if on_gpu:
+            d_out_s = torch.empty((Q, k), dtype=torch.float32, device=t.device)
+            d_out_i = torch.empty((Q, k), dtype=torch.int64, device=t.device)
+            base = gathered.data_ptr()
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+            _lib.check("vrag_topk_merge", lib.vrag_topk_merge(
+                C.c_void_p(base + n * 8), C.c_void_p(base), self.world, Q, kk, k, nbytes, nbytes,
+                C.c_void_p(d_out_s.data_ptr()), C.c_void_p(d_out_i.data_ptr()), 1, self.device, C.c_void_p(stream)))
+            return d_out_s.cpu().numpy(), d_out_i.cpu().numpy()
+        g = np.ascontiguousarray(gathered.numpy())
+        base = g.ctypes.data
+        _lib.check("vrag_topk_merge", lib.vrag_topk_merge(
+            C.c_void_p(base + n * 8), C.c_void_p(base), self.world, Q, kk, k, nbytes, nbytes,
+            out_s.ctypes.data_as(C.c_void_p), out_i.ctypes.data_as(C.c_void_p), 0, self.device, None))
+        return out_s, out_i
+
+
+class ShardedTopK:
+    """Wraps a local search callable `local(queries, k) -> (scores[Q,k], local_ids[Q,k])` over the contiguous row range
+    starting at `shard_base`; `search` returns the global top-k (identical on every rank)."""
+
+    def __init__(self, local_search, shard_base: int, group=None, device: int = 0, merge: Optional[Callable] = None):
         self.local_search = local_search
         self.shard_base = int(shard_base)
         self.group = group
         self.device = device
+        self._merge = merge
+        self._comm: Optional[ShardComm] = None
 
     def search(self, queries, k: int) -> Tuple[np.ndarray, np.ndarray]:
-        import torch
         import torch.distributed as dist
 
         scores, ids = self.local_search(queries, k)
         ids = np.where(ids >= 0, ids + self.shard_base, -1).astype(np.int64)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
-            return merge_topk(scores[None], ids[None], k)
-        world = dist.get_world_size(self.group)
-        dev = self.device or ("cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
-        # one all-gather per query batch: pack (score bits, id) into one int64 tensor [Q, k, 2]
-        payload = np.stack([scores.astype(np.float32).view(np.int32).astype(np.int64), ids], axis=-1)
-        t = torch.from_numpy(payload).to(dev)
-        gathered = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t, group=self.group)
-        g = torch.stack(gathered).cpu().numpy()
-        all_scores = g[..., 0].astype(np.int32).view(np.float32)
-        all_ids = g[..., 1]
-        return merge_topk(all_scores, all_ids, k)
+            return np.where(ids >= 0, scores, -np.inf).astype(np.float32), ids
+        if self._comm is None:
+            self._comm = ShardComm(self.group, self.device, self._merge)
+        return self._comm.allgather_merge(scores, ids, k)

@@ -71,119 +71,138 @@ class VectorStore(ABC):
         pass
 
 
-# ---------------------------------------------------------------------------- hybrid_search.py
+# ---------------------------------------------------------------------------- rank fusion
+# The reference fuses per-method hit lists with weighted reciprocal-rank fusion (vector_stores/hybrid_search.py:15-175).
+# Here ONE array routine (`rrf_merge_rows`) does the arithmetic for a whole batch of queries on row numbers; the
+# per-query, dict-shaped entry points the reference's callers know are thin adapters over it.  The arithmetic contract
+# (pinned by tests/golden/host_fixtures.json, generated from the imported reference): float64,
+# `score(id) = sum over methods in insertion order of share(method) / (rrf_k + rank + 1)` with 0-based ranks, ids ordered
+# by score descending with ties in first-seen order, reported `distance = 1 - score`.
+FUSION_METHODS = ("dense", "sparse", "full_text")
+
+
 def sanitize_hybrid_weights(hybrid_weights: Dict[str, float]) -> Dict[str, float]:
-    """hybrid_search.py:15-45."""
+    """Keeps the entries that name a fusion method with a positive numeric weight, as floats (hybrid_search.py:15-45).
+    Raises ValueError for an empty mapping or when nothing survives; dropped entries are logged."""
     if not hybrid_weights:
         raise ValueError("hybrid_weights must be a non-empty dict")
-    allowed = {"dense", "sparse", "full_text"}
-    cleaned: Dict[str, float] = {}
-    for method, weight in hybrid_weights.items():
-        if method not in allowed:
-            logger.warning("Ignoring unsupported hybrid method '%s'", method)
-            continue
-        if not isinstance(weight, (int, float)) or weight <= 0:
-            logger.warning("Ignoring non-positive weight for method '%s': %s", method, weight)
-            continue
-        cleaned[method] = float(weight)
-    if not cleaned:
+    kept: Dict[str, float] = {}
+    for name, w in hybrid_weights.items():
+        usable = name in FUSION_METHODS and isinstance(w, (int, float)) and w > 0
+        if usable:
+            kept[name] = float(w)
+        else:
+            logger.warning("hybrid_weights: dropping %r: %r (unknown method or non-positive weight)", name, w)
+    if not kept:
         raise ValueError("No valid hybrid_weights after validation")
-    return cleaned
+    return kept
 
 
-def normalize_weights(results_by_method: Dict[str, List], weights: Dict[str, float]) -> Dict[str, float]:
-    """hybrid_search.py:48-70."""
-    avail = {m: weights.get(m, 0.0) for m in results_by_method}
-    total = sum(avail.values())
+def normalize_weights(results_by_method: Dict[str, Any], weights: Dict[str, float]) -> Dict[str, float]:
+    """Share of each method that actually produced a list (hybrid_search.py:48-70): its weight over the sum of the
+    present methods' weights; equal shares when that sum is zero."""
+    present = list(results_by_method)
+    mass = [weights.get(m, 0.0) for m in present]
+    total = sum(mass)
     if total == 0:
-        logger.warning("No non-zero weights for available methods; using equal weights for: %s",
-                       list(results_by_method.keys()))
-        return {k: 1.0 / len(results_by_method) for k in results_by_method}
-    return {k: v / total for k, v in avail.items()}
-
-
-def merge_hybrid_results(results_by_method: Dict[str, List[dict]], top_k: int, weights: Dict[str, float],
-                         rrf_k: int = 60, log_label: str = "") -> List[dict]:
-    """Weighted reciprocal-rank fusion, hybrid_search.py:73-129: score[id] += w_m / (rrf_k + rank + 1)
-    in method insertion order, stable sort descending, `distance = 1 - score`."""
-    nw = normalize_weights(results_by_method, weights)
-    scores: Dict[Any, float] = {}
-    hit_map: Dict[Any, dict] = {}
-    for method, results in results_by_method.items():
-        w = nw.get(method, 0.0)
-        for rank, hit in enumerate(results):
-            hid = hit.get("id")
-            if not hid:
-                continue
-            if hid not in scores:
-                scores[hid] = 0.0
-                hit_map[hid] = hit
-            scores[hid] += w * (1.0 / (rrf_k + rank + 1))
-    ordered = sorted(scores.keys(), key=lambda i: scores[i], reverse=True)
-    merged = []
-    for hid in ordered[:top_k]:
-        h = hit_map[hid].copy()
-        h["distance"] = 1.0 - scores[hid]
-        merged.append(h)
-    return merged
+        logger.warning("hybrid search: no weight on any of %s, fusing with equal shares", present)
+        return dict.fromkeys(present, 1.0 / len(present))
+    return {m: w / total for m, w in zip(present, mass)}
 
 
 def rrf_merge_rows(rows_by_method: Dict[str, np.ndarray], top_k: int, weights: Dict[str, float],
                    rrf_k: int = 60) -> Tuple[np.ndarray, np.ndarray]:
-    """`merge_hybrid_results` for a whole batch of queries on row numbers: `rows_by_method[m]` is `[Q, L]` ranked rows
-    (-1 = no hit, only as a tail) of at most two methods, in the methods' insertion order.  Returns `rows [Q, top_k]`
-    (-1 padded) and `distance [Q, top_k]` (float64, `1 - score`).  Same arithmetic in the same order as the per-query
-    routine -- `score = 0.0 + w_first / (rrf_k + rank + 1) (+ w_second / ...)` in float64, stable descending sort, so
-    equal scores keep first-seen order -- which `tests/test_store_host_logic.py` checks element for element."""
+    """Weighted RRF for a whole batch of queries on row numbers.  `rows_by_method[m]` is `[Q, L_m]` ranked rows, methods
+    in insertion order; a negative entry is a rank without a candidate (no hit, or a hit the caller must skip: it still
+    occupies its rank).  Returns `rows [Q, top_k]` (-1 padded) and `distance [Q, top_k]` (float64, `1 - score`).
+
+    All lists are laid side by side as one `[Q, L]` candidate matrix; a candidate's score is gathered at its FIRST
+    occurrence by adding, method by method, the contribution of whichever later position holds the same row (one
+    non-zero term per method, so every float64 sum has the same operands in the same order as a sequential
+    accumulation); a stable argsort on the negated score then keeps first-seen order among equal scores."""
     methods = list(rows_by_method)
-    if not 1 <= len(methods) <= 2:
-        raise ValueError("rrf_merge_rows merges one or two methods")
-    nw = normalize_weights({m: None for m in methods}, weights)
-    first = np.asarray(rows_by_method[methods[0]], dtype=np.int64)
-    Q, L1 = first.shape
-    contrib1 = nw.get(methods[0], 0.0) * (1.0 / (rrf_k + np.arange(L1, dtype=np.float64) + 1))
-    score1 = np.broadcast_to(0.0 + contrib1, (Q, L1)).copy()
-    if len(methods) == 1:
-        cand_rows, cand_score = first, score1
-    else:
-        second = np.asarray(rows_by_method[methods[1]], dtype=np.int64)
-        L2 = second.shape[1]
-        contrib2 = nw.get(methods[1], 0.0) * (1.0 / (rrf_k + np.arange(L2, dtype=np.float64) + 1))
-        same = (first[:, :, None] == second[:, None, :]) & (first[:, :, None] >= 0)          # [Q, L1, L2]: at most one per row / column
-        score1 += (same * contrib2[None, None, :]).sum(axis=2)                             # a + b (one non-zero term) or a + 0.0
-        only2 = ~same.any(axis=1)                                                            # second-method rows not seen before
-        cand_rows = np.concatenate([first, np.where(only2, second, -1)], axis=1)
-        cand_score = np.concatenate([score1, np.broadcast_to(0.0 + contrib2, (Q, L2))], axis=1)
-    key = np.where(cand_rows >= 0, -cand_score, np.inf)
-    order = np.argsort(key, axis=1, kind="stable")[:, :top_k]
-    rows = np.take_along_axis(cand_rows, order, axis=1)
-    dist = 1.0 - np.take_along_axis(cand_score, order, axis=1)
-    if rows.shape[1] < top_k:
-        pad = top_k - rows.shape[1]
-        rows = np.pad(rows, ((0, 0), (0, pad)), constant_values=-1)
+    if not methods:
+        raise ValueError("rrf_merge_rows needs at least one method")
+    share = normalize_weights(dict.fromkeys(methods), weights)
+    lists = [np.asarray(rows_by_method[m], dtype=np.int64) for m in methods]
+    Q = lists[0].shape[0]
+    cand = np.concatenate(lists, axis=1)                                          # [Q, L]
+    L = cand.shape[1]
+    live = cand >= 0
+    same = (cand[:, :, None] == cand[:, None, :]) & live[:, :, None]              # [Q, L, L] (symmetric on live entries)
+    earlier = np.tril(np.ones((L, L), dtype=bool), -1)                            # [p, p'] : p' < p
+    first = live & ~(same & earlier[None]).any(axis=2)
+    score = np.zeros((Q, L), np.float64)
+    lo = 0
+    for m, rows in zip(methods, lists):
+        n = rows.shape[1]
+        gain = share.get(m, 0.0) * (1.0 / (rrf_k + np.arange(n, dtype=np.float64) + 1))
+        score = score + (same[:, :, lo:lo + n] * gain[None, None, :]).sum(axis=2)
+        lo += n
+    order = np.argsort(np.where(first, -score, np.inf), axis=1, kind="stable")[:, :top_k]
+    picked = np.take_along_axis(first, order, axis=1)
+    rows_out = np.where(picked, np.take_along_axis(cand, order, axis=1), -1)
+    dist = np.where(picked, 1.0 - np.take_along_axis(score, order, axis=1), 0.0)
+    if rows_out.shape[1] < top_k:
+        pad = top_k - rows_out.shape[1]
+        rows_out = np.pad(rows_out, ((0, 0), (0, pad)), constant_values=-1)
         dist = np.pad(dist, ((0, 0), (0, pad)))
-    return rows, dist
+    return rows_out, dist
+
+
+def merge_hybrid_results(results_by_method: Dict[str, List[dict]], top_k: int, weights: Dict[str, float],
+                         rrf_k: int = 60, log_label: str = "") -> List[dict]:
+    """The per-query, dict-shaped form (hybrid_search.py:73-129): hits are dicts with an "id"; hits whose id is falsy
+    are skipped but keep their rank.  Ids are numbered in first-seen order and the batch routine does the rest; each
+    merged entry is a copy of the first hit seen for its id with `distance = 1 - score`."""
+    number: Dict[Any, int] = {}
+    exemplar: List[dict] = []
+    coded: Dict[str, np.ndarray] = {}
+    for method, hits in results_by_method.items():
+        row = np.full((1, len(hits)), -1, np.int64)
+        for pos, hit in enumerate(hits):
+            key = hit.get("id")
+            if not key:
+                continue
+            if key not in number:
+                number[key] = len(exemplar)
+                exemplar.append(hit)
+            row[0, pos] = number[key]
+        coded[method] = row
+    if log_label:
+        logger.info("hybrid merge (%s): methods=%s rrf_k=%s top_k=%s", log_label, list(coded), rrf_k, top_k)
+    rows, dist = rrf_merge_rows(coded, top_k, weights, rrf_k)
+    merged = []
+    for code, d in zip(rows[0], dist[0]):
+        if code >= 0:
+            hit = dict(exemplar[int(code)])
+            hit["distance"] = float(d)
+            merged.append(hit)
+    return merged
+
+
+def _metadata_of(entity: dict) -> Dict[str, Any]:
+    raw = entity.get("metadata", {}) or {}
+    if not isinstance(raw, str):
+        return raw
+    try:                                # a JSON column read back as text
+        return json.loads(raw)
+    except Exception:
+        return {"raw": raw}
 
 
 def convert_hits_to_results(hits: List[dict], dynamic_fields: Optional[List[str]] = None) -> List[SearchResult]:
-    """hybrid_search.py:132-175."""
-    dynamic_fields = dynamic_fields or []
-    out: List[SearchResult] = []
+    """Search hits (`{"id", "distance", "entity": {...}}`, the shape a Milvus client returns and the shape
+    `merge_hybrid_results` passes through) -> `SearchResult`s; `dynamic_fields` present on the entity are copied into
+    the metadata (hybrid_search.py:132-175)."""
+    results = []
     for hit in hits:
         entity = hit.get("entity", {})
-        metadata = entity.get("metadata", {}) or {}
-        if isinstance(metadata, str):
-            try:
-                metadata = json.loads(metadata)
-            except Exception:
-                metadata = {"raw": metadata}
-        for f in dynamic_fields:
-            val = entity.get(f)
-            if val is not None:
-                metadata[f] = val
-        out.append(SearchResult(id=hit.get("id"), score=hit.get("distance", 0.0), text=entity.get("text", ""),
-                                enhanced_text=entity.get("enhanced_text", ""), metadata=metadata))
-    return out
+        metadata = _metadata_of(entity)
+        metadata.update({f: entity[f] for f in (dynamic_fields or ()) if entity.get(f) is not None})
+        results.append(SearchResult(id=hit.get("id"), score=hit.get("distance", 0.0), metadata=metadata,
+                                    text=entity.get("text", ""), enhanced_text=entity.get("enhanced_text", "")))
+    return results
 
 
 # ---------------------------------------------------------------------------- device indexes
@@ -298,35 +317,53 @@ class SparseShard:
 
 
 def json_serialize_safe(obj: Any) -> Any:
-    """What the reference's store does to metadata before the insert (vector_stores/utils.py:10-29): datetimes become
-    ISO strings, enums their values, dict keys strings, recursively through dicts and lists -- the JSON column's view of
-    the caller's objects, which is what searches return and filters compare against."""
+    """The JSON column's view of caller metadata -- what a search returns and what filters compare against
+    (the reference applies the same conversion before its insert, vector_stores/utils.py:10-29): datetimes as ISO
+    strings, enum members as their values, mapping keys as strings, descending through dicts and lists only."""
     from datetime import datetime
     from enum import Enum
 
-    if isinstance(obj, datetime):
-        return obj.isoformat()
-    if isinstance(obj, Enum):
-        return getattr(obj, "value", str(obj))
-    if isinstance(obj, dict):
-        return {str(k): json_serialize_safe(v) for k, v in obj.items()}
-    if isinstance(obj, list):
-        return [json_serialize_safe(item) for item in obj]
-    return obj
+    def view(x):
+        if isinstance(x, dict):
+            return {str(key): view(val) for key, val in x.items()}
+        if isinstance(x, list):
+            return [view(item) for item in x]
+        if isinstance(x, datetime):
+            return x.isoformat()
+        if isinstance(x, Enum):
+            return getattr(x, "value", str(x))
+        return x
+
+    return view(obj)
 
 
-# ---------------------------------------------------------------------------- the store
-_FILTER_TOKEN = re.compile(r"""\s*(?:(?P<meta>metadata\[\s*["'](?P<mkey>[^"']+)["']\s*\])|(?P<str>"[^"]*"|'[^']*')|(?P<num>-?\d+(?:\.\d+)?)"""
+# ---------------------------------------------------------------------------- filters
+_FILTER_TOKEN = re.compile(r"""\s*(?:(?P<meta>metadata\[\s*["'](?P<mkey>[^"']+)["']\s*\])|(?P<str>"[^"]*"|'[^']*')"""
+                           r"""|(?P<num>-?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?)"""
                            r"""|(?P<op>==|!=|<=|>=|<|>|&&|\|\||[()\[\],])|(?P<word>\w+))""")
+
+
+def _typed(value: Any):
+    """Comparison key of a metadata value or a filter literal: JSON semantics, not text -- a number equals a number
+    (2020 == 2020.0), a string equals a string ("5" != 5), booleans only booleans; anything else (None, a missing
+    key, lists, dicts) equals nothing."""
+    if isinstance(value, bool):
+        return ("b", value)
+    if isinstance(value, (int, float)):
+        return ("n", float(value))
+    if isinstance(value, str):
+        return ("s", value)
+    return None
 
 
 def parse_filter(expr: str):
     """Compiles the subset of Milvus boolean expressions the store supports into `predicate(metadata: dict) -> bool`:
-    comparisons `field == value`, `field != value`, `field in [v, ...]`, `field < / <= / > / >= value` (numbers against
-    numeric metadata, quoted strings against text metadata) (field = `metadata["key"]`, the Local dialect,
-    or a bare `key`, the Cloud dialect: index.py:735-739; values = quoted strings or numbers, compared as strings like
-    the JSON-path match on string metadata), combined with `and` / `&&`, `or` / `||`, `not` and parentheses.
-    Anything else raises ValueError -- a filter is never silently ignored."""
+    `field == value`, `field != value`, `field in [v, ...]`, `field < / <= / > / >= value`, combined with `and` / `&&`,
+    `or` / `||`, `not` and parentheses.  field = `metadata["key"]` (the Local dialect) or a bare `key` (the Cloud
+    dialect: index.py:735-739); value = a quoted string, a number (`7`, `-2.5`, `1e3`) or `true` / `false`.
+    Comparisons are typed like Milvus' JSON path match: numbers against numeric metadata, strings against text,
+    booleans against booleans; a missing key equals nothing (so `!=` holds for it).  Anything else raises ValueError --
+    a filter is never silently ignored."""
     toks, pos = [], 0
     while pos < len(expr):
         if expr[pos:].strip() == "":
@@ -340,12 +377,17 @@ def parse_filter(expr: str):
         elif m.group("str"):
             toks.append(("val", m.group("str")[1:-1]))
         elif m.group("num"):
-            toks.append(("num", m.group("num")))
+            toks.append(("val", float(m.group("num"))))
         elif m.group("op"):
             toks.append(("op", m.group("op")))
         else:
             w = m.group("word")
-            toks.append(("op", w.lower()) if w.lower() in ("and", "or", "not", "in") else ("field", w))
+            if w.lower() in ("and", "or", "not", "in"):
+                toks.append(("op", w.lower()))
+            elif w.lower() in ("true", "false"):
+                toks.append(("val", w.lower() == "true"))
+            else:
+                toks.append(("field", w))
     i = 0
 
     def peek():
@@ -354,9 +396,7 @@ def parse_filter(expr: str):
     def take(kind=None, value=None):
         nonlocal i
         k, v = peek()
-        if kind == "val" and k == "num":      # a number where a value is expected (compared as text by == / != / in)
-            k = "val"
-        if k is None or (kind and k != kind) or (value and v != value):
+        if k is None or (kind and k != kind) or (value is not None and v != value):
             raise ValueError(f"GpuVectorStore: unsupported filter {expr!r}")
         i += 1
         return v
@@ -374,33 +414,35 @@ def parse_filter(expr: str):
         key = take("field")
         op = take("op")
         if op in ("==", "!="):
-            val = take("val")
+            want = _typed(take("val"))
             if op == "!=":
-                return lambda md: str(md.get(key)) != val
-            f = lambda md: str(md.get(key)) == val   # noqa: E731
-            f.lookup = (key, [val])                  # lets the store answer from a per-key value index
+                return lambda md: _typed(md.get(key)) != want
+            f = lambda md: _typed(md.get(key)) == want   # noqa: E731
+            f.lookup = (key, [want])                      # lets the store answer from a per-key value index
             return f
         if op == "in":
             take("op", "[")
-            vals = [take("val")]
+            vals = [_typed(take("val"))]
             while peek() == ("op", ","):
                 take()
-                vals.append(take("val"))
+                vals.append(_typed(take("val")))
             take("op", "]")
             vs = set(vals)
-            f = lambda md: str(md.get(key)) in vs    # noqa: E731
+            f = lambda md: _typed(md.get(key)) in vs      # noqa: E731
             f.lookup = (key, vals)
             return f
         if op in ("<", "<=", ">", ">="):
             import operator
 
             cmp = {"<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}[op]
-            kind, raw = peek()
-            take("val")
-            if kind == "num":       # numeric bound: only numeric metadata values can pass (JSON numbers; bools are not)
-                bound = float(raw)
-                return lambda md: isinstance(md.get(key), (int, float)) and not isinstance(md.get(key), bool) and cmp(md.get(key), bound)
-            return lambda md: isinstance(md.get(key), str) and cmp(md.get(key), raw)   # quoted bound: text order
+            kind, bound = _typed(take("val"))
+            if kind == "b":
+                raise ValueError(f"GpuVectorStore: ordering comparison with a boolean in filter {expr!r}")
+
+            def ordered(md):
+                have = _typed(md.get(key))
+                return have is not None and have[0] == kind and cmp(have[1], bound)
+            return ordered
         raise ValueError(f"GpuVectorStore: unsupported operator {op!r} in filter {expr!r}")
 
     def conjunction():
@@ -425,42 +467,68 @@ def parse_filter(expr: str):
     return pred
 
 
+# ---------------------------------------------------------------------------- the store
 class GpuVectorStore(VectorStore):
     """Exact GPU search store with BaseMilvusStore's behaviour (milvus_base.py:90-127,189-459).
 
     dense = COSINE (rows and queries are L2-normalised here, so IP on the device equals cosine),
     sparse = IP over shared terms.  Rows live on the host until the first query after an insert
-    ("flush"), then in HBM.  `filter` supports the comparison subset of Milvus expressions in `parse_filter`
+    ("flush"), then in HBM; a flush appends the new dense rows to the resident shard and rebuilds the sparse image.
+    Dense rows are stored fp32 like the reference's FLOAT_VECTOR field (milvus_local.py:109-118);
+    `dense_dtype="bf16"` halves the bytes a query streams at the price of rounding the stored rows.
+    `filter` supports the comparison subset of Milvus expressions in `parse_filter`
     (the reference itself only builds `metadata["document_id"] == "..."`, index.py:735-739); anything else is
     rejected loudly.  Filters and deletes act before the search like Milvus' (a selective filter still returns its
-    best rows): `_search_batch` re-runs short queries on a cached shard of just the passing rows.
+    best rows): `_topk_rows` re-runs short queries on a cached shard of just the passing rows.
+
+    Multi-GPU: `distributed=True` (one process per GPU, torch.distributed initialised, every rank making
+    the SAME calls with the SAME arguments) row-shards the vectors -- each insert batch is cut contiguously over the
+    ranks -- while ids / texts / metadata stay replicated on the hosts.  A search runs on each rank's shard, ONE
+    all-gather carries the per-shard `[Q, k]` lists and every rank merges them on its GPU (`distributed.ShardComm`),
+    so `query` / `query_batch` return the same results on every rank and the same results as a single-GPU store.
     """
 
     enable_full_text = False
 
     def __init__(self, dense_dim: Optional[int] = 384, sparse_vocab: Optional[int] = 30522, enable_dense: bool = True,
-                 enable_sparse: bool = True, dense_dtype: str = "bf16", device: int = 0):
+                 enable_sparse: bool = True, dense_dtype: str = "f32", device: int = 0, distributed: bool = False,
+                 group=None, comm=None):
         self._lib = _lib.load()
         _lib.require_gpu()
+        if dense_dtype not in ("f32", "bf16"):
+            raise ValueError(f"dense_dtype must be 'f32' or 'bf16' (got {dense_dtype!r})")
         self.enable_dense, self.enable_sparse = enable_dense, enable_sparse
         self.dense_dim, self.sparse_vocab, self.dense_dtype, self.device = dense_dim, sparse_vocab, dense_dtype, device
+        self._comm = comm
+        if comm is None and distributed:
+            from .distributed import ShardComm
+
+            self._comm = ShardComm(group, device)
+        self._rank = self._comm.rank if self._comm is not None else 0
+        self._world = self._comm.world if self._comm is not None else 1
+        # replicated on every rank, indexed by global row
         self._ids: List[str] = []
         self._texts: List[str] = []
         self._enh: List[str] = []
         self._meta: List[Dict[str, Any]] = []
+        self._alive: List[bool] = []
+        # this rank's shard, indexed by local row; `_owned[j]` = global row of local row j (ascending)
+        self._owned: List[int] = []
         self._dense_rows: List[np.ndarray] = []
         self._sparse_rows: List[Dict[int, float]] = []
-        self._alive: List[bool] = []
         self._dense: Optional[DenseShard] = None
+        self._dense_cap = 0          # capacity of the resident dense shard
+        self._dense_flushed = 0      # local rows already in it
         self._sparse: Optional[SparseShard] = None
+        self._main_rows: Optional[np.ndarray] = None   # np.asarray(_owned) at the last flush
         self._dirty = False
         # Callers arrive from asyncio.to_thread workers (index.py:552-655 under api/): inserts, deletes, the flush and the
         # cache fills are serialised by this lock; searches run outside it on the shard objects they captured, and a shard
         # that has been replaced or evicted is released by its last user (DenseShard / SparseShard.__del__), never closed
-        # under a running search.
+        # under a running search.  (Sharded stores are SPMD: one caller thread per rank.)
         self._mu = threading.RLock()
         self._masks: Dict[str, Optional[np.ndarray]] = {}
-        self._value_indexes: Dict[str, Dict[str, np.ndarray]] = {}
+        self._value_indexes: Dict[str, Dict[Any, np.ndarray]] = {}
         self._all_ids_truthy: Optional[bool] = None
         self._documents: Dict[str, Dict[str, Any]] = {}      # document records (add_documents / get_document)
         self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
@@ -474,26 +542,53 @@ class GpuVectorStore(VectorStore):
             raise ValueError("Dense vectors required but not provided")          # milvus_base.py:101-104
         if self.enable_sparse and (sparse_vectors is None or len(sparse_vectors) == 0):
             raise ValueError("Sparse vectors required but not provided")
-        with self._mu:
-            self._add_locked(ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas)
+        # Build and validate every new row BEFORE touching the store (the reference assembles the whole batch and
+        # inserts it in one call, milvus_base.py:90-127): a malformed entry leaves the store exactly as it was.
+        n = len(ids)
+        columns = {"texts": texts, "enhanced_texts": enhanced_texts, "metadatas": metadatas}
+        if self.enable_dense:
+            columns["dense_vectors"] = dense_vectors
+        if self.enable_sparse:
+            columns["sparse_vectors"] = sparse_vectors
+        for name, col in columns.items():
+            if len(col) != n:
+                raise ValueError(f"add_vectors: {len(col)} {name} for {n} ids")
+        lo, hi = (0, n)
+        if self._world > 1:
+            from .distributed import shard_range
 
-    def _add_locked(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
-        for i in range(len(ids)):
-            self._ids.append(ids[i])
-            self._texts.append(texts[i])
-            self._enh.append(enhanced_texts[i])
-            self._meta.append(json_serialize_safe(dict(metadatas[i] or {})))   # milvus_base.py:108-109
-            self._alive.append(True)
+            lo, hi = shard_range(n, self._rank, self._world)
+        new_meta = [json_serialize_safe(dict(md or {})) for md in metadatas]     # milvus_base.py:108-109
+        new_dense: List[np.ndarray] = []
+        new_sparse: List[Dict[int, float]] = []
+        for i in range(n):
             if self.enable_dense:
                 v = np.asarray(dense_vectors[i], dtype=np.float32)
-                n = float(np.sqrt((v * v).sum(dtype=np.float32)))
-                self._dense_rows.append(v / n if n > 0 else v)                  # COSINE == IP on unit rows
+                if v.ndim != 1 or v.shape[0] != self.dense_dim:
+                    raise ValueError(f"add_vectors: dense vector {i} has shape {v.shape}, the store holds {self.dense_dim}-d rows")
+                if lo <= i < hi:
+                    norm = float(np.sqrt((v * v).sum(dtype=np.float32)))
+                    new_dense.append(v / norm if norm > 0 else v)                # COSINE == IP on unit rows
             if self.enable_sparse:
-                self._sparse_rows.append({int(k): float(v) for k, v in sparse_vectors[i].items()})
-        self._dirty = True
-        self._drop_subsets()
-        self._value_indexes.clear()
-        self._all_ids_truthy = None
+                row = {int(t): float(w) for t, w in sparse_vectors[i].items()}
+                if row and (min(row) < 0 or max(row) >= self.sparse_vocab):
+                    raise ValueError(f"add_vectors: sparse vector {i} has a term outside [0, {self.sparse_vocab})")
+                if lo <= i < hi:
+                    new_sparse.append(row)
+        with self._mu:
+            base = len(self._ids)
+            self._ids.extend(ids)
+            self._texts.extend(texts)
+            self._enh.extend(enhanced_texts)
+            self._meta.extend(new_meta)
+            self._alive.extend([True] * n)
+            self._owned.extend(range(base + lo, base + hi))
+            self._dense_rows.extend(new_dense)
+            self._sparse_rows.extend(new_sparse)
+            self._dirty = True
+            self._drop_subsets()
+            self._value_indexes.clear()
+            self._all_ids_truthy = None
 
     def delete(self, ids: List[str]):
         kill = set(ids)
@@ -507,23 +602,31 @@ class GpuVectorStore(VectorStore):
         with self._mu:
             if not self._dirty:
                 return
-            n = len(self._ids)
-            if self.enable_dense:
-                self._dense = None                      # released now unless a search on another thread still holds it
-                dense = DenseShard(self.dense_dim, max(n, 1), self.dense_dtype, self.device)
-                if n:
+            n = len(self._owned)
+            if self.enable_dense and n > self._dense_flushed:
+                fresh = np.stack(self._dense_rows[self._dense_flushed:])
+                if self._dense is None or n > self._dense_cap:
+                    # (re)build with head-room so later inserts append instead of re-uploading every row
+                    self._dense = None                  # released now unless a search on another thread still holds it
+                    self._dense_cap = max(1024, 2 * n)
+                    dense = DenseShard(self.dense_dim, self._dense_cap, self.dense_dtype, self.device)
                     dense.add(np.stack(self._dense_rows))
-                self._dense = dense
+                    self._dense = dense
+                else:
+                    self._dense.add(fresh)
+                self._dense_flushed = n
             if self.enable_sparse:
                 self._sparse = None
                 self._sparse = SparseShard(self.sparse_vocab, *dicts_to_csr(self._sparse_rows), device=self.device) if n else None
+            self._main_rows = np.asarray(self._owned, dtype=np.int64)
             self._dirty = False
 
     def _main_shard(self, kind: str):
-        """(shard, rows it holds) after a flush, captured under the lock."""
+        """(shard or None, global row of each of its rows, rows in the whole store) after a flush, captured under the lock."""
         with self._mu:
             self._flush()
-            return (self._dense if kind == "dense" else self._sparse), len(self._ids)
+            rows = self._main_rows if self._main_rows is not None else np.zeros(0, np.int64)
+            return (self._dense if kind == "dense" else self._sparse), rows, len(self._ids)
 
     # -------------------------------------------------------------- search
     def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
@@ -554,15 +657,17 @@ class GpuVectorStore(VectorStore):
             self._masks[key] = None if alive.all() else alive
         return self._masks[key]
 
-    def _value_index(self, key: str) -> Dict[str, np.ndarray]:
-        """str(metadata[key]) -> rows, built once per key until the next insert: a per-document filter then costs its
-        matches, not a Python predicate call per stored row."""
+    def _value_index(self, key: str) -> Dict[Any, np.ndarray]:
+        """typed metadata[key] -> rows, built once per key until the next insert: a per-document filter then costs its
+        matches, not a Python predicate call per stored row.  Rows without a comparable value are in no bucket."""
         with self._mu:
             index = self._value_indexes.get(key)
             if index is None:
-                buckets: Dict[str, List[int]] = {}
+                buckets: Dict[Any, List[int]] = {}
                 for i, md in enumerate(self._meta):
-                    buckets.setdefault(str(md.get(key)), []).append(i)
+                    t = _typed(md.get(key))
+                    if t is not None:
+                        buckets.setdefault(t, []).append(i)
                 index = self._value_indexes[key] = {v: np.asarray(rows, dtype=np.int64) for v, rows in buckets.items()}
             return index
 
@@ -572,41 +677,54 @@ class GpuVectorStore(VectorStore):
         return {"id": self._ids[row], "distance": float(score), "_row": row}
 
     def _results(self, hits: List[dict]) -> List[SearchResult]:
-        full = []
-        for h in hits:
-            row = h["_row"]
-            full.append({"id": h["id"], "distance": h["distance"],
-                         "entity": {"text": self._texts[row], "enhanced_text": self._enh[row], "metadata": dict(self._meta[row])}})
-        return convert_hits_to_results(full)
+        return [SearchResult(id=h["id"], score=h["distance"], metadata=dict(self._meta[h["_row"]]),
+                             text=self._texts[h["_row"]], enhanced_text=self._enh[h["_row"]]) for h in hits]
 
     def _search(self, kind: str, query, limit: int, mask: Optional[np.ndarray]) -> List[dict]:
         return self._search_batch(kind, [query], limit, mask)[0]
 
-    def _device_topk(self, kind: str, shard, queries: Sequence[Any], k: int):
-        if kind == "dense":   # COSINE: unit queries against the unit rows (fp32 norm, one row at a time or all at once: same bits)
-            rows_q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(len(queries), self.dense_dim))
-            norms = np.sqrt((rows_q * rows_q).sum(axis=1, dtype=np.float32))
-            return shard.search(rows_q / np.where(norms > 0, norms, np.float32(1.0))[:, None], k)
-        return shard.search(queries, k)       # dicts_to_csr converts keys / weights to int32 / float32
+    def _device_topk(self, kind: str, shard, shard_rows: np.ndarray, queries: Sequence[Any], k: int):
+        """Top-k of `queries` over one (possibly sharded) set of rows -> (`scores [Q, k]`, GLOBAL `rows [Q, k]`, -1 = no
+        hit).  `shard` is this rank's part (None when it holds none of the rows) and `shard_rows[j]` the global row of
+        its row j; with more than one rank the per-shard lists meet in one all-gather and are merged on the GPU."""
+        Q = len(queries)
+        if shard is None or len(shard_rows) == 0:
+            scores = np.full((Q, k), -np.inf, np.float32)
+            rows = np.full((Q, k), -1, np.int64)
+        else:
+            if kind == "dense":   # COSINE: unit queries against the unit rows (fp32 norm, one row at a time or all at once: same bits)
+                rows_q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(Q, self.dense_dim))
+                norms = np.sqrt((rows_q * rows_q).sum(axis=1, dtype=np.float32))
+                scores, local = shard.search(rows_q / np.where(norms > 0, norms, np.float32(1.0))[:, None], k)
+            else:
+                scores, local = shard.search(queries, k)       # dicts_to_csr converts keys / weights to int32 / float32
+            found = local >= 0
+            rows = np.where(found, shard_rows[np.where(found, local, 0)], -1)
+        if self._world > 1:
+            scores, rows = self._comm.allgather_merge(scores, rows, k)
+        return scores, rows
 
     def _subset(self, kind: str, mask: np.ndarray):
-        """A shard holding only the rows that pass `mask` (Milvus filters before it searches, milvus_base.py:240-262, so
-        a selective filter must still return its best rows however far down the unfiltered ranking they are).  Built
-        from the host copies, cached per (kind, mask) until the next insert / delete; subset row j is global row idx[j],
-        idx ascending, so the kernels' `(score desc, id asc)` order carries over."""
+        """A shard holding only this rank's rows that pass `mask` (Milvus filters before it searches,
+        milvus_base.py:240-262, so a selective filter must still return its best rows however far down the unfiltered
+        ranking they are).  Built from the host copies, cached per (kind, mask) until the next insert / delete; returns
+        (shard or None, global row of each subset row) -- rows ascending, so the kernels' `(score desc, id asc)` order
+        carries over."""
         key = (kind, mask.tobytes())
         with self._mu:
             hit = self._subsets.get(key)
             if hit is None:
-                idx = np.nonzero(mask)[0]
-                if kind == "dense":
-                    shard = DenseShard(self.dense_dim, len(idx), self.dense_dtype, self.device)
-                    shard.add(np.stack([self._dense_rows[i] for i in idx]))
-                else:
-                    shard = SparseShard(self.sparse_vocab, *dicts_to_csr([self._sparse_rows[i] for i in idx]), device=self.device)
+                owned = np.asarray(self._owned, dtype=np.int64)
+                local = np.nonzero(mask[owned])[0] if len(owned) else np.zeros(0, np.int64)
+                shard = None
+                if len(local) and kind == "dense":
+                    shard = DenseShard(self.dense_dim, len(local), self.dense_dtype, self.device)
+                    shard.add(np.stack([self._dense_rows[j] for j in local]))
+                elif len(local):
+                    shard = SparseShard(self.sparse_vocab, *dicts_to_csr([self._sparse_rows[j] for j in local]), device=self.device)
                 while len(self._subsets) >= self.SUBSET_CACHE:
                     self._subsets.pop(next(iter(self._subsets)))          # freed when its last user lets go
-                hit = self._subsets[key] = (shard, idx)
+                hit = self._subsets[key] = (shard, owned[local] if len(owned) else local)
             return hit
 
     def _drop_subsets(self):
@@ -615,24 +733,28 @@ class GpuVectorStore(VectorStore):
             self._masks.clear()
 
     def _topk_rows(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
-        """Best `limit` (<= 1024) rows per query among the rows that pass `mask`: `rows [Q, limit]` (-1 = no hit, tail
-        only) and their fp32 scores.  One device pass for the whole batch over the full shard; queries that come up
-        short because filtered / deleted rows took their slots (and every query when the filter passes under 1/8 of
-        the rows) get a second pass over the masked subset shard."""
-        main, n = self._main_shard(kind)
+        """Best `limit` rows per query among the rows that pass `mask`: `rows [Q, limit]` (-1 = no hit, tail only) and
+        their fp32 scores.  One device pass for the whole batch over the full shard; queries that come up short because
+        filtered / deleted rows took their slots (and every query when the filter passes under 1/8 of the rows) get a
+        second pass over the masked subset shard.  Every branch below depends only on replicated state and on merged
+        results, so the ranks of a sharded store take the same path and meet in the same collectives."""
+        if limit > self.K_LIMIT:
+            raise ValueError(f"GpuVectorStore: a search may ask for at most {self.K_LIMIT} rows per method "
+                             f"(got {limit}; hybrid search asks for 2 * top_k)")
+        main, main_rows, n = self._main_shard(kind)
         if mask is not None and len(mask) != n:     # rows were inserted after the caller built its mask
             mask = np.concatenate([mask, np.zeros(n - len(mask), dtype=bool)]) if len(mask) < n else mask[:n]
         Q = len(queries)
         rows_out = np.full((Q, limit), -1, np.int64)
         score_out = np.zeros((Q, limit), np.float32)
-        k = min(self.K_LIMIT, limit)
+        k = limit
         n_pass = n if mask is None else int(mask.sum())
-        if n == 0 or Q == 0 or n_pass == 0 or main is None:
+        if n == 0 or Q == 0 or n_pass == 0:
             return rows_out, score_out
         want = min(k, n_pass)
         short = np.ones(Q, dtype=bool)
         if mask is None or n_pass * 8 >= n:
-            scores, rows = self._device_topk(kind, main, queries, k)
+            scores, rows = self._device_topk(kind, main, main_rows, queries, k)
             found = rows >= 0
             valid = found if mask is None else found & mask[np.where(found, rows, 0)]
             count = valid.sum(axis=1)
@@ -644,15 +766,14 @@ class GpuVectorStore(VectorStore):
             scores_c = np.take_along_axis(scores, order, axis=1)
             rows_c[np.arange(k)[None, :] >= count[:, None]] = -1
             rows_out[done, :k] = rows_c[done]
-            score_out[done, :k] = scores_c[done]
+            score_out[done, :k] = np.where(rows_c[done] >= 0, scores_c[done], np.float32(0.0))
             short = ~done
         if short.any():
-            shard, idx = self._subset(kind, mask)
+            shard, shard_rows = self._subset(kind, mask)
             which = np.nonzero(short)[0]
-            scores, rows = self._device_topk(kind, shard, [queries[i] for i in which], want)
-            found = rows >= 0
-            rows_out[which, :want] = np.where(found, idx[np.where(found, rows, 0)], -1)
-            score_out[which, :want] = scores
+            scores, rows = self._device_topk(kind, shard, shard_rows, [queries[i] for i in which], want)
+            rows_out[which, :want] = rows
+            score_out[which, :want] = np.where(rows >= 0, scores, np.float32(0.0))
         return rows_out, score_out
 
     def _search_batch(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> List[List[dict]]:
@@ -665,8 +786,8 @@ class GpuVectorStore(VectorStore):
     RRF_VECTOR_MAX = 64   # candidate lists up to this long are merged for the whole batch at once (an [Q, L, L] compare)
 
     def _hybrid_batch(self, dq, sq, top_k, mask, weights, rrf_k) -> List[List[SearchResult]]:
-        """Both methods for all queries, then weighted RRF: vectorised over the batch, or the per-query restatement of
-        hybrid_search.py when the lists are long or an id is falsy (`merge_hybrid_results` skips such hits)."""
+        """Both methods for all queries, then weighted RRF: one array merge for the whole batch, or query by query when
+        the lists are long (the `[Q, L, L]` compare) or an id is falsy (such hits keep their rank but are skipped)."""
         limit = top_k * 2
         rows_d, sc_d = self._topk_rows("dense", dq, limit, mask)
         rows_s, sc_s = self._topk_rows("sparse", sq, limit, mask)
@@ -818,56 +939,67 @@ class GpuVectorStore(VectorStore):
 
     # -------------------------------------------------------------- persistence
     def save(self, path: str) -> None:
-        """Writes the store to a directory: `vectors.npz` (packed unit dense rows, sparse CSR) and `rows.json`
-        (ids, texts, enhanced texts, metadata; deleted rows are dropped).  The reference persists through the
-        Milvus-lite database file (milvus_local.py:39-56); this is the GPU store's own on-disk format."""
-        import json
+        """Writes the store to a directory: `rows.json` (ids, texts, enhanced texts, metadata; deleted rows are dropped)
+        and one `vectors.rank{r}.npz` per rank (that rank's packed unit dense rows and sparse CSR plus the row numbers
+        they belong to).  The reference persists through the Milvus-lite database file (milvus_local.py:39-56); this is
+        the GPU store's own on-disk format.  Sharded stores: every rank calls `save` with the same path."""
         import os
 
         os.makedirs(path, exist_ok=True)
-        keep = [i for i, a in enumerate(self._alive) if a]
-        arrays: Dict[str, np.ndarray] = {}
+        alive = np.asarray(self._alive, dtype=bool)
+        keep = np.nonzero(alive)[0]
+        new_row = np.cumsum(alive) - 1                                   # row number after dropping the deleted rows
+        local = [j for j, g in enumerate(self._owned) if alive[g]]
+        arrays: Dict[str, np.ndarray] = {"owned": np.asarray([new_row[self._owned[j]] for j in local], dtype=np.int64)}
         if self.enable_dense:
-            arrays["dense"] = (np.stack([self._dense_rows[i] for i in keep]).astype(np.float32) if keep
+            arrays["dense"] = (np.stack([self._dense_rows[j] for j in local]).astype(np.float32) if local
                                else np.zeros((0, self.dense_dim or 0), np.float32))
         if self.enable_sparse:
-            indptr, indices, values = dicts_to_csr([self._sparse_rows[i] for i in keep])
+            indptr, indices, values = dicts_to_csr([self._sparse_rows[j] for j in local])
             arrays.update(sp_indptr=indptr, sp_indices=indices, sp_values=values)
-        np.savez(os.path.join(path, "vectors.npz"), **arrays)
-        with open(os.path.join(path, "rows.json"), "w", encoding="utf-8") as f:
-            json.dump({"format": 1, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
-                       "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse,
-                       "dense_dtype": self.dense_dtype, "ids": [self._ids[i] for i in keep],
-                       "texts": [self._texts[i] for i in keep], "enhanced_texts": [self._enh[i] for i in keep],
-                       "metadatas": [self._meta[i] for i in keep], "documents": list(self._documents.values())},
-                      f, ensure_ascii=False)
+        np.savez(os.path.join(path, f"vectors.rank{self._rank}.npz"), **arrays)
+        if self._rank == 0:
+            with open(os.path.join(path, "rows.json"), "w", encoding="utf-8") as f:
+                json.dump({"format": 2, "world": self._world, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
+                           "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse,
+                           "dense_dtype": self.dense_dtype, "ids": [self._ids[i] for i in keep],
+                           "texts": [self._texts[i] for i in keep], "enhanced_texts": [self._enh[i] for i in keep],
+                           "metadatas": [self._meta[i] for i in keep], "documents": list(self._documents.values())},
+                          f, ensure_ascii=False)
 
     @classmethod
-    def load(cls, path: str, device: int = 0) -> "GpuVectorStore":
-        import json
+    def load(cls, path: str, device: int = 0, distributed: bool = False, group=None, comm=None) -> "GpuVectorStore":
+        """Reads a directory written by `save` (by a store of the same world size)."""
         import os
 
         with open(os.path.join(path, "rows.json"), encoding="utf-8") as f:
             rows = json.load(f)
-        if rows.get("format") != 1:
+        if rows.get("format") != 2:
             raise ValueError(f"{path}: unknown GpuVectorStore format {rows.get('format')!r}")
         st = cls(dense_dim=rows["dense_dim"], sparse_vocab=rows["sparse_vocab"], enable_dense=rows["enable_dense"],
-                 enable_sparse=rows["enable_sparse"], dense_dtype=rows["dense_dtype"], device=device)
-        z = np.load(os.path.join(path, "vectors.npz"))
+                 enable_sparse=rows["enable_sparse"], dense_dtype=rows["dense_dtype"], device=device,
+                 distributed=distributed, group=group, comm=comm)
+        if rows.get("world", 1) != st._world:
+            raise ValueError(f"{path}: written by {rows.get('world', 1)} rank(s), opened by {st._world}")
+        z = np.load(os.path.join(path, f"vectors.rank{st._rank}.npz"))
         n = len(rows["ids"])
         st._ids, st._texts, st._enh = list(rows["ids"]), list(rows["texts"]), list(rows["enhanced_texts"])
         st._meta = [dict(m) for m in rows["metadatas"]]
         st._documents = {d.get("id", ""): dict(d) for d in rows.get("documents", [])}
         st._alive = [True] * n
+        st._owned = [int(g) for g in z["owned"]]
+        m = len(st._owned)
+        if m and (min(st._owned) < 0 or max(st._owned) >= n):
+            raise ValueError(f"{path}: shard rows outside the {n} stored ids")
         if st.enable_dense:
             d = z["dense"]
-            if d.shape[0] != n:
-                raise ValueError(f"{path}: {d.shape[0]} dense rows for {n} ids")
-            st._dense_rows = [d[i] for i in range(n)]
+            if d.shape[0] != m:
+                raise ValueError(f"{path}: {d.shape[0]} dense rows for {m} shard rows")
+            st._dense_rows = [d[i] for i in range(m)]
         if st.enable_sparse:
             ip, ix, vv = z["sp_indptr"], z["sp_indices"], z["sp_values"]
-            if len(ip) != n + 1:
-                raise ValueError(f"{path}: sparse indptr has {len(ip)} entries for {n} ids")
-            st._sparse_rows = [{int(k): float(v) for k, v in zip(ix[ip[i]:ip[i + 1]], vv[ip[i]:ip[i + 1]])} for i in range(n)]
+            if len(ip) != m + 1:
+                raise ValueError(f"{path}: sparse indptr has {len(ip)} entries for {m} shard rows")
+            st._sparse_rows = [{int(k): float(v) for k, v in zip(ix[ip[i]:ip[i + 1]], vv[ip[i]:ip[i + 1]])} for i in range(m)]
         st._dirty = n > 0
         return st

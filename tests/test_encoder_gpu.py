@@ -178,3 +178,54 @@ def test_full_context_8192_tokens():
     eng.close()
     ref = O.encoder_forward(cfg, w, seqs[0])
     assert np.abs(got - ref).max() < 3e-2
+
+
+def test_layernorm_fold_with_row_mean_offsets_and_outlier_channels(monkeypatch):
+    """Trained encoders have what random-init ones lack: residual rows whose mean is many sigmas away from zero and a
+    few channels that are 50x larger than the rest.  The default schedule folds LayerNorm into the GEMMs
+    (bf16(h - c) operand copy and one-pass statistics of (h - c), c = the row's mean after the previous sub-layer;
+    layer 0's first sub-layer, which has no previous mean, keeps a stand-alone LayerNorm: capi.hip / gemm_bf16.hip); it
+    must hold the same error as the stand-alone two-pass LayerNorm kernels (VRAG_LN_FOLD=0) on such rows.  Layer 0's
+    attention Wo gets a rank-one term that adds (u . x) to every output channel -- a common-mode offset of ~8 sigma that
+    then rides the residual stream through every later layer -- and the embedding LayerNorm gain is x50 on three
+    channels."""
+    cfg = O.EncoderConfig(**TINY256)
+    w = {k: v.copy() for k, v in O.random_weights(cfg, seed=21).items()}
+    rng = np.random.default_rng(22)
+    H = cfg.hidden_size
+    w["embeddings.norm.weight"][[5, 77, 200]] *= 50.0
+    name = "layers.0.attn.Wo.weight"
+    u = rng.standard_normal(w[name].shape[1]).astype(np.float32)
+    w[name] += (8.0 * u / np.linalg.norm(u))[None, :] * np.ones((H, 1), np.float32)
+    seqs = _seqs(rng, [300, 64, 129, 5, 511], cfg.vocab_size)
+    refs = [O.encoder_forward(cfg, w, s, return_all=True)[1] for s in seqs]
+    # the stress is real: after the last layer most rows sit several sigmas (of the non-outlier channels) off zero
+    last = np.concatenate([r[cfg.num_hidden_layers] for r in refs])
+    body = np.delete(last, [5, 77, 200], axis=1)
+    ratio = np.abs(body.mean(axis=1)) / body.std(axis=1)
+    assert np.median(ratio) > 3.0, f"median |mean|/sigma = {np.median(ratio):.2f}: the construction lost its offsets"
+
+    def run(fold):
+        monkeypatch.setenv("VRAG_LN_FOLD", "1" if fold else "0")
+        eng = _engine(cfg, w, max_tokens=4096, max_seqs=16, max_seq_len=512, max_ranges=64)
+        errs = []
+        for n_layers in (1, 2, 3):
+            eng.load_batch(seqs)
+            eng.run(n_layers=n_layers)
+            got = eng.read_hidden(final_norm=False)
+            o, worst = 0, 0.0
+            for s, r in zip(seqs, refs):
+                d = np.abs(got[o:o + len(s)] - r[n_layers])
+                worst = max(worst, float(np.delete(d, [5, 77, 200], axis=1).max()))
+                o += len(s)
+            errs.append(worst)
+        fin = eng.read_hidden(final_norm=True)
+        eng.close()
+        ref_fin = np.concatenate([O.encoder_forward(cfg, w, s) for s in seqs])
+        return errs, float(np.delete(np.abs(fin - ref_fin), [5, 77, 200], axis=1).max())
+
+    e_fold, f_fold = run(True)
+    e_plain, f_plain = run(False)
+    for a, b in zip(e_fold, e_plain):
+        assert a < max(3e-2, 1.5 * b), f"fold {e_fold} vs stand-alone LayerNorm {e_plain}"
+    assert f_fold < max(3e-2, 1.5 * f_plain), (f_fold, f_plain)

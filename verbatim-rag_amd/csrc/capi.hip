@@ -65,9 +65,13 @@ __global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __re
   }
 }
 
-// (mu, rstd) per token row from the per-segment partial sums left by the residual GEMM epilogue.
+// Row statistics from the per-segment partial sums left by the residual GEMM epilogue.  The sums are over (h - c)
+// with c = shift[r] (the row's previous mean; null = 0):  d = mean(h - c),  var = E[(h-c)^2] - d^2  -- no
+// cancellation however large |mean(h)| is --, mu_rel[r] = d (what the consumer GEMM's fold subtracts from its
+// bf16(h - c) operand), shift[r] <- c + d (the absolute mean: next shift, and the post-LN rebuild's mean).
 __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np, int H, float eps, int rows,
-                                         float* __restrict__ mu, float* __restrict__ rstd) {
+                                         float* __restrict__ mu_rel, float* __restrict__ rstd, const float* shift_in,
+                                         float* shift_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float s1 = 0.f, s2 = 0.f;
@@ -75,10 +79,12 @@ __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np,
     s1 += part[((size_t)r * np + i) * 2];
     s2 += part[((size_t)r * np + i) * 2 + 1];
   }
-  const float m = s1 / (float)H;
-  const float var = fmaxf(s2 / (float)H - m * m, 0.f);
-  mu[r] = m;
+  const float d = s1 / (float)H;
+  const float var = fmaxf(s2 / (float)H - d * d, 0.f);
+  const float c = shift_in ? shift_in[r] : 0.f;
+  mu_rel[r] = d;
   rstd[r] = 1.0f / sqrtf(var + eps);
+  shift_out[r] = c + d;
 }
 
 // One workgroup per sequence: stable compaction of a SPLADE row (weights are >= 0) into (index, value) pairs.
@@ -206,7 +212,8 @@ struct vrag_encoder {
   float* h = nullptr;
   bf16_t *a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr, *act = nullptr;
   float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
-  float *st_part = nullptr, *ln_mu = nullptr, *ln_rstd = nullptr;  // folded-LayerNorm row statistics
+  float *st_part = nullptr, *ln_mu = nullptr, *ln_rstd = nullptr;  // folded-LayerNorm row statistics (ln_mu relative to ln_shift's previous value)
+  float* ln_shift = nullptr;                                        // absolute row means = the next residual epilogue's shift
   int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;     // global-layer q-blocks
   int *d_lblk_start = nullptr, *d_lblk_len = nullptr, *d_lblk_q0 = nullptr;  // banded-layer q-blocks
   int cap_blocks = 0;
@@ -418,11 +425,12 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         int rc = layer_norm(L.attn_norm);
         if (rc) return rc;
       }
-      auto finalize_stats = [&]() -> int {
+      // `first`: no previous mean to shift by (c = 0)
+      auto finalize_stats = [&](bool first) -> int {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st,
                            e->st_part + (size_t)r0 * (H / 64) * 2, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
-                           e->ln_rstd + r0);
+                           e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0);
         HIP_TRY(hipGetLastError());
         return VRAG_OK;
       };
@@ -475,22 +483,30 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.N = H;
         g.K = H;
         g.out_f32 = e->h + (size_t)r0 * H;
-        if (fold) {
+        // The fold's per-row shift is the row's previous mean; the very first sub-layer has none, so layer 0's
+        // mlp_norm runs as a stand-alone (two-pass) LayerNorm that also records the exact row means.
+        const bool fold_here = fold && l > 0;
+        if (fold_here) {
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+          g.ln_shift = e->ln_shift + r0;
         }
         ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
-      {
-        int rc = fold ? finalize_stats() : layer_norm(L.mlp_norm);
+      if (fold && l == 0) {   // a = bf16(normalised h) without the gain (folded into Wi), ln_shift = mean(h)
+        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, nullptr, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr,
+                                 e->ln_shift + r0));
+      } else {
+        int rc = fold ? finalize_stats(false) : layer_norm(L.mlp_norm);
         if (rc) return rc;
       }
       {
         GemmParams g{};
         g.A = e->a + (size_t)r0 * H;
         g.W = L.wi;
-        if (fold) {
+        if (fold && l > 0) {
           g.ln_mu = e->ln_mu + r0;
           g.ln_rstd = e->ln_rstd + r0;
           g.ln_s = L.s_wi;
@@ -513,12 +529,13 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         if (fold && l + 1 < c.num_layers) {  // the next layer's attn_norm is folded into its QKV GEMM
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+          g.ln_shift = e->ln_shift + r0;
         }
         ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
       if (fold && l + 1 < c.num_layers) {
-        int rc = finalize_stats();
+        int rc = finalize_stats(false);
         if (rc) return rc;
       }
     }
@@ -566,10 +583,10 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
     }
     const bool fold = e->ln_fold;
     float* st_part = e->st_part + (size_t)r0 * (H / 64) * 2;
-    auto finalize_stats = [&]() -> int {
+    auto finalize_stats = [&](bool first) -> int {
       ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
       hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, st_part, H / 64, H, c.norm_eps, M,
-                         e->ln_mu + r0, e->ln_rstd + r0);
+                         e->ln_mu + r0, e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0);
       HIP_TRY(hipGetLastError());
       return VRAG_OK;
     };
@@ -631,20 +648,20 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.bias = L.bo;
         if (lazy_in) {
           const BertLayer& P = e->blayers[l - 1];
-          g.res_mu = e->ln_mu + r0;
+          g.res_mu = e->ln_shift + r0;   // absolute mean of t2 of the previous layer
           g.res_rstd = e->ln_rstd + r0;
           g.res_g = P.ln2_w;
           g.res_b = P.ln2_b;
         }
         if (fold) {
           g.resid_bf16 = a;
-          g.stats_part = st_part;
+          g.stats_part = st_part;   // no shift here: a post-LN stream is re-centred by every LayerNorm (mean = O(1) sigma)
         }
         ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
       if (fold) {
-        int rc = finalize_stats();   // statistics of t1 = attention sub-layer sum (LN1 stays lazy)
+        int rc = finalize_stats(true);   // statistics of t1 = attention sub-layer sum (LN1 stays lazy)
         if (rc) return rc;
       } else {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
@@ -678,7 +695,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.out_f32 = h;
         g.bias = L.b2;
         if (fold) {
-          g.res_mu = e->ln_mu + r0;
+          g.res_mu = e->ln_shift + r0;   // absolute mean of t1
           g.res_rstd = e->ln_rstd + r0;
           g.res_g = L.ln1_w;
           g.res_b = L.ln1_b;
@@ -689,7 +706,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
       }
       if (fold && l + 1 < n_layers) {
-        int rc = finalize_stats();   // statistics of t2: the next layer consumes LN2 lazily
+        int rc = finalize_stats(true);   // statistics of t2: the next layer consumes LN2 lazily
         if (rc) return rc;
       } else {
         // materialise the layer output (last layer of this run, or un-folded mode): h <- LN2(h), a <- bf16(h)
@@ -751,6 +768,7 @@ int init_workspace(vrag_encoder* e) {
   TRY(dev_alloc(e, &e->st_part, R * (H / 64) * 2));
   TRY(dev_alloc(e, &e->ln_mu, R));
   TRY(dev_alloc(e, &e->ln_rstd, R));
+  TRY(dev_alloc(e, &e->ln_shift, R));
   TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
   TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
@@ -1670,6 +1688,10 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
   g.pos = pos;
   g.hidden = N / 3;
   g.q_scale = 0.125f;
+  if (epi == EPI_RESIDUAL && !getenv("VRAG_DEBUG_GEMM_PLAIN_RESID")) {   // as the encoder launches it with the LayerNorm fold
+    g.resid_bf16 = (bf16_t*)outb;
+    g.stats_part = (float*)q;                                              // Mp * N/64 * 2 floats <= Mp * N * 2 bytes
+  }
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);

@@ -37,10 +37,10 @@ struct GemmParams {
   // EPI_SPLADE
   const int* tok_seq;  // [Mpad] sequence index of each token, -1 for padding tokens
   unsigned* splade_rows;  // [n_seqs, N] float bits (values >= 0 so uint order == float order)
-  // LayerNorm folded into the GEMM (EPI_QKV_ROPE, EPI_GEGLU): A = bf16(h) (un-normalised residual),
-  // W' = W * ln_weight (per input column), ln_s[n] = sum_k W'[n][k]; the epilogue applies
-  //   out[m][n] = ln_rstd[m] * (acc[m][n] - ln_mu[m] * ln_s[n])  ==  (LayerNorm(h) . W^T)[m][n].
-  const float* ln_mu;     // [Mpad] row means of h (null = no fold)
+  // LayerNorm folded into the GEMM (EPI_QKV_ROPE, EPI_GEGLU): A = bf16(h - c) (un-normalised residual minus a per-row
+  // shift c), W' = W * ln_weight (per input column), ln_s[n] = sum_k W'[n][k]; the epilogue applies
+  //   out[m][n] = ln_rstd[m] * (acc[m][n] - ln_mu[m] * ln_s[n])  ==  (LayerNorm(h) . W^T)[m][n],   ln_mu = mean(h) - c.
+  const float* ln_mu;     // [Mpad] row means of (h - c) (null = no fold)
   const float* ln_rstd;   // [Mpad] 1/sqrt(var + eps)
   const float* ln_s;      // [N]
   // EPI_RESIDUAL extras: bf16 copy of the updated residual rows (the next GEMM's A operand) and the
@@ -50,7 +50,8 @@ struct GemmParams {
   const float* res_rstd;  // [Mpad]
   const float* res_g;     // [N] LayerNorm gain
   const float* res_b;     // [N] LayerNorm bias
-  bf16_t* resid_bf16;     // [Mpad, N] or null
+  const float* ln_shift;  // [Mpad] or null: per-row shift c subtracted before the bf16 copy / the statistics (see the epilogue)
+  bf16_t* resid_bf16;     // [Mpad, N] or null  = bf16(updated residual - c)
   float* stats_part;      // [Mpad, N/64, 2] or null
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias

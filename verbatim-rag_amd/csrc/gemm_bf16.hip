@@ -141,6 +141,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         }
         store16_nt(dst, v);
         if constexpr (EPI == EPI_RESIDUAL) {
+          // LayerNorm fold: the bf16 operand copy and the row statistics are taken RELATIVE to a per-row shift c (the
+          // row's mean after the previous sub-layer, a close estimate of its new mean): bf16(h - c) spends its 8
+          // mantissa bits on the deviation instead of on a common offset, and sum / sum of squares of (h - c) do
+          // not cancel in  var = E[(h-c)^2] - (mu-c)^2  however large |mean| / sigma is.
+          if (p.ln_shift) {
+            const float c_ = p.ln_shift[mw + ps * 64 + row];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] -= c_;
+          }
           if (p.resid_bf16) {
             bf16x4 o;
 #pragma unroll
@@ -148,7 +157,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             store8_nt(p.resid_bf16 + (size_t)(mw + ps * 64 + row) * p.N + nw + c16 * 4, o);
           }
           if (p.stats_part) {
-            // the 16 lanes of a row segment reduce (sum, sum of squares) of the UPDATED residual
+            // the 16 lanes of a row segment reduce (sum, sum of squares) of the UPDATED residual (minus the shift)
             float s1 = (v[0] + v[1]) + (v[2] + v[3]);
             float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
@@ -569,7 +578,8 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4>), dim3(std::min(nbm * nbn, 256)), dim3(256), SMEM, stream, p);
     return hipGetLastError();
   }
-  if (!force128 && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
+  static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
+  if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
     constexpr int BM = 256, BN = 256, SMEM = 2 * (BM + BN) * BK * 2;
     static bool attr = false;
     if (!attr) {

@@ -14,8 +14,10 @@ hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float
                            const int* type_ids = nullptr);   // type_ids: per-token row of the table at type_row
 
 // out = LN(h) * w (+ bias); writes bf16 and/or fp32 (either pointer may be null; out_f32 may be h itself).
+// w == nullptr: no gain (it is folded into the consumer GEMM's weight); row_mean != nullptr: also mean(h[row]).
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows,
-                            bf16_t* out_bf16, float* out_f32, hipStream_t stream, const float* bias = nullptr);
+                            bf16_t* out_bf16, float* out_f32, hipStream_t stream, const float* bias = nullptr,
+                            float* row_mean = nullptr);
 
 // For each range r: v = mean_{t in [start[r], end[r]]} LN(h[t]) * lnw   (inclusive token range; lnw == nullptr:
 // no LayerNorm, v = mean of h -- post-LN encoders)

@@ -23,11 +23,12 @@ __device__ __forceinline__ void load_row(const float* row, int H, int lane, f32x
 
 // In-register LayerNorm (biased variance, two-pass), result overwrites x.
 __device__ __forceinline__ void ln_row(f32x4 (&x)[MAXV], const f32x4 (&w)[MAXV], int H, int lane, float eps,
-                                       const float* bias = nullptr) {
+                                       const float* bias = nullptr, float* mean_out = nullptr) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
   const float mean = wave_sum(s) / (float)H;
+  if (mean_out) *mean_out = mean;
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -96,14 +97,22 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
 // `of` may alias `h` (in place): a row is fully in registers before anything is written.
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const float* __restrict__ w,
                                                          float eps, int H, int rows, bf16_t* __restrict__ ob,
-                                                         float* of, const float* __restrict__ bias) {
+                                                         float* of, const float* __restrict__ bias,
+                                                         float* __restrict__ row_mean) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 x[MAXV], wv[MAXV];
   load_row(h + (size_t)row * H, H, lane, x);
-  load_row(w, H, lane, wv);
-  ln_row(x, wv, H, lane, eps, bias);
+  if (w) {
+    load_row(w, H, lane, wv);
+  } else {   // gain already folded into the consumer's weight
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) wv[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  float mean = 0.f;
+  ln_row(x, wv, H, lane, eps, bias, &mean);
+  if (row_mean && lane == 0) row_mean[row] = mean;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane * 4 + 256 * i;
@@ -271,10 +280,10 @@ hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float
 }
 
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows, bf16_t* ob, float* of,
-                            hipStream_t stream, const float* bias) {
+                            hipStream_t stream, const float* bias, float* row_mean) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean);
   return hipGetLastError();
 }
 

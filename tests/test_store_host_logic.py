@@ -145,9 +145,9 @@ def test_query_normalisation_is_the_same_row_by_row_or_batched(store):
     st._dense.search = lambda q, k, stream=None: (seen.append(np.array(q)), (np.zeros((len(q), k), np.float32), np.full((len(q), k), -1, np.int64)))[1]
     X = rng.standard_normal((50, 64)).astype(np.float32) * np.float32(3)
     X[7] = 0
-    st._device_topk("dense", st._dense, st._main_rows, X.tolist(), 3)
+    st._device_topk("dense", st._dense, None, X.tolist(), 3)
     for i in range(len(X)):
-        st._device_topk("dense", st._dense, st._main_rows, [X[i].tolist()], 3)
+        st._device_topk("dense", st._dense, None, [X[i].tolist()], 3)
     want = np.stack([q / float(np.sqrt((q * q).sum(dtype=np.float32))) if q.any() else q for q in X])
     assert np.array_equal(seen[0], want) and all(np.array_equal(seen[1 + i][0], want[i]) for i in range(len(X)))
 

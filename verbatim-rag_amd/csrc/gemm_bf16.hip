@@ -36,7 +36,7 @@
 
 namespace vrag {
 
-constexpr int BK = 64;
+constexpr int BK = 64;   // K-step of the throughput configurations; the kernel template takes BKT = 64 or 32
 
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
 
@@ -74,56 +74,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[ni][mi][r]));
   } else if constexpr (EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_RESIDUAL) {
-    // fp32 [64 rows][64 cols] per pass (256-byte rows, 16 chunks), MI/2 passes
-    f32x4 hv[16];
+    // fp32 [64 rows][64 cols] per pass (256-byte rows, 16 chunks), MI/2 passes; a pass is read back in two halves of
+    // 32 rows (8 row-segment instructions each).  Residual: the h rows of a half are prefetched one half ahead
+    // (two 8 x 16-byte register sets, 8 KiB per wave in flight), so the fp32 read-modify-write is one HBM round trip
+    // per pass that runs under the previous half's LDS reads and stores.
+    constexpr int HALF = 8;
+    f32x4 hA[HALF], hB[HALF];
+    float cw[MI / 2];   // residual + LayerNorm fold: lane L holds the shift of row ps*64 + L (fetched by bpermute below)
+    auto h_ptr = [&](int hp, int i) {   // half-pass hp = 2*ps + half, instruction i: 4 rows x 16 lanes
+      const int row = (hp >> 1) * 64 + (hp & 1) * 32 + i * 4 + (lane >> 4);
+      return p.out_f32 + (size_t)(mw + row) * p.N + nw + (lane & 15) * 4;
+    };
+    auto prefetch = [&](f32x4 (&dst)[HALF], int hp) {
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) dst[i] = load16_nt(h_ptr(hp, i));
+    };
     if constexpr (EPI == EPI_RESIDUAL) {
+      prefetch(hA, 0);
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4), c16 = lane & 15;
-        hv[it] = load16_nt(p.out_f32 + (size_t)(mw + row) * p.N + nw + c16 * 4);
-      }
+      for (int ps = 0; ps < MI / 2; ++ps) cw[ps] = p.ln_shift ? p.ln_shift[mw + ps * 64 + lane] : 0.f;
     }
+    auto finish_half = [&](const f32x4 (&hv)[HALF], int hp) {
+      const int ps = hp >> 1;
 #pragma unroll
-    for (int ps = 0; ps < MI / 2; ++ps) {
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        const int mi = ps * 2 + mh;
-        const int row = mh * 32 + l31;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-            if constexpr (EPI == EPI_F32_GELU) {
-              if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + ni * 32 + 8 * g + 4 * hi);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            }
-            const int c16 = ni * 8 + 2 * g + hi;
-            *reinterpret_cast<f32x4*>(stg + row * 256 + ((c16 ^ (row & 15)) << 4)) = v;
-          }
-      }
-      // residual: this pass's h rows were prefetched (pass 0: before the main loop); put the next
-      // pass's 16 loads in flight now, while the LDS round trip and the stores of this pass run.
-      f32x4 hn[16];
-      if constexpr (EPI == EPI_RESIDUAL) {
-        if (ps + 1 < MI / 2) {
-#pragma unroll
-          for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + (lane >> 4), c16 = lane & 15;
-            hn[it] = load16_nt(p.out_f32 + (size_t)(mw + (ps + 1) * 64 + row) * p.N + nw + c16 * 4);
-          }
-        }
-      }
-      // read back: 16 lanes per row, 4 rows per instruction
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4), c16 = lane & 15;
+      for (int i = 0; i < HALF; ++i) {
+        const int row = (hp & 1) * 32 + i * 4 + (lane >> 4), c16 = lane & 15;   // row inside the pass
         f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
         float* dst = p.out_f32 + (size_t)(mw + ps * 64 + row) * p.N + nw + c16 * 4;
         if constexpr (EPI == EPI_RESIDUAL) {
+          f32x4 hin = hv[i];
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);   // BERT-family linears have biases
           if (p.res_mu) {
             // post-LN encoders keep the PRE-LayerNorm sum in the stream; the residual input LN(t) is rebuilt here
@@ -133,9 +112,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const f32x4 g_ = *reinterpret_cast<const f32x4*>(p.res_g + nw + c16 * 4);
             const f32x4 b_ = *reinterpret_cast<const f32x4*>(p.res_b + nw + c16 * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hv[it][j] = (hv[it][j] - m_) * r_ * g_[j] + b_[j];
+            for (int j = 0; j < 4; ++j) hin[j] = (hin[j] - m_) * r_ * g_[j] + b_[j];
           }
-          v += hv[it];
+          v += hin;
         } else if constexpr (EPI == EPI_F32) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + c16 * 4);
         }
@@ -146,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           // mantissa bits on the deviation instead of on a common offset, and sum / sum of squares of (h - c) do
           // not cancel in  var = E[(h-c)^2] - (mu-c)^2  however large |mean| / sigma is.
           if (p.ln_shift) {
-            const float c_ = p.ln_shift[mw + ps * 64 + row];
+            const float c_ = __shfl(cw[ps], row, 64);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] -= c_;
           }
@@ -173,12 +152,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           }
         }
       }
-      if constexpr (EPI == EPI_RESIDUAL) {
-        if (ps + 1 < MI / 2) {
+    };
 #pragma unroll
-          for (int it = 0; it < 16; ++it) hv[it] = hn[it];
-        }
+    for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int mi = ps * 2 + mh;
+        const int row = mh * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+            if constexpr (EPI == EPI_F32_GELU) {
+              if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + ni * 32 + 8 * g + 4 * hi);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
+            const int c16 = ni * 8 + 2 * g + hi;
+            *reinterpret_cast<f32x4*>(stg + row * 256 + ((c16 ^ (row & 15)) << 4)) = v;
+          }
       }
+      // half 0 of this pass came in under the staging writes; fetch half 1 now, and the next pass's half 0 under half 1
+      if constexpr (EPI == EPI_RESIDUAL) prefetch(hB, 2 * ps + 1);
+      finish_half(hA, 2 * ps);
+      if constexpr (EPI == EPI_RESIDUAL) {
+        if (ps + 1 < MI / 2) prefetch(hA, 2 * ps + 2);
+      }
+      finish_half(hB, 2 * ps + 1);
     }
   } else if constexpr (EPI == EPI_BF16) {
 #pragma unroll
@@ -371,15 +374,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // NS = LDS stages (power of two).  2: the throughput configuration (one stage in flight, plain barriers).  4: the
 // small-batch configuration -- with a handful of tiles the K loop is a chain of memory round trips, and three
 // stages in flight (counted vmcnt, raw barriers) cut that chain to a third.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+//
+// BKT = K-step: 64 (128-byte LDS rows, chunk swizzle (row>>1)&7) or 32 (64-byte rows, swizzle (row>>2)&3 -- both make every
+// 16-lane ds_read_b128 group cover the 64 banks exactly once).  BKT = 32 halves the bytes of a stage, which is what lets a
+// 128 x 256 tile with three stages (72 KiB, 4 waves) run as TWO workgroups per CU: the configuration of the residual
+// GEMMs, whose fp32 read-modify-write epilogue is HBM-bound -- one workgroup's epilogue then streams under the other's
+// main loop instead of leaving the matrix cores idle.
+template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
-  static_assert(NS == 2 || NS == 4, "LDS stages");
+  static_assert(NS >= 2 && NS <= 4, "LDS stages");
+  static_assert(BKT == 64 || BKT == 32, "K-step");
+  constexpr int ROWB = BKT * 2;               // bytes per LDS row
+  constexpr int RPI = 1024 / ROWB;            // tile rows filled by one LDS-DMA instruction (64 lanes x 16 bytes)
+  constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
+  constexpr int KS = BKT / 16;                // MFMA k-substeps per stage
   constexpr int MI = BM / WM / 32;            // 32-row accumulator tiles per wave
-  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int A_INSTR = BM / 8 / (WM * WN); // LDS-DMA instructions per wave per stage (8 rows each)
-  constexpr int W_INSTR = BN / 8 / (WM * WN);
-  static_assert(A_INSTR * 8 * WM * WN == BM && W_INSTR * 8 * WM * WN == BN, "tile rows must split over the waves");
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = BM / RPI / (WM * WN); // LDS-DMA instructions per wave per stage
+  constexpr int W_INSTR = BN / RPI / (WM * WN);
+  static_assert(A_INSTR * RPI * WM * WN == BM && W_INSTR * RPI * WM * WN == BN, "tile rows must split over the waves");
+  static_assert(NS * STAGE_BYTES >= WM * WN * 16384, "the epilogues stage 16 KiB per wave through the operand ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -406,32 +421,33 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 
-  // LDS-DMA staging: instruction i of this wave fills tile rows wave*8*INSTR + i*8 .. +8.
+  // LDS-DMA staging: instruction i of this wave fills tile rows wave*RPI*INSTR + i*RPI .. +RPI.
+  auto swz = [](int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   int soffA[A_INSTR], soffW[W_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    const int row = wave * (8 * A_INSTR) + i * 8 + (lane >> 3);
-    soffA[i] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    const int row = wave * (RPI * A_INSTR) + i * RPI + lane / CPR;
+    soffA[i] = row * K + (((lane % CPR) ^ swz(row)) << 3);
   }
 #pragma unroll
   for (int i = 0; i < W_INSTR; ++i) {
-    const int row = wave * (8 * W_INSTR) + i * 8 + (lane >> 3);
-    soffW[i] = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    const int row = wave * (RPI * W_INSTR) + i * RPI + lane / CPR;
+    soffW[i] = row * K + (((lane % CPR) ^ swz(row)) << 3);
   }
   // fragment read offsets (bytes inside a 32-row sub-tile)
-  const int sw = (lane >> 1) & 7;
-  int fo[4];
+  const int sw = swz(l31);
+  int fo[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) fo[s] = l31 * 128 + ((((2 * s + hi) ^ sw)) << 4);
+  for (int s = 0; s < KS; ++s) fo[s] = l31 * ROWB + ((((2 * s + hi) ^ sw)) << 4);
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE_BYTES;
     char* sW = sA + A_BYTES;
-    const int k0 = kt * BK;
+    const int k0 = kt * BKT;
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) glds16(Ab + soffA[i] + k0, sA + (wave * (8 * A_INSTR) + i * 8) * 128);
+    for (int i = 0; i < A_INSTR; ++i) glds16(Ab + soffA[i] + k0, sA + (wave * (RPI * A_INSTR) + i * RPI) * ROWB);
 #pragma unroll
-    for (int i = 0; i < W_INSTR; ++i) glds16(Wb + soffW[i] + k0, sW + (wave * (8 * W_INSTR) + i * 8) * 128);
+    for (int i = 0; i < W_INSTR; ++i) glds16(Wb + soffW[i] + k0, sW + (wave * (RPI * W_INSTR) + i * RPI) * ROWB);
   };
 
   f32x16 acc[2][MI];
@@ -444,7 +460,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
 
   const int nw = n0 + wn * 64;      // first feature of this wave's 64-wide range
   const int mw = m0 + wm * WROWS;   // first token row of this wave
-  const int KT = K / BK;
+  const int KT = K / BKT;
   // The V third of the QKV product is computed un-swapped (activations as the A operand): then a
   // lane holds 4 consecutive TOKENS of one feature, which is the V^T row layout attention wants.
   bool v_block = false;
@@ -486,19 +502,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
                                                      __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
       }
     }
+    int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
-      const int buf = kt & (NS - 1);
-      const int nxt = kt + NS - 1, nbuf = nxt & (NS - 1);   // the slot read in step kt-1: every wave passed the barrier since
+      const int nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;   // the slot read in step kt-1: every wave passed the barrier since
       const bool do_stage = nxt < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
 #if VRAG_DMA_SPLIT == 0
       if (do_stage) stage(nxt, nbuf);
 #elif VRAG_DMA_SPLIT == 1
       if (do_stage && wave < (WM * WN) / 2) stage(nxt, nbuf);   // first half of the waves: right after the barrier
 #endif
-      const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * 128;
-      const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * 128;
+      const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
+      const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < KS; ++s) {
 #if VRAG_DMA_SPLIT == 1
         if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(nxt, nbuf);   // second half: one substep later
 #endif
@@ -511,7 +527,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
         } else if (DBG && (p.debug_flags & 4)) {   // probe: fresh pseudo-random register operands per MFMA group, no LDS read
 #pragma unroll
           for (int i = 0; i < MI + 2; ++i) {
-            unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)((i * 4 + s + kt * 16) * 40503u);
+            unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)((i * KS + s + kt * 16) * 40503u);
             unsigned w4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -526,9 +542,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
         }
         if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + fo[s]);
+          for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * ROWB + fo[s]);
 #pragma unroll
-          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * 128 + fo[s]);
+          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + fo[s]);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -542,6 +558,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmParam
       }
       wait_allow(max(0, min(NS - 2, KT - 2 - kt)));   // step kt+1 has landed (this wave's share)
       step_barrier();
+      buf = buf + 1 == NS ? 0 : buf + 1;
     }
   };
   if (v_block) mainloop(std::false_type{});
@@ -577,6 +594,26 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     p.n_tiles = nbm * nbn;
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4>), dim3(std::min(nbm * nbn, 256)), dim3(256), SMEM, stream, p);
     return hipGetLastError();
+  }
+  // Residual GEMMs (HBM-bound epilogue): 128 x 256 tiles, 4 waves, BK = 32 x 3 stages = 72 KiB -> two workgroups per CU,
+  // one's read-modify-write streams under the other's main loop (VRAG_GEMM_RES_PAIR=1).
+  static const bool res_pair = getenv("VRAG_GEMM_RES_PAIR") && atoi(getenv("VRAG_GEMM_RES_PAIR")) != 0;   // measured slower (r2b: 178 / 222 us vs 166 / 198 us on the 256 x 256 tile): opt-in
+  if constexpr (EPI == EPI_RESIDUAL) {
+    if (res_pair && !force128 && p.N % 256 == 0 && p.M >= 256 && p.K % 32 == 0) {
+      constexpr int BM = 128, BN = 256, SMEM = 3 * (BM + BN) * 32 * 2;
+      static bool attr_p = false;
+      if (!attr_p) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return e;
+        attr_p = true;
+      }
+      const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+      p.n_tiles = nbm * nbn;
+      static const int pgrid2 = getenv("VRAG_GEMM_PGRID2") ? atoi(getenv("VRAG_GEMM_PGRID2")) : 512;   // 2 workgroups per CU
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32>), dim3(std::min(nbm * nbn, pgrid2)), dim3(256), SMEM, stream, p);
+      return hipGetLastError();
+    }
   }
   static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
   if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {

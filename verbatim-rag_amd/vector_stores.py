@@ -603,6 +603,9 @@ class GpuVectorStore(VectorStore):
             if not self._dirty:
                 return
             n = len(self._owned)
+            # published before the device append: a search that is running on the resident shard decodes its hits with
+            # the mapping it reads AFTER the kernel returns, so every row the kernel can have seen is in it
+            self._main_rows = np.asarray(self._owned, dtype=np.int64)
             if self.enable_dense and n > self._dense_flushed:
                 fresh = np.stack(self._dense_rows[self._dense_flushed:])
                 if self._dense is None or n > self._dense_cap:
@@ -618,15 +621,13 @@ class GpuVectorStore(VectorStore):
             if self.enable_sparse:
                 self._sparse = None
                 self._sparse = SparseShard(self.sparse_vocab, *dicts_to_csr(self._sparse_rows), device=self.device) if n else None
-            self._main_rows = np.asarray(self._owned, dtype=np.int64)
             self._dirty = False
 
     def _main_shard(self, kind: str):
-        """(shard or None, global row of each of its rows, rows in the whole store) after a flush, captured under the lock."""
+        """(shard or None, rows in the whole store) after a flush, captured under the lock."""
         with self._mu:
             self._flush()
-            rows = self._main_rows if self._main_rows is not None else np.zeros(0, np.int64)
-            return (self._dense if kind == "dense" else self._sparse), rows, len(self._ids)
+            return (self._dense if kind == "dense" else self._sparse), len(self._ids)
 
     # -------------------------------------------------------------- search
     def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
@@ -683,12 +684,13 @@ class GpuVectorStore(VectorStore):
     def _search(self, kind: str, query, limit: int, mask: Optional[np.ndarray]) -> List[dict]:
         return self._search_batch(kind, [query], limit, mask)[0]
 
-    def _device_topk(self, kind: str, shard, shard_rows: np.ndarray, queries: Sequence[Any], k: int):
+    def _device_topk(self, kind: str, shard, shard_rows: Optional[np.ndarray], queries: Sequence[Any], k: int):
         """Top-k of `queries` over one (possibly sharded) set of rows -> (`scores [Q, k]`, GLOBAL `rows [Q, k]`, -1 = no
         hit).  `shard` is this rank's part (None when it holds none of the rows) and `shard_rows[j]` the global row of
-        its row j; with more than one rank the per-shard lists meet in one all-gather and are merged on the GPU."""
+        its row j (None = the resident main shard, whose append-only mapping is read after the search); with more than
+        one rank the per-shard lists meet in one all-gather and are merged on the GPU."""
         Q = len(queries)
-        if shard is None or len(shard_rows) == 0:
+        if shard is None:
             scores = np.full((Q, k), -np.inf, np.float32)
             rows = np.full((Q, k), -1, np.int64)
         else:
@@ -698,8 +700,9 @@ class GpuVectorStore(VectorStore):
                 scores, local = shard.search(rows_q / np.where(norms > 0, norms, np.float32(1.0))[:, None], k)
             else:
                 scores, local = shard.search(queries, k)       # dicts_to_csr converts keys / weights to int32 / float32
-            found = local >= 0
-            rows = np.where(found, shard_rows[np.where(found, local, 0)], -1)
+            mapping = shard_rows if shard_rows is not None else self._main_rows
+            found = (local >= 0) & (local < len(mapping))
+            rows = np.where(found, mapping[np.where(found, local, 0)], -1) if len(mapping) else np.full_like(local, -1)
         if self._world > 1:
             scores, rows = self._comm.allgather_merge(scores, rows, k)
         return scores, rows
@@ -715,7 +718,8 @@ class GpuVectorStore(VectorStore):
             hit = self._subsets.get(key)
             if hit is None:
                 owned = np.asarray(self._owned, dtype=np.int64)
-                local = np.nonzero(mask[owned])[0] if len(owned) else np.zeros(0, np.int64)
+                known = owned < len(mask)                     # rows inserted after the caller built its mask are not in it
+                local = np.nonzero(known & mask[np.where(known, owned, 0)])[0] if len(owned) else np.zeros(0, np.int64)
                 shard = None
                 if len(local) and kind == "dense":
                     shard = DenseShard(self.dense_dim, len(local), self.dense_dtype, self.device)
@@ -732,7 +736,8 @@ class GpuVectorStore(VectorStore):
             self._subsets.clear()
             self._masks.clear()
 
-    def _topk_rows(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    def _topk_rows(self, kind: str, queries: Sequence[Any], limit: int, mask: Optional[np.ndarray],
+                   _retry: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         """Best `limit` rows per query among the rows that pass `mask`: `rows [Q, limit]` (-1 = no hit, tail only) and
         their fp32 scores.  One device pass for the whole batch over the full shard; queries that come up short because
         filtered / deleted rows took their slots (and every query when the filter passes under 1/8 of the rows) get a
@@ -741,7 +746,7 @@ class GpuVectorStore(VectorStore):
         if limit > self.K_LIMIT:
             raise ValueError(f"GpuVectorStore: a search may ask for at most {self.K_LIMIT} rows per method "
                              f"(got {limit}; hybrid search asks for 2 * top_k)")
-        main, main_rows, n = self._main_shard(kind)
+        main, n = self._main_shard(kind)
         if mask is not None and len(mask) != n:     # rows were inserted after the caller built its mask
             mask = np.concatenate([mask, np.zeros(n - len(mask), dtype=bool)]) if len(mask) < n else mask[:n]
         Q = len(queries)
@@ -754,7 +759,10 @@ class GpuVectorStore(VectorStore):
         want = min(k, n_pass)
         short = np.ones(Q, dtype=bool)
         if mask is None or n_pass * 8 >= n:
-            scores, rows = self._device_topk(kind, main, main_rows, queries, k)
+            scores, rows = self._device_topk(kind, main, None, queries, k)
+            if (rows >= n).any() and _retry < 3:      # rows inserted while this search ran took slots: search again
+                return self._topk_rows(kind, queries, limit, mask, _retry + 1)
+            rows = np.where(rows < n, rows, -1)
             found = rows >= 0
             valid = found if mask is None else found & mask[np.where(found, rows, 0)]
             count = valid.sum(axis=1)

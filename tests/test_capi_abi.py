@@ -84,3 +84,17 @@ def test_graft_entry_build_is_consistent_with_the_binding():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build()   # incremental: objects are up to date after the session's build
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libvrag_amd.so first, torch second must still leave ONE libamdhip64 mapped (torch's wheel bundles its own copy
+    under an un-versioned NEEDED name; two runtimes in one process = torch sees no GPU, r2c GPU session)."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); import verbatim_rag_amd; from verbatim_rag_amd import _lib; _lib.load(); "
+            "import torch; "
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout

@@ -29,28 +29,61 @@ def test_dense_topk_exact_on_dyadic_grid(dtype, n, dim, nq, k):
     assert np.array_equal(s, rs)
 
 
-def test_dense_topk_random_data_recall_and_scores():
-    """Non-dyadic data: accumulation order differs from the oracle, so scores agree to rounding and the
-    ranking to recall.  One query keeps fp32 query values; >= 3 queries take the matrix-core path,
-    which rounds the QUERIES to bf16 as well (rows are bf16 in both)."""
+def _assert_same_ranking(got_s, got_i, ref_s, ref_i, rows, queries, tol=2e-6, max_swapped=0.02):
+    """Top-k lists agree up to fp32 near-ties: wherever the ids differ, the two rows' exact (float64) scores are within
+    `tol` of each other -- no fp32 implementation with a different summation order than the oracle's can do better --
+    and such positions are rare."""
+    assert got_i.shape == ref_i.shape and np.abs(got_s - ref_s).max() < tol
+    diff = got_i != ref_i
+    assert diff.mean() <= max_swapped, f"{diff.sum()} of {diff.size} positions differ"
+    r64, q64 = rows.astype(np.float64), queries.astype(np.float64)
+    for q, p in zip(*np.nonzero(diff)):
+        a = float(r64[got_i[q, p]] @ q64[q])
+        b = float(r64[ref_i[q, p]] @ q64[q])
+        assert abs(a - b) < tol, (q, p, got_i[q, p], ref_i[q, p], a, b)
+        assert set(got_i[q]) == set(ref_i[q]) or abs(a - float(ref_s[q, -1])) < tol
+
+
+def test_dense_topk_random_data_ranking_equals_the_fp32_query_oracle():
+    """Non-dyadic data (normalised Gaussian rows, fp32 queries that are NOT bf16 numbers).  The accumulation order
+    differs from the oracle's sequential fmaf chain, so scores agree to fp32 summation noise; the top-k ids must be the
+    oracle's, position by position, except where two rows' scores tie to within that noise (a handful of positions
+    among thousands; dyadic-grid data, where every sum is exact, is compared bit for bit in the tests above).
+    Single queries run the scalar fp32-query kernel; batches of >= 3 over bf16 rows run on the matrix cores with every
+    query carried as a (bf16, bf16 remainder) column pair (topk.hip `split`: 16 significant bits -- with plain bf16
+    queries 11 of these 400 positions come out different and scores are off by 2e-4); fp32 rows take the scalar
+    kernels at every batch size."""
     from verbatim_rag_amd.vector_stores import DenseShard
 
     rng = np.random.default_rng(1)
-    X = rng.standard_normal((50000, 768)).astype(np.float32)
+    X = rng.standard_normal((60000, 768)).astype(np.float32)
     X /= np.linalg.norm(X, axis=1, keepdims=True)
-    Q = X[:4] + 0.05 * rng.standard_normal((4, 768)).astype(np.float32)
-    sh = DenseShard(768, 50000, "bf16")
-    sh.add(X)
-    s4, i4 = sh.search(Q, 10)            # batched path
-    s1, i1 = sh.search(Q[:1], 10)        # single-query path
-    sh.close()
-    Xb = T.bf16_round(X)
-    rs, ri = T.dense_topk(Xb, Q, 10)                      # fp32 queries
-    rsb, rib = T.dense_topk(Xb, T.bf16_round(Q), 10)      # bf16-rounded queries
-    assert np.abs(s1 - rs[:1]).max() < 1e-4 and np.array_equal(i1[:, :3], ri[:1, :3])
-    assert np.abs(s4 - rsb).max() < 1e-4
-    recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(i4, ri)])
-    assert recall >= 0.95 and (i4[:, 0] == np.arange(4)).all() and (i1[:, 0] == 0).all()
+    Q = X[:40] + 0.05 * rng.standard_normal((40, 768)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    assert (Q.view(np.uint32) & 0xFFFF).any()                    # genuinely fp32 queries
+    for dtype, rows in (("bf16", T.bf16_round(X)), ("f32", X)):  # the oracle sees the rows the index stores
+        sh = DenseShard(768, 60000, dtype)
+        sh.add(X)
+        sb, ib = sh.search(Q, 10)            # batched path
+        s1, i1 = sh.search(Q[:1], 10)        # single-query path
+        sh.close()
+        rs, ri = T.dense_topk(rows, Q, 10)   # fp32 queries, sequential fp32 fmaf chain
+        _assert_same_ranking(sb, ib, rs, ri, rows, Q)
+        _assert_same_ranking(s1, i1, rs[:1], ri[:1], rows, Q[:1], max_swapped=0.2)
+        assert (ib[:, 0] == np.arange(40)).all()
+    # 384-d rows (the other matrix-core instantiation) and a dimension served by the first-generation kernel
+    for dim in (384, 256):
+        Xd = rng.standard_normal((30000, dim)).astype(np.float32)
+        Xd /= np.linalg.norm(Xd, axis=1, keepdims=True)
+        Qd = rng.standard_normal((19, dim)).astype(np.float32)
+        Qd /= np.linalg.norm(Qd, axis=1, keepdims=True)
+        sh = DenseShard(dim, 30000, "bf16")
+        sh.add(Xd)
+        sb, ib = sh.search(Qd, 8)
+        sh.close()
+        rows = T.bf16_round(Xd)
+        rs, ri = T.dense_topk(rows, Qd, 8)
+        _assert_same_ranking(sb, ib, rs, ri, rows, Qd)
 
 
 def test_dense_fewer_rows_than_k_and_empty():

@@ -126,6 +126,31 @@ def library_path() -> str:
     return os.environ.get("VRAG_AMD_LIB", os.path.join(_HERE, "libvrag_amd.so"))
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own `libamdhip64.so` and link it by that
+    un-versioned name, so when libvrag_amd.so (linked against the system `libamdhip64.so.7`) is loaded BEFORE torch, the
+    loader does not recognise the two as the same library and maps both: torch then finds no usable GPU, and stream
+    handles could not cross between the two runtimes.  Mapping torch's copy first (without importing torch) makes
+    libvrag_amd.so bind to it by SONAME -- the arrangement that `import torch` before this package produces anyway."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Loads the shared library and binds every declared symbol (raises if anything is missing)."""
     global _LIB
@@ -138,6 +163,7 @@ def load() -> C.CDLL:
                 f"{path} not found: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950). verbatim_rag_amd has no CPU fallback."
             )
+        _preload_torch_hip_runtime()
         lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -9,8 +9,35 @@ namespace vrag {
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MFMA operand type of an encoder: bf16 (default; fp32's exponent range) or fp16 (11 significant bits instead of 8 at
+// the same MFMA rate -- what the per-token logits of the v2 highlighter need to stay within 1e-3 of the fp32 reference,
+// tests/probes/precision_probe.py).  Both are 2 bytes: host-side buffers are typed bf16_t* whatever they hold and the
+// kernels, templated on the operand type, reinterpret them.  fp16 conversions saturate at +-65504 instead of
+// producing inf.
+constexpr int kOpBf16 = 0, kOpF16 = 1;
+template <typename T> struct Op;
+template <> struct Op<bf16_t> {
+  typedef bf16x4 v4;
+  typedef bf16x8 v8;
+  static __device__ __forceinline__ bf16_t to(float v) { return (bf16_t)v; }
+  static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Op<f16_t> {
+  typedef f16x4 v4;
+  typedef f16x8 v8;
+  static __device__ __forceinline__ f16_t to(float v) { return (f16_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+  static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
 
 constexpr int kWave = 64;
 
@@ -63,8 +90,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
 __device__ __forceinline__ void store16_nt(void* dst, const f32x4& v) {
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
 }
-__device__ __forceinline__ void store8_nt(void* dst, const bf16x4& v) {
-  __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(dst));
+template <typename V4>
+__device__ __forceinline__ void store8_nt(void* dst, const V4& v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<V4*>(dst));
 }
 __device__ __forceinline__ f32x4 load16_nt(const void* src) {
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));

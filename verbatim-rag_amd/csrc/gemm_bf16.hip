@@ -42,9 +42,10 @@ __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(uns
 
 // Epilogue shared by the GEMM kernels. `acc[ni][mi]` are this wave's accumulators (swapped layout:
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
-template <int EPI, int MI, int WROWS>
+template <int EPI, int MI, int WROWS, typename T>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][MI], char* smem, int wave, int lane,
                                               int mw, int nw, bool v_block) {
+  typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
   const int hi = lane >> 5, l31 = lane & 31;
   // ------------------------------------------------------------------ epilogues
   // All operand-tile reads are done (the loop ends with a barrier), so the LDS is reused as a
@@ -55,10 +56,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   char* stg = smem + wave * 16384;
 
   // bf16 tile [R rows][C cols] (C = 64 or 32): lane writes 4 consecutive columns of its row.
-  auto put_bf16 = [&](int row, int col, const bf16x4& v, int row_bytes) {
+  auto put_bf16 = [&](int row, int col, const V4& v, int row_bytes) {
     const int c16 = col >> 3, half = (col >> 2) & 1;
     const int sw16 = row_bytes == 128 ? (row & 7) : (row_bytes == 64 ? (row & 3) : (row & 15));
-    *reinterpret_cast<bf16x4*>(stg + row * row_bytes + ((c16 ^ sw16) << 4) + (half << 3)) = v;
+    *reinterpret_cast<V4*>(stg + row * row_bytes + ((c16 ^ sw16) << 4) + (half << 3)) = v;
   };
   // read back 16 bytes: chunk c16 of `row`
   auto get16 = [&](int row, int c16, int row_bytes) -> f32x4 {
@@ -130,9 +131,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             for (int j = 0; j < 4; ++j) v[j] -= c_;
           }
           if (p.resid_bf16) {
-            bf16x4 o;
+            V4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+            for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(v[j]);
             store8_nt(p.resid_bf16 + (size_t)(mw + ps * 64 + row) * p.N + nw + c16 * 4, o);
           }
           if (p.stats_part) {
@@ -196,14 +197,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int col = ni * 32 + 8 * g + 4 * hi;
-          bf16x4 o;
+          V4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float v = acc[ni][mi][4 * g + j];
             if (p.ln_mu) v = rs * (v - mu * p.ln_s[nw + col + j]);
             if (p.bias) v += p.bias[nw + col + j];
             if (p.act_gelu) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
-            o[j] = (bf16_t)v;
+            o[j] = Op<T>::to(v);
           }
           put_bf16(mi * 32 + l31, col, o, 128);
         }
@@ -232,12 +233,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           s1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 8 * g + 4 * hi);
           s2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + 8 * g + 4 * hi);
         }
-        bf16x4 o;
+        V4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float x1 = rs * (acc[0][mi][4 * g + j] - mu * s1[j]);
           const float x2 = rs * (acc[1][mi][4 * g + j] - mu * s2[j]);
-          o[j] = (bf16_t)(gelu_fast(x1) * x2);
+          o[j] = Op<T>::to(gelu_fast(x1) * x2);
         }
         put_bf16(mi * 32 + l31, 8 * g + 4 * hi, o, 64);
       }
@@ -279,14 +280,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             b1 = *reinterpret_cast<const f32x4*>(p.bias + nw + dd);
             b2 = *reinterpret_cast<const f32x4*>(p.bias + nw + 32 + dd);
           }
-          bf16x4 o1, o2;
+          V4 o1, o2;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float x1 = rs * (acc[0][mi][4 * g + j] - mu * ls1[j]) + b1[j];
             const float x2 = rs * (acc[1][mi][4 * g + j] - mu * ls2[j]) + b2[j];
             // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
-            o1[j] = (bf16_t)((x1 * c[j] - x2 * sv[j]) * scale);
-            o2[j] = (bf16_t)((x2 * c[j] + x1 * sv[j]) * scale);
+            o1[j] = Op<T>::to((x1 * c[j] - x2 * sv[j]) * scale);
+            o2[j] = Op<T>::to((x2 * c[j] + x1 * sv[j]) * scale);
           }
           put_bf16(mi * 32 + l31, dd, o1, 128);
           put_bf16(mi * 32 + l31, dd + 32, o2, 128);
@@ -314,9 +315,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
               mu4 = *reinterpret_cast<const f32x4*>(p.ln_mu + mw + mi * 32 + 8 * g + 4 * hi);
               rs4 = *reinterpret_cast<const f32x4*>(p.ln_rstd + mw + mi * 32 + 8 * g + 4 * hi);
             }
-            bf16x4 o;
+            V4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(rs4[j] * (acc[ni][mi][4 * g + j] - mu4[j] * sn_) + bv_);
+            for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(rs4[j] * (acc[ni][mi][4 * g + j] - mu4[j] * sn_) + bv_);
             put_bf16(ni * 32 + l31, mi * 32 + 8 * g + 4 * hi, o, RB);
           }
       }
@@ -380,8 +381,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // 128 x 256 tile with three stages (72 KiB, 4 waves) run as TWO workgroups per CU: the configuration of the residual
 // GEMMs, whose fp32 read-modify-write epilogue is HBM-bound -- one workgroup's epilogue then streams under the other's
 // main loop instead of leaving the matrix cores idle.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64>
+template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64, typename T = bf16_t>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
+  typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
   static_assert(NS >= 2 && NS <= 4, "LDS stages");
   static_assert(BKT == 64 || BKT == 32, "K-step");
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       if (i < KT) stage(i, i);
     wait_allow(min(NS - 1, KT) - 1);
     step_barrier();
-    bf16x8 dbg_f[MI + 2] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
+    V8 dbg_f[MI + 2] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
     if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
       for (int i = 0; i < MI + 2; ++i) {
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
           h = h * 1664525u + 1013904223u;
           w4[j] = (h & 0x807f807fu) | 0x3f803f80u;
         }
-        dbg_f[i] = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
+        dbg_f[i] = __builtin_bit_cast(V8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
                                                      __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
       }
     }
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
 #if VRAG_DMA_SPLIT == 1
         if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(nxt, nbuf);   // second half: one substep later
 #endif
-        bf16x8 af[MI] = {}, wf[2] = {};
+        V8 af[MI] = {}, wf[2] = {};
         if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) af[i] = dbg_f[i];
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
               h = h * 1664525u + 1013904223u;
               w4[j] = (h & 0x807f807fu) | 0x3f803f80u;   // sign + mantissa random, exponent 127
             }
-            const bf16x8 v = __builtin_bit_cast(bf16x8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
+            const V8 v = __builtin_bit_cast(V8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
                                                               __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
             if (i < MI) af[i] = v;
             else wf[i - MI] = v;
@@ -542,18 +544,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
         }
         if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * ROWB + fo[s]);
+          for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[s]);
 #pragma unroll
-          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + fo[s]);
+          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(sA + i * 32 * ROWB + fo[s]);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if constexpr (SWAPPED)
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+              acc[ni][mi] = Op<T>::mfma32(wf[ni], af[mi], acc[ni][mi]);
             else
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], wf[ni], acc[ni][mi], 0, 0, 0);
+              acc[ni][mi] = Op<T>::mfma32(af[mi], wf[ni], acc[ni][mi]);
           }
       }
       wait_allow(max(0, min(NS - 2, KT - 2 - kt)));   // step kt+1 has landed (this wave's share)
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<EPI, MI, WROWS>(p, acc, smem, wave, lane, mw, nw, v_block);
+  gemm_epilogue<EPI, MI, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
   }  // tile loop
 }
@@ -575,7 +577,7 @@ int gemm_small_m_threshold(int set_to) {
   return thr.load();
 }
 
-template <int EPI>
+template <int EPI, typename T>
 hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
   static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr;  // tuning knob
@@ -585,14 +587,14 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     constexpr int BM = 128, BN = 128, SMEM = 4 * (BM + BN) * BK * 2;   // 128 KiB, one workgroup per CU
     static bool attr_s = false;
     if (!attr_s) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4, 64, T>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
       if (e != hipSuccess) return e;
       attr_s = true;
     }
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
     p.n_tiles = nbm * nbn;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4>), dim3(std::min(nbm * nbn, 256)), dim3(256), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4, 64, T>), dim3(std::min(nbm * nbn, 256)), dim3(256), SMEM, stream, p);
     return hipGetLastError();
   }
   // Residual GEMMs (HBM-bound epilogue): 128 x 256 tiles, 4 waves, BK = 32 x 3 stages = 72 KiB -> two workgroups per CU,
@@ -603,7 +605,7 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
       constexpr int BM = 128, BN = 256, SMEM = 3 * (BM + BN) * 32 * 2;
       static bool attr_p = false;
       if (!attr_p) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32, T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         if (e != hipSuccess) return e;
         attr_p = true;
@@ -611,7 +613,7 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
       const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
       p.n_tiles = nbm * nbn;
       static const int pgrid2 = getenv("VRAG_GEMM_PGRID2") ? atoi(getenv("VRAG_GEMM_PGRID2")) : 512;   // 2 workgroups per CU
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32>), dim3(std::min(nbm * nbn, pgrid2)), dim3(256), SMEM, stream, p);
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32, T>), dim3(std::min(nbm * nbn, pgrid2)), dim3(256), SMEM, stream, p);
       return hipGetLastError();
     }
   }
@@ -620,7 +622,7 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
     constexpr int BM = 256, BN = 256, SMEM = 2 * (BM + BN) * BK * 2;
     static bool attr = false;
     if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
       if (e != hipSuccess) return e;
       attr = true;
@@ -634,41 +636,46 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
         if (env_debug) {   // main-loop decomposition probe: results are garbage by design
           static bool attr5 = false;
           if (!attr5) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1, 2, 64, T>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
             if (e != hipSuccess) return e;
             attr5 = true;
           }
           p.debug_flags = env_debug;
-          hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
+          hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1, 2, 64, T>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
           return hipGetLastError();
         }
       }
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
     }
   } else {
     constexpr int BM = 128, BN = 128, SMEM = 2 * (BM + BN) * BK * 2;
     const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
     p.n_tiles = nbm * nbn;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2>), dim3(std::min(nbm * nbn, 512)), dim3(256), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 2, 64, T>), dim3(std::min(nbm * nbn, 512)), dim3(256), SMEM, stream, p);
   }
   return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_typed(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
+  switch (epi) {
+    case EPI_F32: return launch_t<EPI_F32, T>(p, stream);
+    case EPI_BF16: return launch_t<EPI_BF16, T>(p, stream);
+    case EPI_F32_GELU: return launch_t<EPI_F32_GELU, T>(p, stream);
+    case EPI_RESIDUAL: return launch_t<EPI_RESIDUAL, T>(p, stream);
+    case EPI_GEGLU: return launch_t<EPI_GEGLU, T>(p, stream);
+    case EPI_QKV_ROPE: return launch_t<EPI_QKV_ROPE, T>(p, stream);
+    case EPI_SPLADE: return launch_t<EPI_SPLADE, T>(p, stream);
+    case EPI_NONE: return launch_t<EPI_NONE, T>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
   if (p.M <= 0) return hipSuccess;
   if (p.N % 128 != 0 || p.K % BK != 0) return hipErrorInvalidValue;
-  switch (epi) {
-    case EPI_F32: return launch_t<EPI_F32>(p, stream);
-    case EPI_BF16: return launch_t<EPI_BF16>(p, stream);
-    case EPI_F32_GELU: return launch_t<EPI_F32_GELU>(p, stream);
-    case EPI_RESIDUAL: return launch_t<EPI_RESIDUAL>(p, stream);
-    case EPI_GEGLU: return launch_t<EPI_GEGLU>(p, stream);
-    case EPI_QKV_ROPE: return launch_t<EPI_QKV_ROPE>(p, stream);
-    case EPI_SPLADE: return launch_t<EPI_SPLADE>(p, stream);
-    case EPI_NONE: return launch_t<EPI_NONE>(p, stream);
-    default: return hipErrorInvalidValue;
-  }
+  return p.op_dtype == kOpF16 ? launch_typed<f16_t>(epi, p, stream) : launch_typed<bf16_t>(epi, p, stream);
 }
 
 const char* gemm_kernel_name(GemmEpi epi) {

@@ -255,9 +255,12 @@ constexpr int MROWS_WG = 2048;   // rows per workgroup
 constexpr int MSLOTS = 5;
 constexpr int MKMAX = 16;        // private list length limit (LDS budget)
 
+// `split` (fp32 queries that are not exactly bf16): a pass carries 16 queries, column j holds bf16(q_j) and column
+// j + 16 the remainder bf16(q_j - bf16(q_j)); the rows are bf16, so both products are exact and their sum carries the
+// query to 16 significant bits -- the scores then agree with the fp32-query oracle to fp32 summation noise.
 __global__ __launch_bounds__(256) void dense_topk_mfma_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
                                                                const float* __restrict__ queries, int nq, int q0, int k,
-                                                               u64* __restrict__ cand) {
+                                                               u64* __restrict__ cand, int split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;                                         // [32][dim] bf16, chunk-swizzled
   char* ring = smem + (size_t)MQ * dim * 2;                // MSLOTS x 16 KiB
@@ -299,13 +302,18 @@ __global__ __launch_bounds__(256) void dense_topk_mfma_kernel(const bf16_t* __re
   // queries -> bf16 LDS image (while the first tiles fly): element (j, c) at
   // j*row_bytes + ((c/8) ^ (j & 15))*16 + (c%8)*2
   const int dim4 = dim >> 2;
+  const int qpp = split ? MQ / 2 : MQ;   // queries per pass
   for (int i = tid; i < MQ * dim4; i += 256) {
     const int j = i / dim4, c = (i - j * dim4) << 2;
+    const int jq = split ? (j & 15) : j;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q0 + j < nq) v = *reinterpret_cast<const f32x4*>(queries + (size_t)(q0 + j) * dim + c);
+    if (q0 + jq < nq) v = *reinterpret_cast<const f32x4*>(queries + (size_t)(q0 + jq) * dim + c);
     bf16x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (bf16_t)v[e];
+      if (split && j >= 16) o[e] = (bf16_t)(v[e] - (float)o[e]);
+    }
     *reinterpret_cast<bf16x4*>(sQ + j * row_bytes + ((((c >> 3) ^ (j & 15))) << 4) + ((c & 7) << 1)) = o;
   }
   u64* mylist = lists + (size_t)tid * k;
@@ -342,7 +350,11 @@ __global__ __launch_bounds__(256) void dense_topk_mfma_kernel(const bf16_t* __re
       kt = 0;
       // 16 row scores of query (q0 + l31): private filtered insertion
       const long long rb = r_begin + (long long)g * 128 + wave * 32 + 4 * hi;
-      if (q0 + l31 < nq) {
+      if (split) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += __shfl_xor(acc[r], 16, 64);   // hi part + remainder part of the same query
+      }
+      if (q0 + l31 < nq && l31 < qpp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long long row = rb + (r & 3) + 8 * (r >> 2);
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256) void dense_topk_mfma_kernel(const bf16_t* __re
   }
   __syncthreads();
   // per query: 8 sorted lists (4 waves x 2 halves) -> k best
-  if (tid < MQ && q0 + tid < nq) {
+  if (tid < qpp && q0 + tid < nq) {
     int head[8];
     for (int gg = 0; gg < 8; ++gg) head[gg] = 0;
     u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
@@ -396,8 +408,9 @@ __global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* 
                                                                    long long n_rows /* = end of this launch's row range */,
                                                                    const float* __restrict__ queries, int nq, int q0, int k,
                                                                    u64* __restrict__ cand, int rows_per_wg,
-                                                                   u64* __restrict__ thr) {
+                                                                   u64* __restrict__ thr, int split) {
   constexpr int DIM = KT * 64;
+  const int qpp = split ? MQ / 2 : MQ;   // queries per pass (see dense_topk_mfma_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                                               // M2SLOTS x 16 KiB
   u64* lists = reinterpret_cast<u64*>(ring + M2SLOTS * 16384);      // [256 lanes][k]
@@ -407,9 +420,10 @@ __global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* 
 
   // query (q0 + l31) as B-operand fragments: k-slots 8*hi .. 8*hi+7 of step s <-> dims 16*s + 8*hi + j (bf16-rounded)
   bf16x8 qf[KT * 4];
+  const int lq = split ? (l31 & 15) : l31;     // query of this lane's column
   {
-    const bool live = q0 + l31 < nq;
-    const float* qrow = queries + (size_t)(live ? q0 + l31 : 0) * DIM + 8 * hi;
+    const bool live = q0 + lq < nq;
+    const float* qrow = queries + (size_t)(live ? q0 + lq : 0) * DIM + 8 * hi;
 #pragma unroll
     for (int s = 0; s < KT * 4; ++s) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -421,6 +435,10 @@ __global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* 
       for (int j = 0; j < 4; ++j) {
         qf[s][j] = (bf16_t)a[j];
         qf[s][4 + j] = (bf16_t)b[j];
+        if (split && l31 >= 16) {   // remainder column
+          qf[s][j] = (bf16_t)(a[j] - (float)qf[s][j]);
+          qf[s][4 + j] = (bf16_t)(b[j] - (float)qf[s][4 + j]);
+        }
       }
     }
   }
@@ -496,7 +514,15 @@ __global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* 
     // any list of its query cannot be in the query's top-k, so the union of the lists still contains it, while
     // the number of (divergent, LDS read-modify-write) insertions drops from ~k ln(n) per list to per shard.
     const long long rb = r_begin + (long long)g * 128 + wave * 32 + 4 * hi;
-    if (q0 + l31 < nq) {
+    if (split) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] += acc1[r];
+        acc1[r] = 0.f;
+        acc0[r] += __shfl_xor(acc0[r], 16, 64);   // hi part + remainder part of the same query
+      }
+    }
+    if (q0 + l31 < nq && l31 < qpp) {
       const u64 shared = __hip_atomic_load(thr + q0 + l31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       u64 bar = shared > kth ? shared : kth;
       bool changed = false;
@@ -518,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* 
   }
   __syncthreads();
   // per query: 8 sorted lists (4 waves x 2 halves) -> k best
-  if (tid < MQ && q0 + tid < nq) {
+  if (tid < qpp && q0 + tid < nq) {
     int head[8];
     for (int gg = 0; gg < 8; ++gg) head[gg] = 0;
     u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
@@ -586,7 +612,9 @@ static int dense_n_wg(int dtype, int dim, int nq, int k, long long size) {
 
 // all passes of one search: query tiles of 4 (a final tile of 1 query uses the register path)
 static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int dim, const float* dq, int nq, int k,
-                                   u64* cand, int n_wg, hipStream_t st, u64* thr, u64* out, const u64* bound = nullptr) {
+                                   u64* cand, int n_wg, hipStream_t st, u64* thr, u64* out, const u64* bound = nullptr,
+                                   int split = 0) {
+  const int qpp = split ? MQ / 2 : MQ;
   if (bound && dense_use_mfma(dtype, dim, nq, k)) return hipErrorInvalidValue;   // pages run with k = KMAX: scalar path only
   if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
     static const int dbg_fill = getenv("VRAG_TOPK_DEBUG_NOINSERT") ? 0xff : 0;   // probe: reject every key
@@ -606,10 +634,10 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
     }
     const bf16_t* r16 = reinterpret_cast<const bf16_t*>(rows);
     auto pass = [&](long long lo, long long hi, int per, int wgs, u64* cand_base) -> hipError_t {
-      for (int q0 = 0; q0 < nq; q0 += MQ) {
-        if (dim == 384) hipLaunchKernelGGL(dense_topk_mfma2_kernel<6>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr);
-        else if (dim == 768) hipLaunchKernelGGL(dense_topk_mfma2_kernel<12>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr);
-        else hipLaunchKernelGGL(dense_topk_mfma2_kernel<16>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr);
+      for (int q0 = 0; q0 < nq; q0 += qpp) {
+        if (dim == 384) hipLaunchKernelGGL(dense_topk_mfma2_kernel<6>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr, split);
+        else if (dim == 768) hipLaunchKernelGGL(dense_topk_mfma2_kernel<12>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr, split);
+        else hipLaunchKernelGGL(dense_topk_mfma2_kernel<16>, dim3(wgs), dim3(256), lds2, st, r16, lo, hi, dq, nq, q0, k, cand_base, per, thr, split);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
       }
@@ -638,9 +666,9 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
       if (e != hipSuccess) return e;
       attr = true;
     }
-    for (int q0 = 0; q0 < nq; q0 += MQ) {
+    for (int q0 = 0; q0 < nq; q0 += qpp) {
       hipLaunchKernelGGL(dense_topk_mfma_kernel, dim3(n_wg), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows), n,
-                         dim, dq, nq, q0, k, cand);
+                         dim, dq, nq, q0, k, cand, split);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return e;
     }
@@ -1031,6 +1059,7 @@ struct vrag_dense_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;   // d_bound: per-query page bound (k > KMAX)
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
+  int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
 };
 
 struct vrag_sparse_index {
@@ -1236,11 +1265,23 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, st));
   const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
   ARG_CHECK(lds <= 160 * 1024, "dim/k too large for the LDS budget");
+  // Batched search over bf16 rows runs on the matrix cores with bf16 query operands: exact when every query element
+  // is a bf16 number; otherwise the queries ride as (bf16 part, bf16 remainder) column pairs, 16 queries per pass.
+  ix->resident_split = 0;
+  if (dense_use_mfma(ix->dtype, ix->dim, nq, k) && !getenv("VRAG_TOPK_NO_SPLIT")) {
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(queries);
+    const size_t n_el = (size_t)nq * ix->dim;
+    for (size_t i = 0; i < n_el; ++i)
+      if (bits[i] & 0xFFFFu) {
+        ix->resident_split = 1;
+        break;
+      }
+  }
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
   } else {
     HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
-                             ix->d_out + (size_t)nq * k, ix->d_out));
+                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
     HIP_TRY(hipGetLastError());
   }
@@ -1262,7 +1303,7 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
   ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k + nq, "scratch too small");
   HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
-                             ix->d_out + (size_t)nq * k, ix->d_out));
+                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
   HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
   HIP_TRY(hipGetLastError());
   return VRAG_OK;

@@ -822,9 +822,9 @@ class GpuVectorStore(VectorStore):
         with the dense and the sparse searches of all queries done as one batched device pass each (the batched
         kernels order hits by `(score desc, id asc)` like the single-query ones).  Queries that take one of `query`'s
         side branches (no vectors, a missing half in hybrid mode) are answered by `query` itself.  On a bf16 shard a
-        batch of >= 8 dense queries runs on the matrix cores with the queries rounded to bf16 (include/vrag_amd.h,
-        vrag_dense_index_search), so for queries that are not bf16-exact the scores of a batch can differ from the
-        single-query scores in the third digit; an f32 shard has no such difference."""
+        batch of >= 3 dense queries runs on the matrix cores with every fp32 query carried as a (bf16, bf16 remainder)
+        pair (16 significant bits; include/vrag_amd.h, vrag_dense_index_search): scores then agree with the single-query
+        fp32 path to fp32 summation noise; an f32 shard (the default) uses fp32 queries at every batch size."""
         n = max(len(x) for x in (dense_queries, sparse_queries, text_queries) if x is not None)
         dq = list(dense_queries) if dense_queries is not None else [None] * n
         sq = list(sparse_queries) if sparse_queries is not None else [None] * n

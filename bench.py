@@ -260,6 +260,8 @@ def main() -> None:
     ap.add_argument("--micro-batch-tokens", type=int, default=int(os.environ.get("VRAG_MICRO_BATCH", "65536")))
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--operand-dtype", choices=["bf16", "f16"], default="bf16",
+                    help="MFMA operand type (bf16 = the metric's dtype; f16 = the highlighter extractor's default, informational)")
     ap.add_argument("--model", choices=["base", "large"], default="base",
                     help="base = BASELINE configs[1] (the metric); large = ModernBERT-large geometry (configs[4] extractor), informational")
     args = ap.parse_args()
@@ -307,7 +309,8 @@ def main() -> None:
     qa_w, qa_b = random_qa_head(shape)
     n_chunks = args.chunks
     eng = EncoderEngine(shape, weights, max_tokens=n_chunks * SEQ, max_seqs=n_chunks, max_seq_len=SEQ,
-                        max_ranges=n_chunks * N_SENT, micro_batch_tokens=args.micro_batch_tokens, device=local_rank)
+                        max_ranges=n_chunks * N_SENT, micro_batch_tokens=args.micro_batch_tokens, device=local_rank,
+                        operand_dtype=args.operand_dtype)
     eng.set_qa_head(qa_w, qa_b)
     seqs, bounds = synth_batch(shape, n_chunks, seed=1234 + rank)
     stream = torch.cuda.current_stream().cuda_stream
@@ -431,11 +434,11 @@ def main() -> None:
             "metric": "query x chunk span-extractions/sec @512tok (ModernBERT-base extractor, chunks/s)",
             "value": value, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.operand_dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: ModernBERT-base span extractor, batch 256 chunks x 512 tok, single query, 16 sentences/chunk" if args.model == "base" else "ModernBERT-large geometry (BASELINE configs[4] extractor), batch 256 chunks x 512 tok, 16 sentences/chunk"),
                        "chunks_per_gpu_per_step": n_chunks, "seq_len": SEQ, "sentences_per_chunk": N_SENT,
                        "micro_batch_tokens": args.micro_batch_tokens, "parallelism": f"dp{world} (independent chunks, no collective)",
-                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), bf16 MFMA operands, fp32 accumulate/residual/LN/softmax"},
+                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), {args.operand_dtype} MFMA operands, fp32 accumulate/residual/LN/softmax"},
             "sentence_classifications_per_s": value * N_SENT,
             "model_tflops": value * chunk_flops(shape) / 1e12,
             "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),

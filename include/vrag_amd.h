@@ -39,6 +39,12 @@ extern "C" {
 
 #define VRAG_ABI_VERSION 3
 
+/* MFMA operand type of an encoder handle.  bf16: fp32's exponent range (safe for any checkpoint), 8 significant bits --
+ * sentence logits within 3e-4 of the fp32 reference.  fp16: 11 significant bits at the same matrix-core rate, values
+ * saturate at +-65504 -- what the per-token logits of the v2 highlighter need to stay within 1e-3. */
+#define VRAG_OPERAND_BF16 0
+#define VRAG_OPERAND_F16 1
+
 typedef struct vrag_encoder vrag_encoder;
 
 typedef struct vrag_encoder_config {
@@ -59,6 +65,9 @@ typedef struct vrag_encoder_config {
   int32_t max_ranges;          /* sentence / pooling ranges per batch */
   int32_t micro_batch_tokens;  /* 0 = whole batch per kernel; else split (cache blocking) */
   int32_t device;              /* HIP device ordinal */
+  int32_t operand_dtype;       /* VRAG_OPERAND_BF16 (default) or VRAG_OPERAND_F16: type of the MFMA operands (weights,
+                                  LayerNorm outputs, q/k/v/P, GeGLU output); accumulation, the residual stream, LayerNorm,
+                                  softmax, RoPE and the heads are fp32 either way */
 } vrag_encoder_config;
 
 /* Host fp32 arrays, HF layouts ([out,in] row-major for nn.Linear weights). Per-layer arrays
@@ -97,6 +106,7 @@ typedef struct vrag_bert_config {
   int32_t max_ranges;
   int32_t micro_batch_tokens;
   int32_t device;
+  int32_t operand_dtype;            /* VRAG_OPERAND_BF16 / VRAG_OPERAND_F16 */
 } vrag_bert_config;
 
 /* Host fp32 arrays, HF layouts. wqkv/bqkv are the query, key, value matrices / biases concatenated

@@ -13,7 +13,11 @@ TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_random_batches_vs_oracle(seed):
+@pytest.mark.parametrize("dtype,logit_tol", [("bf16", 2e-3), ("f16", 1e-3)])
+def test_random_batches_vs_oracle(seed, dtype, logit_tol):
+    """The classifier rows here are drawn at 5x the init scale of a real head (std 0.1 vs 0.02) and ranges may be a
+    single token, so logits carry 5x the hidden-state error un-averaged: 1e-3 holds with fp16 operands, 2e-3 with bf16
+    (whose realistic-head, sentence-length figure is 3e-4: test_encoder_gpu.py, bench.py parity field)."""
     from verbatim_rag_amd import _lib
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
 
@@ -26,7 +30,8 @@ def test_random_batches_vs_oracle(seed):
     shape = ModernBertShape(**{k: v for k, v in TINY.items()})
     lib = _lib.load()
     lib.vrag_debug_set_gemm_small_m(int(rng.choice([0, 8192])))
-    eng = EncoderEngine(shape, w, max_tokens=6000, max_seqs=40, max_seq_len=512, max_ranges=400, micro_batch_tokens=mb)
+    eng = EncoderEngine(shape, w, max_tokens=6000, max_seqs=40, max_seq_len=512, max_ranges=400, micro_batch_tokens=mb,
+                        operand_dtype=dtype)
     try:
         eng.set_qa_head(qa_w, qa_b)
         for _round in range(3):
@@ -50,7 +55,7 @@ def test_random_batches_vs_oracle(seed):
                 ref_h = O.encoder_forward(cfg, w, s)
                 assert np.abs(hid[o:o + len(s)] - ref_h).max() < 3e-2, (seed, mb, lens)
                 ref_l = O.qa_sentence_logits(ref_h, b, qa_w, qa_b)
-                assert np.abs(g - ref_l).max() < 2e-3, (seed, mb, lens)
+                assert np.abs(g - ref_l).max() < logit_tol, (seed, mb, lens, dtype)
                 o += len(s)
     finally:
         eng.close()

@@ -33,10 +33,11 @@ class EncoderConfig(C.Structure):
         ("sliding_window", C.c_int32), ("rope_theta_global", C.c_float), ("rope_theta_local", C.c_float),
         ("norm_eps", C.c_float), ("pad_token_id", C.c_int32), ("max_seq_len", C.c_int32),
         ("max_tokens", C.c_int32), ("max_seqs", C.c_int32), ("max_ranges", C.c_int32),
-        ("micro_batch_tokens", C.c_int32), ("device", C.c_int32),
+        ("micro_batch_tokens", C.c_int32), ("device", C.c_int32), ("operand_dtype", C.c_int32),
     ]
 
 
+OPERAND_DTYPES = {"bf16": 0, "f16": 1}
 _FP = C.POINTER(C.c_float)
 _FPP = C.POINTER(_FP)
 _IP = C.POINTER(C.c_int32)
@@ -55,7 +56,7 @@ class BertConfig(C.Structure):
         ("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
         ("intermediate_size", C.c_int32), ("max_position_embeddings", C.c_int32), ("norm_eps", C.c_float),
         ("pad_token_id", C.c_int32), ("max_seq_len", C.c_int32), ("max_tokens", C.c_int32), ("max_seqs", C.c_int32),
-        ("max_ranges", C.c_int32), ("micro_batch_tokens", C.c_int32), ("device", C.c_int32),
+        ("max_ranges", C.c_int32), ("micro_batch_tokens", C.c_int32), ("device", C.c_int32), ("operand_dtype", C.c_int32),
     ]
 
 

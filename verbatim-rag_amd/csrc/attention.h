@@ -17,6 +17,7 @@ struct AttnParams {
   int nh;
   int Tp;      // padded token rows (leading dimension of vt)
   int window;  // banded layers: keep |i-j| <= window; ignored for global layers
+  int op_dtype;  // kOpBf16 / kOpF16: what q, k, vt and o hold
 };
 
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream);

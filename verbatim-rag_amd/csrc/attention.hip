@@ -29,8 +29,10 @@ constexpr int ATT_QB_LOCAL = 256;   // banded layers (128 rows / 2 waves measure
 constexpr int ATT_TILE = 16384;  // bytes per LDS ring slot (K 8 KiB + V^T 8 KiB)
 constexpr int ATT_SLOTS = 3;
 
-template <bool LOCAL, int NW>
+template <bool LOCAL, int NW, typename T>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p) {
+  typedef typename Op<T>::v4 V4;
+  typedef typename Op<T>::v8 V8;
   constexpr int ATT_QB = NW * 64;
   constexpr int NI = 8 / NW;  // LDS-DMA instructions per wave per operand per tile (8 rows each)
   __shared__ __attribute__((aligned(16))) char smem[ATT_SLOTS * ATT_TILE];
@@ -49,13 +51,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
   const int W = p.window;
 
   // Q fragments (B operand) for both sub-tiles: k-slot (8*hi + j) of step s <-> d = 16*s + 8*hi + j
-  bf16x8 qf[2][4];
+  V8 qf[2][4];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int row = min(t0 + qw0 + u * 32 + l31, Tp - 1);
-    const bf16_t* qrow = p.q + (size_t)row * H + head * 64 + 8 * hi;
+    const T* qrow = reinterpret_cast<const T*>(p.q) + (size_t)row * H + head * 64 + 8 * hi;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+    for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const V8*>(qrow + 16 * s);
   }
   // Retire the Q loads HERE: an ordinary load still pending when the loop starts makes hipcc wait
   // vmcnt(0) at its first use inside the loop on every iteration, which drains the LDS-DMA
@@ -131,15 +133,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * 128 + (((2 * s + hi) ^ fsw) << 4));
-        st[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], st[0][t], 0, 0, 0);
-        st[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], st[1][t], 0, 0, 0);
+        const V8 kf = *reinterpret_cast<const V8*>(sK + (t * 32 + l31) * 128 + (((2 * s + hi) ^ fsw) << 4));
+        st[0][t] = Op<T>::mfma32(kf, qf[0][s], st[0][t]);
+        st[1][t] = Op<T>::mfma32(kf, qf[1][s], st[1][t]);
       }
 
     // ---- mask + online softmax (scores arrive in log2 units: q was pre-scaled by d^-1/2 * log2 e),
     //      P -> bf16 B-operand fragments.  Interior tiles (every key valid and inside every row's
     //      band) take the mask-free path: the VALU, not the MFMA, is the busier pipe at head_dim 64.
-    bf16x8 pf[2][2][2];
+    V8 pf[2][2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int q_lo = qw0 + u * 32;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(st[u][t][r] - m_new);
           psum += pv;
-          pf[u][t][r >> 3][r & 7] = (bf16_t)pv;
+          pf[u][t][r >> 3][r & 7] = (T)pv;   // p in [0, 1]: no saturation needed
         }
       if (grew) {
         const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
@@ -208,38 +210,48 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const char* vrow = sV + (n * 32 + l31) * 128 + (hi << 3);
-          const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vrow + ((c16 ^ fsw) << 4));
-          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vrow + (((c16 + 1) ^ fsw) << 4));
-          bf16x8 vf;
+          const V4 a0 = *reinterpret_cast<const V4*>(vrow + ((c16 ^ fsw) << 4));
+          const V4 a1 = *reinterpret_cast<const V4*>(vrow + (((c16 + 1) ^ fsw) << 4));
+          V8 vf;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             vf[j] = a0[j];
             vf[4 + j] = a1[j];
           }
-          ot[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][t][hf], ot[0][n], 0, 0, 0);
-          ot[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][t][hf], ot[1][n], 0, 0, 0);
+          ot[0][n] = Op<T>::mfma32(vf, pf[0][t][hf], ot[0][n]);
+          ot[1][n] = Op<T>::mfma32(vf, pf[1][t][hf], ot[1][n]);
         }
       }
   }
 
-  // ---- normalise and store O[q][head*64 + d]
+  // ---- normalise and store O[q][head*64 + d].  A lane holds 4 consecutive dims of ITS row per register group, i.e.
+  // 8-byte pieces at a 2H-byte row stride; staged through the (now idle) LDS ring -- 8 KiB per wave, 16-byte chunk index
+  // XOR (row & 7) -- every store instruction writes 8 whole 128-byte head rows instead of 64 scattered 8-byte pieces.
+  __builtin_amdgcn_s_barrier();   // every wave is past its last K / V^T tile read before the ring is reused
+  asm volatile("" ::: "memory");
+  char* stg = smem + wave * 8192;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int qi = qw0 + u * 32 + l31;
     const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
-    if (qi < S) {
-      const float inv = 1.0f / l_tot;
-      bf16_t* orow = p.o + (size_t)(t0 + qi) * H + head * 64;
+    const float inv = 1.0f / l_tot;
+    const int row = u * 32 + l31;
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4 o;
+      for (int g = 0; g < 4; ++g) {
+        V4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(ot[u][n][4 * g + j] * inv);
-          *reinterpret_cast<bf16x4*>(orow + n * 32 + 8 * g + 4 * hi) = o;
-        }
-    }
+        for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(ot[u][n][4 * g + j] * inv);
+        *reinterpret_cast<V4*>(stg + row * 128 + (((n * 4 + g) ^ (row & 7)) << 4) + (hi << 3)) = o;
+      }
+  }
+  // the staging area is private to the wave: program order + the compiler's lgkmcnt wait order the reads below
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((c16 ^ (row & 7)) << 4));
+    if (qw0 + row < S)
+      *reinterpret_cast<f32x4*>(reinterpret_cast<T*>(p.o) + (size_t)(t0 + qw0 + row) * H + head * 64 + c16 * 8) = v;
   }
 }
 
@@ -248,10 +260,13 @@ int attention_q_block(bool local) { return local ? ATT_QB_LOCAL : ATT_QB_GLOBAL;
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream) {
   if (p.n_blocks <= 0) return hipSuccess;
   dim3 grid(p.n_blocks, p.nh);
-  if (local)
-    hipLaunchKernelGGL((attn_fwd_kernel<true, ATT_QB_LOCAL / 64>), grid, dim3(ATT_QB_LOCAL), 0, stream, p);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<false, ATT_QB_GLOBAL / 64>), grid, dim3(ATT_QB_GLOBAL), 0, stream, p);
+  if (p.op_dtype == kOpF16) {
+    if (local) hipLaunchKernelGGL((attn_fwd_kernel<true, ATT_QB_LOCAL / 64, f16_t>), grid, dim3(ATT_QB_LOCAL), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, ATT_QB_GLOBAL / 64, f16_t>), grid, dim3(ATT_QB_GLOBAL), 0, stream, p);
+  } else {
+    if (local) hipLaunchKernelGGL((attn_fwd_kernel<true, ATT_QB_LOCAL / 64, bf16_t>), grid, dim3(ATT_QB_LOCAL), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, ATT_QB_GLOBAL / 64, bf16_t>), grid, dim3(ATT_QB_GLOBAL), 0, stream, p);
+  }
   return hipGetLastError();
 }
 

@@ -32,13 +32,18 @@ void set_error(const char* fmt, ...) {
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------- weight packing kernels
-__global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows_dst,
+template <typename T>
+__global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst_, int rows_dst,
                                      int rows_src, int cols, int interleave_I,
-                                     const float* __restrict__ col_scale, float* __restrict__ row_sum) {
+                                     const float* __restrict__ col_scale, float* __restrict__ row_sum,
+                                     bf16_t* __restrict__ dst_lo_ = nullptr) {
   // dst row r <- src row perm(r) (* col_scale per input column: a LayerNorm gain folded into the
   // weight); rows beyond rows_src are zero.  interleave_I > 0 applies the GeGLU interleave: each
   // 64-row group = 32 input rows (x1) then the 32 matching gate rows (x2).  row_sum[r] = sum over
-  // the bf16-ROUNDED row (what the MFMA will actually multiply), fp32.
+  // the ROUNDED row (what the MFMA will actually multiply), fp32.  T = operand type (bf16 / fp16);
+  // dst_lo (optional) receives the remainder  v - float(T(v))  in the same type (split-operand head GEMMs).
+  T* dst = reinterpret_cast<T*>(dst_);
+  T* dst_lo = reinterpret_cast<T*>(dst_lo_);
   __shared__ float red[4];
   const int r = blockIdx.x;
   int s = r;
@@ -53,8 +58,9 @@ __global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __re
   for (int c = threadIdx.x; c < cols; c += blockDim.x) {
     float v = (valid && r < rows_dst && s < rows_src) ? src[(size_t)s * cols + c] : 0.f;
     if (col_scale) v *= col_scale[c];
-    const bf16_t b = (bf16_t)v;
+    const T b = Op<T>::to(v);
     dst[(size_t)r * cols + c] = b;
+    if (dst_lo) dst_lo[(size_t)r * cols + c] = Op<T>::to(v - (float)b);
     acc += (float)b;
   }
   if (row_sum) {
@@ -63,6 +69,16 @@ __global__ void cvt_rows_bf16_kernel(const float* __restrict__ src, bf16_t* __re
     __syncthreads();
     if (threadIdx.x == 0) row_sum[r] = (red[0] + red[1]) + (red[2] + red[3]);
   }
+}
+
+static void launch_cvt_rows(int op_dtype, dim3 grid, hipStream_t st, const float* src, bf16_t* dst, int rows_dst, int rows_src,
+                            int cols, int interleave_I, const float* col_scale, float* row_sum, bf16_t* dst_lo = nullptr) {
+  if (op_dtype == kOpF16)
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel<f16_t>, grid, dim3(256), 0, st, src, dst, rows_dst, rows_src, cols, interleave_I,
+                       col_scale, row_sum, dst_lo);
+  else
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel<bf16_t>, grid, dim3(256), 0, st, src, dst, rows_dst, rows_src, cols, interleave_I,
+                       col_scale, row_sum, dst_lo);
 }
 
 // Row statistics from the per-segment partial sums left by the residual GEMM epilogue.  The sums are over (h - c)
@@ -173,6 +189,7 @@ struct vrag_encoder {
   std::vector<void*> host_allocs;
 
   // weights
+  int op_dtype = kOpBf16;   // MFMA operand type of every 16-bit buffer of this handle (cfg.operand_dtype)
   int arch = 0;  // 0 = ModernBERT (pre-LN, RoPE, GeGLU, no biases); 1 = BERT family (post-LN, biases, learned positions)
   float* tok_emb = nullptr;
   float* emb_norm = nullptr;
@@ -199,7 +216,7 @@ struct vrag_encoder {
   // heads
   float *qa_w = nullptr, *qa_b = nullptr;
   int qa_labels = 0;
-  bf16_t* tk_dense = nullptr;
+  bf16_t *tk_dense = nullptr, *tk_dense_lo = nullptr;
   float *tk_norm = nullptr, *tk_w = nullptr, *tk_b = nullptr;
   int tk_labels = 0;
   bf16_t *mlm_dense = nullptr, *mlm_dec = nullptr;
@@ -301,9 +318,14 @@ int upload_f32(vrag_encoder* e, float** out, const float* src, size_t count) {
 // fp32 host matrix [rows_src, cols] -> bf16 device matrix [rows_dst, cols] (zero padded rows).
 int upload_bf16(vrag_encoder* e, bf16_t** out, const float* src, int rows_src, int cols, int rows_dst,
                 int interleave_I, float* stage, size_t stage_elems, const float* d_col_scale = nullptr,
-                float** row_sum_out = nullptr) {
+                float** row_sum_out = nullptr, bf16_t** out_lo = nullptr) {
   int rc = dev_alloc(e, out, (size_t)rows_dst * cols, false);
   if (rc) return rc;
+  bf16_t* d_lo = nullptr;
+  if (out_lo) {
+    if ((rc = dev_alloc(e, &d_lo, (size_t)rows_dst * cols, false))) return rc;
+    *out_lo = d_lo;
+  }
   float* d_row_sum = nullptr;
   if (row_sum_out) {
     if ((rc = dev_alloc(e, &d_row_sum, rows_dst, true))) return rc;
@@ -311,11 +333,11 @@ int upload_bf16(vrag_encoder* e, bf16_t** out, const float* src, int rows_src, i
   }
   // stream the fp32 source through the staging buffer in row chunks
   const int chunk_rows_max = (int)std::max<size_t>(1, stage_elems / cols);
-  if (interleave_I > 0 || d_col_scale || row_sum_out || rows_src <= chunk_rows_max) {
+  if (interleave_I > 0 || d_col_scale || row_sum_out || out_lo || rows_src <= chunk_rows_max) {
     ARG_CHECK((size_t)rows_src * cols <= stage_elems, "internal: staging buffer too small");
     HIP_TRY(hipMemcpy(stage, src, (size_t)rows_src * cols * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(rows_dst), dim3(256), 0, 0, stage, *out, rows_dst, rows_src, cols,
-                       interleave_I, d_col_scale, d_row_sum);
+    launch_cvt_rows(e->op_dtype, dim3(rows_dst), 0, stage, *out, rows_dst, rows_src, cols, interleave_I, d_col_scale, d_row_sum,
+                    d_lo);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return VRAG_OK;
@@ -326,8 +348,7 @@ int upload_bf16(vrag_encoder* e, bf16_t** out, const float* src, int rows_src, i
     if (nr_src > 0)
       HIP_TRY(hipMemcpy(stage, src + (size_t)r0 * cols, (size_t)nr_src * cols * sizeof(float),
                         hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(nr_dst), dim3(256), 0, 0, stage, *out + (size_t)r0 * cols, nr_dst,
-                       nr_src, cols, 0, (const float*)nullptr, (float*)nullptr);
+    launch_cvt_rows(e->op_dtype, dim3(nr_dst), 0, stage, *out + (size_t)r0 * cols, nr_dst, nr_src, cols, 0, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }
@@ -406,7 +427,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
     {
       ProfScope ps(e, VRAG_PROF_EMBED, st);
       HIP_TRY(launch_embed_ln(e->d_ids + r0, e->tok_emb, e->emb_norm, c.norm_eps, H, M, e->h + (size_t)r0 * H,
-                              e->a + (size_t)r0 * H, st));
+                              e->a + (size_t)r0 * H, st, nullptr, nullptr, nullptr, nullptr, nullptr, e->op_dtype));
     }
     for (int l = 0; l < n_layers; ++l) {
       const Layer& L = e->layers[l];
@@ -418,7 +439,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       const bool fold = e->ln_fold;
       auto layer_norm = [&](const float* gain) -> int {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, gain, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st));
+        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, gain, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr, nullptr,
+                                 e->op_dtype));
         return VRAG_OK;
       };
       if (!fold && l > 0) {
@@ -436,6 +458,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       };
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = e->a + (size_t)r0 * H;
         g.W = L.wqkv;
         if (fold && l > 0) {  // layer 0 consumes the embedding LayerNorm output directly (no attn_norm)
@@ -460,6 +483,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         AttnParams ap{};
+        ap.op_dtype = e->op_dtype;
         ap.q = e->q;
         ap.k = e->k;
         ap.vt = e->vt;
@@ -477,6 +501,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = e->o + (size_t)r0 * H;
         g.W = L.wo;
         g.M = M;
@@ -497,13 +522,14 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       if (fold && l == 0) {   // a = bf16(normalised h) without the gain (folded into Wi), ln_shift = mean(h)
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, nullptr, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr,
-                                 e->ln_shift + r0));
+                                 e->ln_shift + r0, e->op_dtype));
       } else {
         int rc = fold ? finalize_stats(false) : layer_norm(L.mlp_norm);
         if (rc) return rc;
       }
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = e->a + (size_t)r0 * H;
         g.W = L.wi;
         if (fold && l > 0) {
@@ -520,6 +546,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = e->act + (size_t)r0 * I;
         g.W = L.wo_mlp;
         g.M = M;
@@ -579,7 +606,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       ProfScope ps(e, VRAG_PROF_EMBED, st);
       HIP_TRY(launch_embed_ln(e->d_ids + r0, e->tok_emb, e->emb_norm, c.norm_eps, H, M, h, a, st, e->pos_emb,
                               e->d_pos + r0, e->types_loaded ? e->type_table : e->type_row, e->emb_norm_b,
-                              e->types_loaded ? e->d_types + r0 : nullptr));
+                              e->types_loaded ? e->d_types + r0 : nullptr, e->op_dtype));
     }
     const bool fold = e->ln_fold;
     float* st_part = e->st_part + (size_t)r0 * (H / 64) * 2;
@@ -597,6 +624,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       const bool lazy_in = fold && l > 0;           // this layer's input is LN2 of layer l-1, still lazy
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = a;
         g.W = L.wqkv;
         g.bias = L.bqkv;
@@ -622,6 +650,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         AttnParams ap{};
+        ap.op_dtype = e->op_dtype;
         ap.q = e->q;
         ap.k = e->k;
         ap.vt = e->vt;
@@ -639,6 +668,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = e->o + (size_t)r0 * Ha;
         g.W = L.wo;
         g.M = M;
@@ -665,10 +695,11 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         if (rc) return rc;
       } else {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(h, L.ln1_w, c.norm_eps, H, M, a, h, st, L.ln1_b));
+        HIP_TRY(launch_layernorm(h, L.ln1_w, c.norm_eps, H, M, a, h, st, L.ln1_b, nullptr, e->op_dtype));
       }
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = a;
         g.W = L.w1;
         g.M = M;
@@ -687,6 +718,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       }
       {
         GemmParams g{};
+        g.op_dtype = e->op_dtype;
         g.A = e->act + (size_t)r0 * I;
         g.W = L.w2;
         g.M = M;
@@ -711,7 +743,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       } else {
         // materialise the layer output (last layer of this run, or un-folded mode): h <- LN2(h), a <- bf16(h)
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(h, L.ln2_w, c.norm_eps, H, M, a, h, st, L.ln2_b));
+        HIP_TRY(launch_layernorm(h, L.ln2_w, c.norm_eps, H, M, a, h, st, L.ln2_b, nullptr, e->op_dtype));
       }
     }
   }
@@ -851,6 +883,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
             "max_tokens/max_seqs/max_seq_len/max_ranges must be positive");
   ARG_CHECK(cfg->pad_token_id >= 0 && cfg->pad_token_id < V, "pad_token_id outside the vocabulary");
   ARG_CHECK(cfg->micro_batch_tokens >= 0, "micro_batch_tokens must be >= 0");
+  ARG_CHECK(cfg->operand_dtype == VRAG_OPERAND_BF16 || cfg->operand_dtype == VRAG_OPERAND_F16, "operand_dtype: 0 = bf16, 1 = fp16");
   if (vrag_device_count() <= cfg->device) {
     set_error("no HIP device %d visible (the gfx950 library has no CPU fallback)", cfg->device);
     return VRAG_ERR_NO_DEVICE;
@@ -859,6 +892,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
 
   vrag_encoder* e = new vrag_encoder();
   e->cfg = *cfg;
+  e->op_dtype = cfg->operand_dtype;
   auto fail = [&](int rc) {
     vrag_encoder_destroy(e);
     return rc;
@@ -935,6 +969,7 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
   ARG_CHECK(cfg->max_seq_len <= P, "max_seq_len %d exceeds max_position_embeddings %d", cfg->max_seq_len, P);
   ARG_CHECK(cfg->pad_token_id >= 0 && cfg->pad_token_id < V, "pad_token_id outside the vocabulary");
   ARG_CHECK(cfg->micro_batch_tokens >= 0, "micro_batch_tokens must be >= 0");
+  ARG_CHECK(cfg->operand_dtype == VRAG_OPERAND_BF16 || cfg->operand_dtype == VRAG_OPERAND_F16, "operand_dtype: 0 = bf16, 1 = fp16");
   ARG_CHECK(w->word_embeddings && w->position_embeddings && w->emb_norm_w && w->emb_norm_b && w->wqkv && w->bqkv &&
                 w->wo && w->bo && w->attn_norm_w && w->attn_norm_b && w->w1 && w->b1 && w->w2 && w->b2 &&
                 w->out_norm_w && w->out_norm_b,
@@ -951,6 +986,7 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
   const int hd = H / cfg->num_heads, Ha = cfg->num_heads * 64;
   vrag_encoder* e = new vrag_encoder();
   e->arch = 1;
+  e->op_dtype = cfg->operand_dtype;
   e->ln_fold = false;   // measured 2-3 % slower than the LayerNorm kernels on this family (opt-in: VRAG_BERT_LN_FOLD=1)
   if (const char* lf = getenv("VRAG_BERT_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
   e->attn_w = Ha;
@@ -1109,7 +1145,8 @@ int vrag_encoder_set_token_head(vrag_encoder* e, const float* dense_w, const flo
   float* stage = nullptr;
   int rc = dev_alloc(e, &stage, (size_t)H * H, false);
   if (rc) return rc;
-  rc = upload_bf16(e, &e->tk_dense, dense_w, H, H, H, 0, stage, (size_t)H * H);
+  // dense weight as (value, remainder) operand pairs: the head GEMM then carries ~fp32 precision (see run_token_head)
+  rc = upload_bf16(e, &e->tk_dense, dense_w, H, H, H, 0, stage, (size_t)H * H, nullptr, nullptr, &e->tk_dense_lo);
   if (rc) return rc;
   if ((rc = upload_f32(e, &e->tk_norm, norm_w, H))) return rc;
   if ((rc = upload_f32(e, &e->tk_w, cls_w, (size_t)num_labels * H))) return rc;
@@ -1139,8 +1176,7 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* e, const float* dense_w, const fl
   } else {
     // tied decoder: convert the device-resident fp32 embedding table
     if ((rc = dev_alloc(e, &e->mlm_dec, (size_t)vpad * H, false))) return rc;
-    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(vpad), dim3(256), 0, 0, e->tok_emb, e->mlm_dec, vpad, V, H, 0,
-                       (const float*)nullptr, (float*)nullptr);
+    launch_cvt_rows(e->op_dtype, dim3(vpad), 0, e->tok_emb, e->mlm_dec, vpad, V, H, 0, (const float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }
@@ -1468,17 +1504,27 @@ int vrag_encoder_run_token_head(vrag_encoder* e, void* stream) {
   hipStream_t st = pick_stream(e, stream);
   const int H = e->cfg.hidden_size;
   ProfScope ps(e, VRAG_PROF_HEAD, st);
-  HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
-  GemmParams g{};
-  g.A = e->a;
-  g.W = e->tk_dense;
-  g.M = e->rows;
-  g.N = H;
-  g.K = H;
-  g.out_f32 = e->f32tmp;
-  HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
+  // Per-token logits see the un-averaged operand rounding of the head's dense layer (2e-2 with plain bf16 operands,
+  // against north_star's 1e-3): the head runs with split operands -- x = x_hi + x_lo, W = W_hi + W_lo in the operand
+  // type, three MFMA GEMMs accumulated in fp32 (hi.hi + lo.hi + hi.lo; lo.lo is below fp32 resolution) -- which costs
+  // 3 x 2.T.H^2 FLOP, under 2 % of the encoder (tests/probes/precision_probe.py: 6.3e-3 -> 8.8e-4 on bf16 encoders).
+  bf16_t* x_lo = e->o;   // the attention output buffer is free once the layers have run (row stride H for arch 0)
+  HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, nullptr, nullptr, e->op_dtype, x_lo));
+  HIP_TRY(hipMemsetAsync(e->f32tmp, 0, (size_t)e->rows * H * sizeof(float), st));
+  const bf16_t* parts[3][2] = {{e->a, e->tk_dense}, {x_lo, e->tk_dense}, {e->a, e->tk_dense_lo}};
+  for (auto& pr : parts) {
+    GemmParams g{};
+    g.op_dtype = e->op_dtype;
+    g.A = pr[0];
+    g.W = pr[1];
+    g.M = e->rows;
+    g.N = H;
+    g.K = H;
+    g.out_f32 = e->f32tmp;
+    HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+  }
   HIP_TRY(launch_ln_classifier(e->f32tmp, e->tk_norm, e->cfg.norm_eps, H, e->rows, e->tk_w, e->tk_b, e->tk_labels,
-                               e->d_tok_logits, st));
+                               e->d_tok_logits, st, nullptr, /*gelu_first=*/1));
   return VRAG_OK;
 }
 
@@ -1503,13 +1549,13 @@ int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
   const int H = e->cfg.hidden_size;
   ProfScope ps(e, VRAG_PROF_HEAD, st);
   if (e->arch == 1) {  // post-LN stream: no final LayerNorm, just the bf16 operand copy
-    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(e->rows), dim3(256), 0, st, e->h, e->a, e->rows, e->rows, H, 0,
-                       (const float*)nullptr, (float*)nullptr);
+    launch_cvt_rows(e->op_dtype, dim3(e->rows), st, e->h, e->a, e->rows, e->rows, H, 0, (const float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
   } else {
-    HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st));
+    HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, nullptr, nullptr, e->op_dtype));
   }
   GemmParams g{};
+  g.op_dtype = e->op_dtype;
   g.A = e->a;
   g.W = e->mlm_dense;
   g.M = e->rows;
@@ -1518,9 +1564,11 @@ int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
   g.out_f32 = e->f32tmp;
   g.bias = e->mlm_dense_b;
   HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
-  HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, e->mlm_norm_b));
+  HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, e->mlm_norm_b, nullptr,
+                           e->op_dtype));
   HIP_TRY(hipMemsetAsync(e->d_splade, 0, (size_t)e->n_seqs * e->vpad * sizeof(unsigned), st));
   GemmParams d{};
+  d.op_dtype = e->op_dtype;
   d.A = e->a;
   d.W = e->mlm_dec;
   d.M = e->rows;
@@ -1672,6 +1720,7 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
   (void)hipMemset(cs, 0, 512 * 32 * 4);
   (void)hipMemset(sn, 0, 512 * 32 * 4);
   GemmParams g{};
+  g.op_dtype = getenv("VRAG_DEBUG_GEMM_F16") ? kOpF16 : kOpBf16;   // same bit patterns read as fp16: finite values in [2^-15, 2^-7)
   g.A = (const bf16_t*)A;
   g.W = (const bf16_t*)W;
   g.M = M;

@@ -11,13 +11,16 @@ namespace vrag {
 hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows,
                            float* h, bf16_t* a, hipStream_t stream, const float* P = nullptr,
                            const int* pos = nullptr, const float* type_row = nullptr, const float* bias = nullptr,
-                           const int* type_ids = nullptr);   // type_ids: per-token row of the table at type_row
+                           const int* type_ids = nullptr,    // type_ids: per-token row of the table at type_row
+                           int op_dtype = kOpBf16);          // what `a` holds (kOpBf16 / kOpF16)
 
 // out = LN(h) * w (+ bias); writes bf16 and/or fp32 (either pointer may be null; out_f32 may be h itself).
 // w == nullptr: no gain (it is folded into the consumer GEMM's weight); row_mean != nullptr: also mean(h[row]).
+// op_dtype: what out_bf16 holds (kOpBf16 / kOpF16); out_lo != nullptr: also the remainder  x - float(out_bf16)  in the
+// same type (the split-operand head GEMM multiplies both parts).
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows,
                             bf16_t* out_bf16, float* out_f32, hipStream_t stream, const float* bias = nullptr,
-                            float* row_mean = nullptr);
+                            float* row_mean = nullptr, int op_dtype = kOpBf16, bf16_t* out_lo = nullptr);
 
 // For each range r: v = mean_{t in [start[r], end[r]]} LN(h[t]) * lnw   (inclusive token range; lnw == nullptr:
 // no LayerNorm, v = mean of h -- post-LN encoders)
@@ -28,10 +31,11 @@ hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H,
                              const int* end, int n_ranges, int mode, const float* Wc, const float* bc,
                              int num_labels, float* out, hipStream_t stream);
 
-// Token-classification tail: logits[t][c] = LN(x[t]) * lnw . Wc[c] + bc[c]   (x fp32 = gelu(dense(h)))
+// Token-classification tail: logits[t][c] = LN(x[t]) * lnw . Wc[c] + bc[c]   (x fp32 = gelu(dense(h));
+// gelu_first: x holds the raw dense output and the kernel applies gelu_erf itself)
 hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows,
                                 const float* Wc, const float* bc, int num_labels, float* logits,
-                                hipStream_t stream, const float* lnb = nullptr);
+                                hipStream_t stream, const float* lnb = nullptr, int gelu_first = 0);
 
 // logits[s][c] = Wc[c] . tanh(Wp . h[first[s]] + bp) + bc[c]   (BertPooler + classifier; one workgroup per sequence)
 hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row, int n_seqs, const float* Wp,

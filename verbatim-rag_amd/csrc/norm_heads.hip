@@ -56,6 +56,7 @@ __device__ __forceinline__ void ln_row(f32x4 (&x)[MAXV], const f32x4 (&w)[MAXV],
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const float* __restrict__ E,
                                                         const float* __restrict__ w, float eps, int H, int rows,
                                                         float* __restrict__ h, bf16_t* __restrict__ a,
@@ -86,19 +87,20 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
     const int c = lane * 4 + 256 * i;
     if (c < H) {
       *reinterpret_cast<f32x4*>(h + (size_t)row * H + c) = x[i];
-      bf16x4 o;
+      typename Op<T>::v4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)x[i][j];
-      *reinterpret_cast<bf16x4*>(a + (size_t)row * H + c) = o;
+      for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(x[i][j]);
+      *reinterpret_cast<typename Op<T>::v4*>(a + (size_t)row * H + c) = o;
     }
   }
 }
 
 // `of` may alias `h` (in place): a row is fully in registers before anything is written.
+template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const float* __restrict__ w,
                                                          float eps, int H, int rows, bf16_t* __restrict__ ob,
                                                          float* of, const float* __restrict__ bias,
-                                                         float* __restrict__ row_mean) {
+                                                         float* __restrict__ row_mean, bf16_t* __restrict__ ob_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -119,10 +121,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const fl
     if (c < H) {
       if (of) *reinterpret_cast<f32x4*>(of + (size_t)row * H + c) = x[i];
       if (ob) {
-        bf16x4 o;
+        typename Op<T>::v4 o, lo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)x[i][j];
-        *reinterpret_cast<bf16x4*>(ob + (size_t)row * H + c) = o;
+        for (int j = 0; j < 4; ++j) {
+          o[j] = Op<T>::to(x[i][j]);
+          lo[j] = Op<T>::to(x[i][j] - (float)o[j]);   // remainder: x = o + lo to twice the operand precision
+        }
+        *reinterpret_cast<typename Op<T>::v4*>(ob + (size_t)row * H + c) = o;
+        if (ob_lo) *reinterpret_cast<typename Op<T>::v4*>(ob_lo + (size_t)row * H + c) = lo;
       }
     }
   }
@@ -203,12 +209,19 @@ __global__ __launch_bounds__(256) void range_pool_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void ln_classifier_kernel(const float* __restrict__ x_in, const float* __restrict__ lnw,
                                                              float eps, int H, int rows, const float* __restrict__ Wc,
                                                              const float* __restrict__ bc, int num_labels,
-                                                             float* __restrict__ logits, const float* __restrict__ lnb) {
+                                                             float* __restrict__ logits, const float* __restrict__ lnb,
+                                                             int gelu_first) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 x[MAXV], wv[MAXV];
   load_row(x_in + (size_t)row * H, H, lane, x);
+  if (gelu_first) {   // x_in is the raw dense output (split-operand head): the activation was not applied by a GEMM epilogue
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[i][j] = gelu_erf(x[i][j]);
+  }
   load_row(lnw, H, lane, wv);
   ln_row(x, wv, H, lane, eps, lnb);
   for (int c = 0; c < num_labels; ++c) {
@@ -271,19 +284,26 @@ __global__ __launch_bounds__(256) void pooler_classifier_kernel(const float* __r
 
 hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float eps, int H, int rows, float* h,
                            bf16_t* a, hipStream_t stream, const float* P, const int* pos, const float* type_row,
-                           const float* bias, const int* type_ids) {
+                           const float* bias, const int* type_ids, int op_dtype) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3) || (P && !pos)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a, P, pos,
-                     type_row, bias, type_ids);
+  if (op_dtype == kOpF16)
+    hipLaunchKernelGGL(embed_ln_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a, P, pos,
+                       type_row, bias, type_ids);
+  else
+    hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, ids, E, w, eps, H, rows, h, a, P, pos,
+                       type_row, bias, type_ids);
   return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows, bf16_t* ob, float* of,
-                            hipStream_t stream, const float* bias, float* row_mean) {
+                            hipStream_t stream, const float* bias, float* row_mean, int op_dtype, bf16_t* ob_lo) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean);
+  if (op_dtype == kOpF16)
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean, ob_lo);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean, ob_lo);
   return hipGetLastError();
 }
 
@@ -298,11 +318,12 @@ hipError_t launch_range_pool(const float* h, const float* lnw, float eps, int H,
 }
 
 hipError_t launch_ln_classifier(const float* x, const float* lnw, float eps, int H, int rows, const float* Wc,
-                                const float* bc, int num_labels, float* logits, hipStream_t stream, const float* lnb) {
+                                const float* bc, int num_labels, float* logits, hipStream_t stream, const float* lnb,
+                                int gelu_first) {
   if (rows <= 0) return hipSuccess;
   if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_classifier_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, lnw, eps, H, rows, Wc, bc,
-                     num_labels, logits, lnb);
+                     num_labels, logits, lnb, gelu_first);
   return hipGetLastError();
 }
 

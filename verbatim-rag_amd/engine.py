@@ -100,9 +100,16 @@ class EncoderEngine:
         max_ranges: int = 4096,
         micro_batch_tokens: int = 0,
         device: int = 0,
+        operand_dtype: str = "bf16",
     ):
+        """operand_dtype: type of the MFMA operands -- "bf16" (default: fp32's exponent range, sentence logits within
+        3e-4 of the fp32 reference) or "f16" (11 significant bits at the same rate, saturating at 65504: per-token logits
+        within 1e-3).  Accumulation, residual stream, LayerNorm, softmax, RoPE and heads are fp32 either way."""
         self._lib = _lib.load()
         _lib.require_gpu()
+        if operand_dtype not in _lib.OPERAND_DTYPES:
+            raise ValueError(f"operand_dtype must be one of {sorted(_lib.OPERAND_DTYPES)} (got {operand_dtype!r})")
+        self.operand_dtype = operand_dtype
         self.shape = shape
         self._h = C.c_void_p()
         w = strip_prefix(weights)
@@ -144,7 +151,7 @@ class EncoderEngine:
             sliding_window=shape.local_attention // 2, rope_theta_global=shape.global_rope_theta,
             rope_theta_local=shape.local_rope_theta, norm_eps=shape.norm_eps, pad_token_id=shape.pad_token_id,
             max_seq_len=max_seq_len, max_tokens=max_tokens, max_seqs=max_seqs, max_ranges=max_ranges,
-            micro_batch_tokens=micro_batch_tokens, device=device,
+            micro_batch_tokens=micro_batch_tokens, device=device, operand_dtype=_lib.OPERAND_DTYPES[operand_dtype],
         )
         self.max_tokens, self.max_seqs, self.max_seq_len, self.max_ranges = max_tokens, max_seqs, max_seq_len, max_ranges
         _lib.check("vrag_encoder_create", self._lib.vrag_encoder_create(C.byref(cfg), C.byref(cw), C.byref(self._h)))
@@ -366,9 +373,13 @@ class BertEncoderEngine(EncoderEngine):
     `weights.bert_canonical(...)`; every batch entry point of `EncoderEngine` works unchanged."""
 
     def __init__(self, shape: BertShape, weights: Dict[str, np.ndarray], max_tokens: int = 8192, max_seqs: int = 64,
-                 max_seq_len: int = 512, max_ranges: int = 4096, micro_batch_tokens: int = 0, device: int = 0):
+                 max_seq_len: int = 512, max_ranges: int = 4096, micro_batch_tokens: int = 0, device: int = 0,
+                 operand_dtype: str = "bf16"):
         self._lib = _lib.load()
         _lib.require_gpu()
+        if operand_dtype not in _lib.OPERAND_DTYPES:
+            raise ValueError(f"operand_dtype must be one of {sorted(_lib.OPERAND_DTYPES)} (got {operand_dtype!r})")
+        self.operand_dtype = operand_dtype
         self.shape = shape
         self._h = C.c_void_p()
         L, H, I = shape.num_hidden_layers, shape.hidden_size, shape.intermediate_size
@@ -405,7 +416,7 @@ class BertEncoderEngine(EncoderEngine):
             intermediate_size=I, max_position_embeddings=shape.max_position_embeddings, norm_eps=shape.norm_eps,
             pad_token_id=shape.pad_token_id, max_seq_len=min(max_seq_len, shape.max_position_embeddings),
             max_tokens=max_tokens, max_seqs=max_seqs, max_ranges=max_ranges, micro_batch_tokens=micro_batch_tokens,
-            device=device)
+            device=device, operand_dtype=_lib.OPERAND_DTYPES[operand_dtype])
         self.max_tokens, self.max_seqs, self.max_ranges = max_tokens, max_seqs, max_ranges
         self.max_seq_len = min(max_seq_len, shape.max_position_embeddings)
         _lib.check("vrag_bert_encoder_create", self._lib.vrag_bert_encoder_create(C.byref(cfg), C.byref(cw), C.byref(self._h)))

@@ -141,7 +141,12 @@ class GpuModelSpanExtractor(SpanExtractor):
         chunk_cache_size: int = 65536,
         extra_engines: Sequence[Any] = (),
         n_engines: int = 1,
+        operand_dtype: Optional[str] = None,
     ):
+        """operand_dtype: MFMA operand type of the engines this extractor builds (`EncoderEngine`): None picks "bf16" for
+        the sentence-classifier format (sentence logits within 3e-4 of the fp32 reference) and "f16" for the v2 highlighter,
+        whose per-token logits need the three extra mantissa bits to stay within 1e-3."""
+        self.operand_dtype = operand_dtype
         self.model_path = model_path
         self.threshold = threshold
         self.min_span_chars = min_span_chars
@@ -208,8 +213,10 @@ class GpuModelSpanExtractor(SpanExtractor):
 
         shape, tensors, _cfg = load_safetensors_dir(model_path)
         max_seq = self.qa_max_length if self._format == self._FORMAT_QA_MODEL else self.max_length
+        dtype = self.operand_dtype or ("bf16" if self._format == self._FORMAT_QA_MODEL else "f16")
         eng = EncoderEngine(shape, tensors, max_tokens=self.max_batch_tokens, max_seqs=self.max_batch_seqs,
-                            max_seq_len=max_seq, max_ranges=max(4096, self.max_batch_tokens // 8), device=dev)
+                            max_seq_len=max_seq, max_ranges=max(4096, self.max_batch_tokens // 8), device=dev,
+                            operand_dtype=dtype)
         if self._format == self._FORMAT_QA_MODEL:
             eng.set_qa_head(tensors["classifier.weight"], tensors["classifier.bias"])
         else:

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Summarises a rocprofv3 --pmc rocpd database: per kernel name, mean counter value per dispatch."""
+import os
 import sqlite3
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty  # noqa: E402
 
 
 def main(path):
@@ -18,7 +22,7 @@ def main(path):
         return
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, set()]))
     for k, c, v, d in db.execute(f"select {name_c}, {cn}, {val}, {did or 0} from counters_collection"):
-        a = agg[k][c]
+        a = agg[pretty(k)][c]
         a[0] += float(v)
         a[1].add(d)
     for k, cs in agg.items():

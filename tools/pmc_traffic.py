@@ -6,15 +6,19 @@ here on layernorm/embed kernels whose byte counts are known).  The counters sit 
 side, so Infinity-Cache hits are included: `hbm_bytes_per_launch` is an upper bound on DRAM traffic.
 Usage: pmc_traffic.py pmc.txt bench_line.json > profiles/rNN_pmc_traffic.json"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty  # noqa: E402
 
 
 def parse(path):
     out, cur = {}, None
     for line in open(path):
         if not line.startswith(" "):
-            cur = line.strip()
+            cur = pretty(line.strip())
             out.setdefault(cur, {})
         else:
             m = re.match(r"\s+(\S+)\s+([0-9.]+) per dispatch", line)

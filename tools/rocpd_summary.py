@@ -6,8 +6,12 @@ With W K (the --warmup/--steps the profiled `bench.py` ran with) two more tables
 dispatches of the timed region (micro-batches on two streams) and those of bench.py's single-stream
 pass (1 untimed + 2 profiled steps, always last) -- the phases bench.py's `roofline.timed_region`
 and `roofline` report with HIP events."""
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty  # noqa: E402
 
 
 def main(path: str) -> None:
@@ -25,14 +29,14 @@ def main(path: str) -> None:
     for r in rows:
         print(f"{r[1]:7d} {r[2] / 1e6:10.3f} {r[3] / 1e3:10.2f} {r[4] / 1e3:9.2f} {r[5] / 1e3:9.2f} "
               f"{100.0 * r[2] / total:6.2f} {r[6] or 0:5d} {r[7] or 0:5d} {r[8] or 0:5d} {r[9] or 0:7d} "
-              f"{r[10] or 0:5d} {r[11] or 0:9d} {r[12] or 0:4d}  {r[0]}")
+              f"{r[10] or 0:5d} {r[11] or 0:9d} {r[12] or 0:4d}  {pretty(r[0])}")
 
 
 def phases(path: str, W: int, K: int) -> None:
     db = sqlite3.connect(path)
     per = {}
     for name, start, dur in db.execute("select name, start, duration from kernels order by start"):
-        per.setdefault(name, []).append(dur)
+        per.setdefault(pretty(name), []).append(dur)
     tot = W + K + 3
     for title, lo, hi in (("timed region (two streams)", W, W + K), ("single-stream pass (profiled steps)", W + K + 1, tot)):
         print(f"\n# {title}: dispatches of bench steps [{lo}, {hi}) of {tot}")

@@ -381,8 +381,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // 128 x 256 tile with three stages (72 KiB, 4 waves) run as TWO workgroups per CU: the configuration of the residual
 // GEMMs, whose fp32 read-modify-write epilogue is HBM-bound -- one workgroup's epilogue then streams under the other's
 // main loop instead of leaving the matrix cores idle.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64, typename T = bf16_t>
+//
+// SCHED = 1 (256 x 256 x 64 tile, 8 waves, two stages only): the "8-phase" schedule of cdna_hip_programming.md section 5.
+// A K-tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each (8 MFMAs); a phase is
+//   { ds_read the quadrant's new fragments | issue one 16 KiB operand piece of the NEXT K-tile | counted vmcnt }
+//   s_barrier { lgkmcnt(0) | setprio 1 | 8 MFMAs | setprio 0 } s_barrier
+// and the waves 4-7 run one barrier behind the waves 0-3, so on every SIMD one wave feeds the matrix pipe while its
+// partner reads LDS and issues DMA.  Operand pieces are cut by quadrant, not by tile half -- W rows of the n = 0 quadrants,
+// A rows of the m = 0 quadrants, W rows of n = 1, A rows of m = 1, in the order the phases need them -- so every piece has
+// three phases to land before its first read (never a vmcnt(0) in the loop) and is re-staged four or more phases after its
+// last read.
+template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64, typename T = bf16_t, int SCHED = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
+  static_assert(SCHED == 0 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BKT == 64 && DBG == 0),
+                "the 8-phase schedule is written for the 256 x 256 x 64 tile");
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
   static_assert(NS >= 2 && NS <= 4, "LDS stages");
@@ -563,8 +575,108 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       buf = buf + 1 == NS ? 0 : buf + 1;
     }
   };
-  if (v_block) mainloop(std::false_type{});
-  else mainloop(std::true_type{});
+  // ------------------------------------------------------------------ 8-phase schedule (SCHED == 1)
+  auto mainloop8 = [&](auto swapped_tag) {
+    constexpr bool SWAPPED = decltype(swapped_tag)::value;
+    // piece q of a K-tile (16 KiB = 128 tile rows, two DMA instructions per wave): 0 = W rows of the n = 0 quadrants
+    // (wn*64 + [0,32)), 1 = A rows of the m = 0 quadrants (wm*128 + [0,64)), 2 = W rows of n = 1, 3 = A rows of m = 1.
+    // wave w fills piece rows [16 w, 16 w + 16): tile row = block base + offset, blocks of 32 (W) or 64 (A) rows.
+    int prowA[2], prowW[2];   // tile rows of this wave's two instructions inside an A piece / a W piece (for m/n = 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wave * 16 + i * 8;           // piece row of lane 0 of the instruction
+      prowA[i] = (r >> 6) * 128 + (r & 63);      // + 64 for the m = 1 piece
+      prowW[i] = (r >> 5) * 64 + (r & 31);       // + 32 for the n = 1 piece
+    }
+    auto stage_piece = [&](int kt, int q) {      // q is a compile-time constant at every call site
+      char* slot = smem + (kt & 1) * STAGE_BYTES;
+      const int k0 = kt * BKT;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool isA = (q & 1) != 0;
+        const int row0 = (isA ? prowA[i] + (q == 3 ? 64 : 0) : prowW[i] + (q == 2 ? 32 : 0));
+        const int row = row0 + (lane >> 3);
+        const int off = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3) + k0;
+        glds16((isA ? Ab : Wb) + off, slot + (isA ? 0 : A_BYTES) + row0 * ROWB);
+      }
+    };
+    const bool late = wave >= 4;                 // second wave group: one barrier behind
+    // prologue: the whole first K-tile, then the first two pieces of the second
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_piece(0, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (late) __builtin_amdgcn_s_barrier();
+    V8 wf0[KS], wf1[KS], af[2][KS];
+    for (int kt = 0; kt < KT; ++kt) {
+      const char* sA = smem + (kt & 1) * STAGE_BYTES + (wm * WROWS) * ROWB;
+      const char* sW = smem + (kt & 1) * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
+      const bool more = kt + 1 < KT;
+      auto phase = [&](auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        // -- fragments this phase adds
+        if constexpr (PH == 0) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) wf0[s] = *reinterpret_cast<const V8*>(sW + fo[s]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            af[0][s] = *reinterpret_cast<const V8*>(sA + fo[s]);
+            af[1][s] = *reinterpret_cast<const V8*>(sA + 32 * ROWB + fo[s]);
+          }
+        } else if constexpr (PH == 1) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) wf1[s] = *reinterpret_cast<const V8*>(sW + 32 * ROWB + fo[s]);
+        } else if constexpr (PH == 2) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            af[0][s] = *reinterpret_cast<const V8*>(sA + 64 * ROWB + fo[s]);
+            af[1][s] = *reinterpret_cast<const V8*>(sA + 96 * ROWB + fo[s]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // -- one piece of the next K-tile; then this wave's share of the piece the NEXT phase reads must have landed
+        if (more) stage_piece(kt + 1, PH);
+        if constexpr (PH != 2) {   // phase 3 adds no fragments: nothing to wait for before it
+          if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // two younger pieces may stay in flight
+          else if (PH == 3) asm volatile("" ::: "memory");               // last K-tile: everything landed long ago
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int NI_ = (PH == 0 || PH == 3) ? 0 : 1;     // quadrant column
+        constexpr int M0 = (PH < 2) ? 0 : 2;                  // quadrant's first row tile
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const V8& w_ = NI_ == 0 ? wf0[s] : wf1[s];
+            if constexpr (SWAPPED) acc[NI_][M0 + m] = Op<T>::mfma32(w_, af[m][s], acc[NI_][M0 + m]);
+            else acc[NI_][M0 + m] = Op<T>::mfma32(af[m][s], w_, acc[NI_][M0 + m]);
+          }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      };
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 2>{});
+      phase(std::integral_constant<int, 3>{});
+    }
+    if (!late) __builtin_amdgcn_s_barrier();   // re-align the two wave groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  if constexpr (SCHED == 1) {
+    if (v_block) mainloop8(std::false_type{});
+    else mainloop8(std::true_type{});
+  } else {
+    if (v_block) mainloop(std::false_type{});
+    else mainloop(std::true_type{});
+  }
 
   gemm_epilogue<EPI, MI, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
@@ -645,6 +757,18 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
           hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1, 2, 64, T>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
           return hipGetLastError();
         }
+      }
+      static const bool sched8 = getenv("VRAG_GEMM_SCHED8") && atoi(getenv("VRAG_GEMM_SCHED8")) != 0;
+      if (sched8) {
+        static bool attr8 = false;
+        if (!attr8) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T, 1>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+          if (e != hipSuccess) return e;
+          attr8 = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T, 1>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
+        return hipGetLastError();
       }
       hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
     }

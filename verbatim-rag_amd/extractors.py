@@ -339,7 +339,9 @@ class GpuModelSpanExtractor(SpanExtractor):
             nonlocal cur, tok, rng
             n_tok, n_rng = len(item[3]), len(item[4])
             if n_tok > self.engine.max_tokens or n_rng > self.engine.max_ranges:
-                raise ValueError("a single sample exceeds the engine workspace")
+                # this chunk stays without spans, the rest of the call goes on (extractors.py:225-227: log, [] for the chunk)
+                logger.error("query %d: a sample of %d tokens / %d sentences exceeds the engine workspace", item[0], n_tok, n_rng)
+                return
             if len(cur) >= self.engine.max_seqs or tok + n_tok > self.engine.max_tokens or rng + n_rng > self.engine.max_ranges:
                 pending.append(self._worker().submit(self._run_sub_batch, cur, out, len(pending) % len(self.engines)))
                 cur, tok, rng = [], 0, 0
@@ -347,32 +349,34 @@ class GpuModelSpanExtractor(SpanExtractor):
             tok += n_tok
             rng += n_rng
 
-        for qi, (question, results) in enumerate(zip(questions, results_per_question)):
-            texts = [getattr(r, "text", "") for r in results]
-            out.append({t: [] for t in texts})
-            q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
-            for i, (t, entry) in enumerate(zip(texts, self._entries(texts))):
-                if not entry[0]:
-                    continue                              # blank chunk -> [] (extractors.py:209-211)
-                fast = self._pack_fast(q_ids, entry)
-                if fast is not None:
-                    add((qi, t, entry[0], fast[0], fast[1], fast[2]))
-                    continue
-                smp = encode_question_and_sentences(q_ids, entry[1], self._tok.sep_token_id, max_length=self.qa_max_length)
-                vb = valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
-                if not vb:
-                    # the reference's QAModel returns None here and `len(None)` raises; we log and return [].
-                    logger.error("query %d chunk %d: no sentence fits the %d-token budget", qi, i, self.qa_max_length)
-                    continue
-                add((qi, t, entry[0], np.asarray(smp.input_ids, np.int32), np.asarray([b[0] for b in vb], np.int64),
-                     np.asarray([b[1] for b in vb], np.int64)))
-        if cur:
-            if pending:
-                pending.append(self._worker().submit(self._run_sub_batch, cur, out, len(pending) % len(self.engines)))
-            else:
-                self._run_sub_batch(cur, out)             # the common single-query call: no thread hop
-        for f in pending:
-            f.result()
+        try:
+            for qi, (question, results) in enumerate(zip(questions, results_per_question)):
+                texts = [getattr(r, "text", "") for r in results]
+                out.append({t: [] for t in texts})
+                q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
+                for i, (t, entry) in enumerate(zip(texts, self._entries(texts))):
+                    if not entry[0]:
+                        continue                              # blank chunk -> [] (extractors.py:209-211)
+                    fast = self._pack_fast(q_ids, entry)
+                    if fast is not None:
+                        add((qi, t, entry[0], fast[0], fast[1], fast[2]))
+                        continue
+                    smp = encode_question_and_sentences(q_ids, entry[1], self._tok.sep_token_id, max_length=self.qa_max_length)
+                    vb = valid_boundaries(smp.sentence_boundaries, len(smp.input_ids))
+                    if not vb:
+                        # the reference's QAModel returns None here and `len(None)` raises; we log and return [].
+                        logger.error("query %d chunk %d: no sentence fits the %d-token budget", qi, i, self.qa_max_length)
+                        continue
+                    add((qi, t, entry[0], np.asarray(smp.input_ids, np.int32), np.asarray([b[0] for b in vb], np.int64),
+                         np.asarray([b[1] for b in vb], np.int64)))
+            if cur:
+                if pending:
+                    pending.append(self._worker().submit(self._run_sub_batch, cur, out, len(pending) % len(self.engines)))
+                else:
+                    self._run_sub_batch(cur, out)             # the common single-query call: no thread hop
+        finally:
+            for f in pending:                                 # never leave a sub-batch running behind the caller's back
+                f.result()
         return out
 
     def _worker(self):
@@ -468,7 +472,12 @@ class GpuModelSpanExtractor(SpanExtractor):
                     tok += len(flat[end][1][0])
                     end += 1
                 if end == start:
-                    raise ValueError("a single window exceeds the engine workspace")
+                    # one window larger than the workspace: this chunk stays without spans, the others go on (the
+                    # reference logs a failing chunk and returns [] for it, extractors.py:225-227)
+                    logger.error("Highlighter extraction failed: a window of %d tokens exceeds the engine workspace "
+                                 "(max_tokens=%d)", len(flat[start][1][0]), self.engine.max_tokens)
+                    start += 1
+                    continue
                 try:
                     self.engine.load_batch([w[0] for _ji, w in flat[start:end]])
                     self.engine.run()

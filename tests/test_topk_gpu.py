@@ -86,6 +86,34 @@ def test_dense_topk_random_data_ranking_equals_the_fp32_query_oracle():
         _assert_same_ranking(sb, ib, rs, ri, rows, Qd)
 
 
+def test_dense_f32_rows_are_bit_exact_on_arbitrary_data():
+    """fp32 rows (the store's default, like the reference's FLOAT_VECTOR field) run on v_mfma_f32_32x32x2_f32, whose
+    result IS the oracle's sequential `acc = fmaf(x[c], q[c], acc)` chain: scores and ids equal oracle/topk_ref.c bit for
+    bit on data where summation order matters (normalised Gaussian rows and queries), for every batch size -- one
+    query, a partial pass, several passes -- and with ties broken by id (duplicated rows)."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(7)
+    for n, dim in ((70001, 768), (33000, 384), (5000, 96)):
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        X[n // 2] = X[3]                       # an exact duplicate far away: equal scores, the lower id first
+        sh = DenseShard(dim, n, "f32")
+        sh.add(X[: n // 3])
+        sh.add(X[n // 3:])                     # appended in two calls
+        for nq in (1, 2, 5, 33, 70):
+            Q = rng.standard_normal((nq, dim)).astype(np.float32)
+            Q[0] = X[3] * np.float32(1.7)      # query aligned with the duplicated row
+            for k in (1, 10, 16):
+                s, i = sh.search(Q, k)
+                rs, ri = T.dense_topk(X, Q, k)
+                assert np.array_equal(i, ri), (n, dim, nq, k)
+                assert np.array_equal(s, rs), (n, dim, nq, k, float(np.abs(s - rs).max()))
+            if nq == 1:
+                assert i[0, 0] == 3 and (k == 1 or i[0, 1] == n // 2)
+        sh.close()
+
+
 def test_dense_fewer_rows_than_k_and_empty():
     from verbatim_rag_amd.vector_stores import DenseShard
 

@@ -567,6 +567,328 @@ __global__ __launch_bounds__(256, 1) void dense_topk_mfma2_kernel(const bf16_t* 
   }
 }
 
+// ------------------------------------------------------------------------------------ dense, fp32 rows, bit-exact
+// fp32 rows x fp32 queries on the fp32 matrix instruction v_mfma_f32_32x32x2_f32: its result is, bit for bit, the k-ordered
+// chain  D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))  (cdna_hip_programming.md section 3), i.e. exactly the sequential
+// `acc = fmaf(x[c], q[c], acc)` of the CPU restatement when instruction t carries dims (2t, 2t+1).  Scores -- and
+// therefore the top-k order -- equal oracle/topk_ref.c on ARBITRARY data, for every batch size, not only on
+// dyadic-grid data where any summation order is exact.  At 64 FLOP/clk/SIMD (157 TFLOP/s) a pass of 32 queries over
+// N x 768 fp32 rows needs 0.31 us of matrix time per 1000 rows against 0.49 us of HBM time (6.3 TB/s): still a
+// streaming kernel.  One wave per SIMD; rows arrive as 128-row x 32-dim tiles (16 KiB) by LDS-DMA, the 32 query rows sit
+// in LDS as fp32 (row stride dim*4 + 16 bytes: conflict-free ds_read_b128), both operands are read 16 bytes at a time
+// and feed two MFMAs each (lane (i, kk) takes elements kk and 2 + kk).  Every lane keeps the top-KL keys of its
+// (query, 16-row stripe) in REGISTERS (branch-free insertion network, entered only by keys above the shared threshold).
+constexpr int XQ = 32;      // queries per pass
+constexpr int XKL = 16;     // register list length (k <= 16)
+template <int NSLOT>
+__global__ __launch_bounds__(256, 1) void dense_topk_exact_kernel(const float* __restrict__ rows, long long row_lo,
+                                                                   long long n_rows /* end of this launch's row range */,
+                                                                   int dim, const float* __restrict__ queries, int nq, int q0,
+                                                                   int k, u64* __restrict__ cand, int rows_per_wg,
+                                                                   u64* __restrict__ thr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int qstride = dim * 4 + 16;                                  // bytes between query rows in LDS
+  char* sQ = smem;
+  char* ring = smem + ((XQ * qstride + 1023) / 1024) * 1024;          // NSLOT x 16 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const long long r_begin = row_lo + (long long)blockIdx.x * rows_per_wg;
+  const long long r_end = min(n_rows, r_begin + rows_per_wg);
+  const int n_groups = (int)((r_end - r_begin + 127) / 128);
+  const int KT = dim >> 5;
+  const int T = n_groups * KT;
+
+  // queries -> LDS (plain loads, retired before any LDS-DMA is in flight)
+  for (int i = tid; i < XQ * (dim >> 2); i += 256) {
+    const int j = i / (dim >> 2), c = (i - j * (dim >> 2)) << 2;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q0 + j < nq) v = *reinterpret_cast<const f32x4*>(queries + (size_t)(q0 + j) * dim + c);
+    *reinterpret_cast<f32x4*>(sQ + j * qstride + c * 4) = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int soff[4];   // element offset of this lane's 16-byte chunk inside a tile row (source-side swizzle)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    soff[i] = ((lane & 7) ^ ((row >> 1) & 7)) << 2;
+  }
+  int sg = 0, skt = 0, st_t = 0, st_slot = 0;
+  auto stage_next = [&]() {
+    char* slot = ring + st_slot * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const long long gr = min(r_begin + (long long)sg * 128 + row, n_rows - 1);
+      glds16(rows + (size_t)gr * dim + skt * 32 + soff[i], slot + (wave * 32 + i * 8) * 128);
+    }
+    ++st_t;
+    st_slot = st_slot + 1 == NSLOT ? 0 : st_slot + 1;
+    if (++skt == KT) {
+      skt = 0;
+      ++sg;
+    }
+  };
+  for (int t = 0; t < min(T, NSLOT - 1); ++t) stage_next();
+
+  u64 lst[XKL];
+#pragma unroll
+  for (int i = 0; i < XKL; ++i) lst[i] = 0ull;
+  u64 kth = 0ull;
+  __syncthreads();   // sQ visible
+
+  const int fsw = (l31 >> 1) & 7;
+  const char* qrow = sQ + l31 * qstride;
+  int t = 0, slot_r = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kt = 0; kt < KT; ++kt) {
+      // tile t landed (this wave's share); up to NSLOT-2 later tiles (4 DMA instructions each) stay in flight
+      const int ahead = min(NSLOT - 2, T - 1 - t);
+      if (ahead >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (st_t < T) stage_next();   // into the slot of tile t-1, which every wave finished before the barrier
+      const char* sA = ring + slot_r * 16384 + (wave * 32 + l31) * 128;
+      const char* sB = qrow + kt * 128;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(sA + ((u ^ fsw) << 4));
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + (u << 4));
+        // instruction 2u carries dims (4u, 4u+1), instruction 2u+1 dims (4u+2, 4u+3): ascending, like the oracle's loop
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a4[1] : a4[0], hi ? b4[1] : b4[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a4[3] : a4[2], hi ? b4[3] : b4[2], acc, 0, 0, 0);
+      }
+      ++t;
+      slot_r = slot_r + 1 == NSLOT ? 0 : slot_r + 1;
+    }
+    // 16 row scores of query (q0 + l31): filtered insertion (threshold shared through thr[], see dense_topk_mfma2_kernel)
+    const long long rb = r_begin + (long long)g * 128 + wave * 32 + 4 * hi;
+    if (q0 + l31 < nq) {
+      const u64 shared = __hip_atomic_load(thr + q0 + l31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u64 bar = shared > kth ? shared : kth;
+      bool changed = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = rb + (r & 3) + 8 * (r >> 2);
+        const u64 key = row < r_end ? make_key(acc[r], (unsigned)row) : 0ull;
+        if (key > bar) {
+          u64 cur = key;   // branch-free sorted insertion: every slot keeps the larger of (itself, the carried key)
+#pragma unroll
+          for (int i = 0; i < XKL; ++i) {
+            const u64 a = lst[i];
+            const bool up = cur > a;
+            lst[i] = up ? cur : a;
+            cur = up ? a : cur;
+          }
+          kth = k == XKL ? lst[XKL - 1] : 0ull;
+#pragma unroll
+          for (int i = 0; i < XKL - 1; ++i)
+            if (i == k - 1) kth = lst[i];
+          bar = kth > bar ? kth : bar;
+          changed = true;
+        }
+      }
+      if (changed && kth > shared) atomicMax(reinterpret_cast<unsigned long long*>(thr + q0 + l31), (unsigned long long)kth);
+    }
+  }
+  __syncthreads();   // every wave is done with the ring: reuse it for the per-lane lists
+  u64* lists = reinterpret_cast<u64*>(ring);   // [256 lanes][k]
+#pragma unroll
+  for (int i = 0; i < XKL; ++i)
+    if (i < k) lists[(size_t)tid * k + i] = lst[i];
+  __syncthreads();
+  // per query: 8 sorted lists (4 waves x 2 halves) -> k best
+  if (tid < XQ && q0 + tid < nq) {
+    int head[8];
+    for (int gg = 0; gg < 8; ++gg) head[gg] = 0;
+    u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
+    for (int i = 0; i < k; ++i) {
+      u64 best = 0ull;
+      int bg = -1;
+      for (int gg = 0; gg < 8; ++gg) {
+        if (head[gg] < k) {
+          const int src_lane = (gg >> 1) * 64 + (gg & 1) * 32 + tid;
+          const u64 v = lists[(size_t)src_lane * k + head[gg]];
+          if (v > best) {
+            best = v;
+            bg = gg;
+          }
+        }
+      }
+      out[i] = best;
+      if (bg >= 0) ++head[bg];
+    }
+  }
+}
+
+// Second form of the bit-exact kernel for dim = 384 / 768 (KT = dim / 32): the query operands live in REGISTERS -- lane
+// (query j, k-parity kk) holds the dim/2 elements of its query with that parity, 384 VGPRs at dim 768; one wave per SIMD
+// owns the whole 512-entry register file -- so the LDS is all row ring.  The ring is private per wave (8 slots of one
+// 32-row x 32-dim tile = 4 KiB): a wave reads only rows it staged itself, its own counted vmcnt orders DMA -> ds_read
+// (MI355X_MICROARCH.md: only OTHER waves' reads need a barrier), and the main loop has no s_barrier at all; 7 tiles =
+// 28 KiB per wave (112 KiB per CU) are in flight.  Same arithmetic, same results as dense_topk_exact_kernel.
+constexpr int X2SLOTS = 8;
+template <int KT>
+__global__ __launch_bounds__(256, 1) void dense_topk_exact2_kernel(const float* __restrict__ rows, long long row_lo,
+                                                                    long long n_rows /* end of this launch's row range */,
+                                                                    const float* __restrict__ queries, int nq, int q0, int k,
+                                                                    u64* __restrict__ cand, int rows_per_wg,
+                                                                    u64* __restrict__ thr) {
+  constexpr int DIM = KT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  char* ring = smem + wave * (X2SLOTS * 4096);                         // this wave's slots
+  u64* lists = reinterpret_cast<u64*>(smem + 4 * X2SLOTS * 4096);      // [256 lanes][k]
+
+  // query (q0 + l31): elements of parity kk = hi, in the order the MFMAs consume them
+  float qreg[KT][16];
+  {
+    const bool live = q0 + l31 < nq;
+    const float* qrow = queries + (size_t)(live ? q0 + l31 : 0) * DIM;
+    // one 32-dim slice at a time, retired before the next: 8 x 16-byte loads in flight, not 8 KT of them (the
+    // compiler would otherwise hoist every load of the unrolled loop and spill the whole query)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(qrow + kt * 32 + 4 * u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        qreg[kt][2 * u] = live ? (hi ? v[u][1] : v[u][0]) : 0.f;
+        qreg[kt][2 * u + 1] = live ? (hi ? v[u][3] : v[u][2]) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(qreg[kt][i]));
+    }
+  }
+
+  const long long r_begin = row_lo + (long long)blockIdx.x * rows_per_wg;
+  const long long r_end = min(n_rows, r_begin + rows_per_wg);
+  const int n_groups = (int)((r_end - r_begin + 127) / 128);
+  const int T = n_groups * KT;
+
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    soff[i] = ((lane & 7) ^ ((row >> 1) & 7)) << 2;
+  }
+  int sg = 0, skt = 0, st_t = 0;
+  auto stage_next = [&]() {
+    char* slot = ring + (st_t & (X2SLOTS - 1)) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 8 + (lane >> 3);
+      const long long gr = min(r_begin + (long long)sg * 128 + wave * 32 + row, n_rows - 1);
+      glds16(rows + (size_t)gr * DIM + skt * 32 + soff[i], slot + i * 1024);
+    }
+    ++st_t;
+    if (++skt == KT) {
+      skt = 0;
+      ++sg;
+    }
+  };
+  for (int t = 0; t < min(T, X2SLOTS - 1); ++t) stage_next();
+
+  u64* mylist = lists + (size_t)tid * k;
+  for (int i = 0; i < k; ++i) mylist[i] = 0ull;
+  u64 kth = 0ull;
+  const int fsw = (l31 >> 1) & 7;
+  // wait until this wave's tile `tt` has landed: up to `ahead` younger tiles (4 DMA instructions each) may stay in flight
+  auto wait_tile = [&](int tt) {
+    const int ahead = min(st_t - 1 - tt, X2SLOTS - 1);
+    if (ahead >= 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // (Measured r2i: a two-deep register pipeline over half tiles -- next half's reads under the current half's MFMAs, each
+  // element selected right in front of its MFMA -- ran 1.76 ms per pass against 0.93 ms for this plain form: the
+  // select -> MFMA-operand dependency stalls cost more than the exposed LDS latency.)
+  int t = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      wait_tile(t);
+      const char* sA = ring + (t & (X2SLOTS - 1)) * 4096 + l31 * 128;
+      float a2[16];   // this lane's 16 row elements of the tile (parity kk), selected out of eight 16-byte reads
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sA + ((u ^ fsw) << 4));
+        a2[2 * u] = hi ? v[1] : v[0];
+        a2[2 * u + 1] = hi ? v[3] : v[2];
+      }
+      // the slot of tile t-1 is free: its reads were consumed by the MFMAs issued in the previous iteration
+      if (st_t < T) stage_next();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], qreg[kt][i], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // keep later tiles' reads from being hoisted over this one (384 live query registers)
+      ++t;
+    }
+    const long long rb = r_begin + (long long)g * 128 + wave * 32 + 4 * hi;
+    if (q0 + l31 < nq) {
+      const u64 shared = __hip_atomic_load(thr + q0 + l31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u64 bar = shared > kth ? shared : kth;
+      bool changed = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = rb + (r & 3) + 8 * (r >> 2);
+        if (row < r_end) {
+          const u64 key = make_key(acc[r], (unsigned)row);
+          if (key > bar) {
+            insert_key(mylist, k, key);
+            kth = mylist[k - 1];
+            bar = kth > bar ? kth : bar;
+            changed = true;
+          }
+        }
+      }
+      if (changed && kth > shared) atomicMax(reinterpret_cast<unsigned long long*>(thr + q0 + l31), (unsigned long long)kth);
+    }
+  }
+  __syncthreads();
+  // per query: 8 sorted lists (4 waves x 2 halves) -> k best
+  if (tid < XQ && q0 + tid < nq) {
+    int head[8];
+    for (int gg = 0; gg < 8; ++gg) head[gg] = 0;
+    u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
+    for (int i = 0; i < k; ++i) {
+      u64 best = 0ull;
+      int bg = -1;
+      for (int gg = 0; gg < 8; ++gg) {
+        if (head[gg] < k) {
+          const int src_lane = (gg >> 1) * 64 + (gg & 1) * 32 + tid;
+          const u64 v = lists[(size_t)src_lane * k + head[gg]];
+          if (v > best) {
+            best = v;
+            bg = gg;
+          }
+        }
+      }
+      out[i] = best;
+      if (bg >= 0) ++head[bg];
+    }
+  }
+}
+
 // thr[q] = k-th key of query q's exact top-k over a prefix of the shard: a lower bound of the k-th key over the
 // whole shard, so the main pass may discard everything below it.
 __global__ void topk_seed_threshold_kernel(const u64* __restrict__ out, int nq, int k, u64* __restrict__ thr) {
@@ -597,12 +919,16 @@ static bool dense_use_mfma2(int dim) {
   static const bool off = getenv("VRAG_TOPK_MFMA1") != nullptr;   // tuning: force the first-generation kernel
   return !off && (dim == 384 || dim == 768 || dim == 1024);
 }
+static bool dense_use_exact(int dtype, int dim, int k) {
+  static const bool off = getenv("VRAG_TOPK_NO_EXACT") != nullptr;   // tuning: fp32 rows on the scalar kernels
+  return !off && dtype == 1 && dim % 32 == 0 && dim <= 768 && k <= XKL;
+}
 static bool dense_use_mfma(int dtype, int dim, int nq, int k) {
   return dtype == 0 && dim % 128 == 0 && nq >= 3 && k <= MKMAX &&
          (size_t)MQ * dim * 2 + MSLOTS * 16384 + (size_t)256 * k * 8 <= 160 * 1024;
 }
 static int dense_n_wg(int dtype, int dim, int nq, int k, long long size) {
-  if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
+  if (dense_use_exact(dtype, dim, k) || (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim))) {
     const Mfma2Plan pl = dense_mfma2_plan(size);
     return std::max(1, pl.n_wg0 + pl.n_wg1);
   }
@@ -616,6 +942,57 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
                                    int split = 0) {
   const int qpp = split ? MQ / 2 : MQ;
   if (bound && dense_use_mfma(dtype, dim, nq, k)) return hipErrorInvalidValue;   // pages run with k = KMAX: scalar path only
+  if (!bound && dense_use_exact(dtype, dim, k)) {
+    hipError_t me = hipMemsetAsync(thr, 0, (size_t)nq * sizeof(u64), st);
+    if (me != hipSuccess) return me;
+    const int qbytes = ((XQ * (dim * 4 + 16) + 1023) / 1024) * 1024;
+    const bool deep = qbytes + 6 * 16384 <= 160 * 1024;               // dim <= 384: six ring slots, else three
+    const size_t ldsx = (size_t)qbytes + (deep ? 6 : 3) * 16384;
+    static bool attrx = false;
+    if (!attrx) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_exact_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_exact_kernel<6>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attrx = true;
+    }
+    const float* r32 = reinterpret_cast<const float*>(rows);
+    static const bool no_regq = getenv("VRAG_TOPK_EXACT_LDSQ") != nullptr;   // tuning: force the queries-in-LDS form
+    const bool regq = !no_regq && (dim == 768 || dim == 384);
+    const size_t lds2 = (size_t)4 * X2SLOTS * 4096 + (size_t)256 * k * 8;
+    if (regq) {
+      static bool attrx2 = false;
+      if (!attrx2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_exact2_kernel<24>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_topk_exact2_kernel<12>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attrx2 = true;
+      }
+    }
+    auto pass = [&](long long lo, long long hi, int per, int wgs, u64* cand_base) -> hipError_t {
+      for (int q0 = 0; q0 < nq; q0 += XQ) {
+        if (regq && dim == 768) hipLaunchKernelGGL(dense_topk_exact2_kernel<24>, dim3(wgs), dim3(256), lds2, st, r32, lo, hi, dq, nq, q0, k, cand_base, per, thr);
+        else if (regq) hipLaunchKernelGGL(dense_topk_exact2_kernel<12>, dim3(wgs), dim3(256), lds2, st, r32, lo, hi, dq, nq, q0, k, cand_base, per, thr);
+        else if (deep) hipLaunchKernelGGL(dense_topk_exact_kernel<6>, dim3(wgs), dim3(256), ldsx, st, r32, lo, hi, dim, dq, nq, q0, k, cand_base, per, thr);
+        else hipLaunchKernelGGL(dense_topk_exact_kernel<3>, dim3(wgs), dim3(256), ldsx, st, r32, lo, hi, dim, dq, nq, q0, k, cand_base, per, thr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    };
+    const Mfma2Plan pl = dense_mfma2_plan(n);
+    if (pl.prefix > 0) {   // seeding pass: exact top-k of the first rows -> per-query entry threshold for the main pass
+      hipError_t e = pass(0, pl.prefix, 128, pl.n_wg0, cand);
+      if (e == hipSuccess) e = launch_topk_merge(cand, pl.n_wg0, nq, k, out, st);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(topk_seed_threshold_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, out, nq, k, thr);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return pass(pl.prefix, n, pl.per1, pl.n_wg1, cand + (size_t)pl.n_wg0 * nq * k);
+  }
   if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
     static const int dbg_fill = getenv("VRAG_TOPK_DEBUG_NOINSERT") ? 0xff : 0;   // probe: reject every key
     hipError_t me = hipMemsetAsync(thr, dbg_fill, (size_t)nq * sizeof(u64), st);

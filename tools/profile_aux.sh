@@ -7,9 +7,11 @@ OUT=$REPO/gpurun_out/${TAG}_aux
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/kt_topk" -- python $REPO/tools/bench_topk.py 2>/dev/null | grep '^{' > "$OUT/topk_lines.json"
-rocprofv3 --kernel-trace --stats -d "$OUT/kt_embed" -- python $REPO/tools/bench_embed.py --check 0 2>/dev/null | grep '^{' > "$OUT/embed_lines.json"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_embed" -- python $REPO/tools/bench_embed.py 2>/dev/null | grep '^{' > "$OUT/embed_lines.json"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt_f32" -- python $REPO/tools/bench_dense_f32.py 2>/dev/null | grep '^{' > "$OUT/dense_f32_lines.json"
 cd "$REPO"
 python tools/rocpd_summary.py "$(find $OUT/kt_topk -name '*.db' | head -1)" > "$OUT/topk_kernel_stats.txt" 2>&1
 python tools/rocpd_summary.py "$(find $OUT/kt_embed -name '*.db' | head -1)" > "$OUT/embed_kernel_stats.txt" 2>&1
-rm -rf "$OUT/kt_topk" "$OUT/kt_embed"
+python tools/rocpd_summary.py "$(find $OUT/kt_f32 -name '*.db' | head -1)" > "$OUT/dense_f32_kernel_stats.txt" 2>&1
+rm -rf "$OUT/kt_topk" "$OUT/kt_embed" "$OUT/kt_f32"
 head -12 "$OUT/topk_kernel_stats.txt" | cut -c1-180; head -12 "$OUT/embed_kernel_stats.txt" | cut -c1-180

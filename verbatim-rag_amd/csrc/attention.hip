@@ -129,14 +129,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[u][t][r] = 0.f;
+    // Banded layers: a 32-key half of the tile is, for a 32-row sub-tile, either completely outside the band (no row sees any
+    // of its keys: skip its MFMAs and its softmax), completely inside (no mask) or triangular.  Of the six halves a sub-tile
+    // meets in its three tiles one is outside, three inside, two triangular (window 64, 32-aligned rows).
+    bool skip[2][2] = {{false, false}, {false, false}}, tri[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int q_lo = qw0 + u * 32, kh = kb * 64 + t * 32;
+        tri[u][t] = kh + 31 >= S;
+        if constexpr (LOCAL) {
+          skip[u][t] = (kh + 31 < q_lo - W) || (kh > q_lo + 31 + W) || kh >= S;
+          tri[u][t] = tri[u][t] || (kh < q_lo + 31 - W) || (kh + 31 > q_lo + W);
+        }
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (skip[0][t] && skip[1][t]) continue;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const V8 kf = *reinterpret_cast<const V8*>(sK + (t * 32 + l31) * 128 + (((2 * s + hi) ^ fsw) << 4));
-        st[0][t] = Op<T>::mfma32(kf, qf[0][s], st[0][t]);
-        st[1][t] = Op<T>::mfma32(kf, qf[1][s], st[1][t]);
+        if (!skip[0][t]) st[0][t] = Op<T>::mfma32(kf, qf[0][s], st[0][t]);
+        if (!skip[1][t]) st[1][t] = Op<T>::mfma32(kf, qf[1][s], st[1][t]);
       }
+    }
 
     // ---- mask + online softmax (scores arrive in log2 units: q was pre-scaled by d^-1/2 * log2 e),
     //      P -> bf16 B-operand fragments.  Interior tiles (every key valid and inside every row's
@@ -145,49 +162,49 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int q_lo = qw0 + u * 32;
-      bool need_mask = kb * 64 + 63 >= S;
-      if constexpr (LOCAL) need_mask = need_mask || (kb * 64 < q_lo + 31 - W) || (kb * 64 + 63 > q_lo + W);
       float mx = -1e30f;
-      if (need_mask) {  // wave-uniform
-        // visible keys of row qi form one interval [lo, hi_]: key(r) = kbase + c_r is visible iff
-        // (unsigned)(kbase + c_r - lo) <= hi_ - lo  -> one add + one unsigned compare per element
-        int kbase = kb * 64 + 4 * hi;
-        asm volatile("" : "+v"(kbase));  // keep the predicate arithmetic inside this (rare) branch
-        const int qi = q_lo + l31;
-        int lo = 0, hi_ = S - 1;
-        if constexpr (LOCAL) {
-          lo = max(0, qi - W);
-          hi_ = min(S - 1, qi + W);
-        }
-        const unsigned span = hi_ >= lo ? (unsigned)(hi_ - lo) : 0u;
-        const int d0 = hi_ >= lo ? kbase - lo : -100000;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        if (skip[u][t]) continue;   // wave-uniform
+        if (tri[u][t]) {
+          // visible keys of row qi form one interval [lo, hi_]: key(r) = kbase + c_r is visible iff
+          // (unsigned)(kbase + c_r - lo) <= hi_ - lo  -> one add + one unsigned compare per element
+          int kbase = kb * 64 + t * 32 + 4 * hi;
+          asm volatile("" : "+v"(kbase));  // keep the predicate arithmetic inside this branch
+          const int qi = q_lo + l31;
+          int lo = 0, hi_ = S - 1;
+          if constexpr (LOCAL) {
+            lo = max(0, qi - W);
+            hi_ = min(S - 1, qi + W);
+          }
+          const unsigned span = hi_ >= lo ? (unsigned)(hi_ - lo) : 0u;
+          const int d0 = hi_ >= lo ? kbase - lo : -100000;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const bool ok = (unsigned)(d0 + (t * 32 + (r & 3) + 8 * (r >> 2))) <= span;
+            const bool ok = (unsigned)(d0 + ((r & 3) + 8 * (r >> 2))) <= span;
             const float x = ok ? st[u][t][r] : -INFINITY;
             st[u][t][r] = x;
             mx = fmaxf(mx, x);
           }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+        } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][t][r]);
+        }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[u], mx);
       const bool grew = !__all(m_new == m_run[u]);  // wave-uniform
       float psum = 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        if (skip[u][t]) continue;   // its P.V MFMAs are skipped as well
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(st[u][t][r] - m_new);
           psum += pv;
           pf[u][t][r >> 3][r & 7] = (T)pv;   // p in [0, 1]: no saturation needed
         }
+      }
       if (grew) {
         const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
         m_run[u] = m_new;
@@ -203,7 +220,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
 
     // ---- O^T += V^T . P^T (V^T fragments read once for both sub-tiles)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (skip[0][t] && skip[1][t]) continue;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int c16 = 4 * t + 2 * hf;  // 16-byte chunk of keys t*32 + hf*16 .. ; +1 = the next 8 keys
@@ -218,10 +236,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
             vf[j] = a0[j];
             vf[4 + j] = a1[j];
           }
-          ot[0][n] = Op<T>::mfma32(vf, pf[0][t][hf], ot[0][n]);
-          ot[1][n] = Op<T>::mfma32(vf, pf[1][t][hf], ot[1][n]);
+          if (!skip[0][t]) ot[0][n] = Op<T>::mfma32(vf, pf[0][t][hf], ot[0][n]);
+          if (!skip[1][t]) ot[1][n] = Op<T>::mfma32(vf, pf[1][t][hf], ot[1][n]);
         }
       }
+    }
   }
 
   // ---- normalise and store O[q][head*64 + d].  A lane holds 4 consecutive dims of ITS row per register group, i.e.

@@ -124,7 +124,7 @@ def main():
     for q in questions[:100]:
         pipe.query(q)
     t_single = (time.perf_counter() - t0) / 100
-    print(json.dumps({"workload": f"GpuVectorStore {n} chunks (dense {args.dim} bf16 + sparse vocab {V}), hybrid top-{args.k}, "
+    print(json.dumps({"workload": f"GpuVectorStore {n} chunks (dense {args.dim} {store.dense_dtype} + sparse vocab {V}), hybrid top-{args.k}, "
                                   f"ModernBERT-base extraction, {args.queries} queries via StaticVerbatimPipeline.query_batch",
                       "ingest_s": t_ingest, "flush_and_first_query_s": t_flush, **out, "single_query_ms": t_single * 1e3}))
     for e in engs:

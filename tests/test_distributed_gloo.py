@@ -124,7 +124,28 @@ def _store_worker(rank, world, port, q):
         with cpu_stand_ins():
             sharded = build_and_query(comm=ShardComm(merge=merge_topk))
             single = build_and_query(comm=None)
-        q.put((rank, sharded == single or "sharded store answers differ from the single-rank store"))
+            ok = sharded == single or "sharded store answers differ from the single-rank store"
+            # persistence: every rank writes its vector file, rank 0 the row table; a reload with the same world size answers alike
+            import tempfile
+
+            from verbatim_rag_amd import vector_stores as vs
+
+            box = [tempfile.mkdtemp(prefix="vrag_shard_")] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=0)
+            rng = np.random.default_rng(3)
+            dense = np.where(rng.random((37, 64)) < 0.5, 0.5, -0.5).astype(np.float32)
+            st = vs.GpuVectorStore(dense_dim=64, enable_sparse=False, sparse_vocab=None, comm=ShardComm(merge=merge_topk))
+            st.add_vectors([f"r{i}" for i in range(37)], dense.tolist(), None, [f"t{i}" for i in range(37)], [""] * 37,
+                           [{"n": i} for i in range(37)])
+            st.delete(["r5"])
+            before = [(r.id, r.score) for r in st.query(dense_query=dense[9].tolist(), top_k=6, search_type="dense")]
+            st.save(box[0])
+            dist.barrier()
+            st2 = vs.GpuVectorStore.load(box[0], comm=ShardComm(merge=merge_topk))
+            after = [(r.id, r.score) for r in st2.query(dense_query=dense[9].tolist(), top_k=6, search_type="dense")]
+            if before != after or before[0][0] != "r9" or len(st2._ids) != 36 or len(st2._owned) not in (18, 19):
+                ok = f"save / load changed the answers: {before} vs {after}"
+        q.put((rank, ok))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:

@@ -29,6 +29,9 @@ template <> struct Op<bf16_t> {
   static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x4 mfma16(const v8& a, const v8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
 };
 template <> struct Op<f16_t> {
   typedef f16x4 v4;
@@ -36,6 +39,9 @@ template <> struct Op<f16_t> {
   static __device__ __forceinline__ f16_t to(float v) { return (f16_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
   static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(const v8& a, const v8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
 };
 

@@ -392,11 +392,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // three phases to land before its first read (never a vmcnt(0) in the loop) and is re-staged four or more phases after its
 // last read.
 template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64, typename T = bf16_t, int SCHED = 0>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
-  static_assert(SCHED == 0 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BKT == 64 && DBG == 0),
+__global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 : 2) void gemm_bf16_kernel(const GemmParams p) {
+  static_assert(SCHED != 1 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BKT == 64 && DBG == 0),
                 "the 8-phase schedule is written for the 256 x 256 x 64 tile");
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
-  static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
+  constexpr int WC = BN / WN;                 // output features per wave: 64 (one head / one GeGLU group) or 128 (two)
+  constexpr int NI = WC / 32;                 // 32-column accumulator tiles per wave
+  static_assert(WC == 64 || WC == 128, "a wave spans one or two 64-feature groups");
   static_assert(NS >= 2 && NS <= 4, "LDS stages");
   static_assert(BKT == 64 || BKT == 32, "K-step");
   constexpr int ROWB = BKT * 2;               // bytes per LDS row
@@ -464,15 +466,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
     for (int i = 0; i < W_INSTR; ++i) glds16(Wb + soffW[i] + k0, sW + (wave * (RPI * W_INSTR) + i * RPI) * ROWB);
   };
 
-  f32x16 acc[2][MI];
+  f32x16 acc[NI][MI];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
     for (int c = 0; c < MI; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-  const int nw = n0 + wn * 64;      // first feature of this wave's 64-wide range
+  f32x4 acc4[SCHED >= 3 ? NI * MI * 4 : 1];   // SCHED 3 (16 x 16 x 32 probe): the same 256 accumulator registers as 4-register tiles
+#pragma unroll
+  for (int i = 0; i < (SCHED >= 3 ? NI * MI * 4 : 1); ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nw = n0 + wn * WC;      // first feature of this wave's range
   const int mw = m0 + wm * WROWS;   // first token row of this wave
   const int KT = K / BKT;
   // The V third of the QKV product is computed un-swapped (activations as the A operand): then a
@@ -482,10 +487,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
 
   auto mainloop = [&](auto swapped_tag) {
     constexpr bool SWAPPED = decltype(swapped_tag)::value;
-    constexpr int NI = A_INSTR + W_INSTR;   // LDS-DMA instructions per wave per stage
+    constexpr int NDMA = A_INSTR + W_INSTR;   // LDS-DMA instructions per wave per stage
     auto wait_allow = [&](int stages_in_flight) {   // this wave's DMA is retired except the newest `stages_in_flight` stages
-      if (NS > 2 && stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-      else if (NS > 2 && stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      if (NS > 2 && stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+      else if (NS > 2 && stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto step_barrier = [&]() {
@@ -501,10 +506,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       if (i < KT) stage(i, i);
     wait_allow(min(NS - 1, KT) - 1);
     step_barrier();
-    V8 dbg_f[MI + 2] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
+    V8 dbg_f[MI + NI] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
     if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
-      for (int i = 0; i < MI + 2; ++i) {
+      for (int i = 0; i < MI + NI; ++i) {
         unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)(i * 40503u);
         unsigned w4[4];
 #pragma unroll
@@ -526,21 +531,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       if (do_stage && wave < (WM * WN) / 2) stage(nxt, nbuf);   // first half of the waves: right after the barrier
 #endif
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
-      const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
+      const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * WC) * ROWB;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #if VRAG_DMA_SPLIT == 1
         if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(nxt, nbuf);   // second half: one substep later
 #endif
-        V8 af[MI] = {}, wf[2] = {};
+        V8 af[MI] = {}, wf[NI] = {};
         if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
           for (int i = 0; i < MI; ++i) af[i] = dbg_f[i];
-          wf[0] = dbg_f[MI];
-          wf[1] = dbg_f[MI + 1];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) wf[i] = dbg_f[MI + i];
         } else if (DBG && (p.debug_flags & 4)) {   // probe: fresh pseudo-random register operands per MFMA group, no LDS read
 #pragma unroll
-          for (int i = 0; i < MI + 2; ++i) {
+          for (int i = 0; i < MI + NI; ++i) {
             unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)((i * KS + s + kt * 16) * 40503u);
             unsigned w4[4];
 #pragma unroll
@@ -556,15 +561,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
         }
         if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[s]);
+          for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[s]);
 #pragma unroll
           for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(sA + i * 32 * ROWB + fo[s]);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            if constexpr (SWAPPED)
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (SCHED == 4) {   // 16 x 16 x 32 probe in the 8-wave loop (garbage results by design, see SCHED 3)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                f32x4& sub = acc4[(ni * MI + mi) * 4 + 2 * (s & 1) + h];
+                const V8 wv = wf[ni], av = af[mi];
+                if constexpr (std::is_same<T, bf16_t>::value) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
+                else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
+              }
+            } else if constexpr (SWAPPED)
               acc[ni][mi] = Op<T>::mfma32(wf[ni], af[mi], acc[ni][mi]);
             else
               acc[ni][mi] = Op<T>::mfma32(af[mi], wf[ni], acc[ni][mi]);
@@ -670,7 +683,157 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  if constexpr (SCHED == 1) {
+  // ------------------------------------------------------------------ one wave per SIMD (SCHED == 2)
+  // 4 waves x (128 x 128) outputs: the 256 accumulators live in the AGPR half of a 512-register budget and there is no second
+  // wave on the SIMD to cover latencies, so the loop is software-pipelined by hand: the fragments of k-substep s+1 are read
+  // while the 16 MFMAs of substep s run (two register sets), and the K-step barrier sits BEFORE the last substep's MFMAs --
+  // the next stage's first fragments and the DMA of the stage after it are issued under them.
+  auto mainloop4 = [&](auto swapped_tag) {
+    constexpr bool SWAPPED = decltype(swapped_tag)::value;
+    static_assert((SCHED != 2 && SCHED != 3) || (NS == 2 && (KS % 2) == 0), "two stages, even number of k-substeps");
+    constexpr int NDMA = A_INSTR + W_INSTR;
+    V8 fa[2][MI], fw[2][NI];
+    auto read_frags = [&](auto set_tag, int slot, auto s_tag) {
+      constexpr int SET = decltype(set_tag)::value, S = decltype(s_tag)::value;
+      const char* sA = smem + slot * STAGE_BYTES + (wm * WROWS) * ROWB;
+      const char* sW = smem + slot * STAGE_BYTES + A_BYTES + (wn * WC) * ROWB;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fw[SET][i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[S]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[SET][i] = *reinterpret_cast<const V8*>(sA + i * 32 * ROWB + fo[S]);
+    };
+    auto mfmas = [&](auto set_tag) {
+      constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (SWAPPED) acc[ni][mi] = Op<T>::mfma32(fw[SET][ni], fa[SET][mi], acc[ni][mi]);
+          else acc[ni][mi] = Op<T>::mfma32(fa[SET][mi], fw[SET][ni], acc[ni][mi]);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    stage(0, 0);
+    if (KT > 1) {
+      stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(I0{}, 0, I0{});
+    auto interleave = [&]() {   // issue order of a substep: (MFMA, fragment read) x 8, then the other 8 MFMAs
+#pragma unroll
+      for (int i = 0; i < MI + NI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - MI - NI, 0);
+    };
+    // one K-step; NEXT: stage kt+1 exists, NEXT2: stage kt+2 exists (compile-time, so every K-step is one basic block)
+    auto kstep = [&](int kt, auto next_tag, auto next2_tag) {
+      constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value;
+      const int slot = kt & 1;
+      read_frags(I1{}, slot, I1{});
+      mfmas(I0{});
+      interleave();
+      if constexpr (KS == 4) {
+        read_frags(I0{}, slot, std::integral_constant<int, 2>{});
+        mfmas(I1{});
+        interleave();
+        read_frags(I1{}, slot, std::integral_constant<int, 3>{});
+        mfmas(I0{});
+        interleave();
+      }
+      // last substep: barrier first, then the next stage's first fragments / the DMA after next under its MFMAs
+      if constexpr (NEXT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of stage kt+1 landed; my reads of `slot` are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (NEXT2) stage(kt + 2, slot);
+        read_frags(I0{}, slot ^ 1, I0{});
+      }
+      mfmas(I1{});
+      if constexpr (NEXT) {
+#pragma unroll
+        for (int i = 0; i < MI + NI; ++i) {   // (MFMA, fragment read, two DMA instructions) x 8, then the other 8 MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if constexpr (NEXT2) __builtin_amdgcn_sched_group_barrier(0x010, NDMA / (MI + NI), 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - MI - NI, 0);
+      }
+    };
+    // SCHED 3: the same K-step with the MFMAs as volatile asm in explicit program order -- after every second MFMA of a
+    // substep's first 16 one fragment read of the next substep, and under the last substep two DMA instructions as well
+    auto read_one = [&](auto set_tag, int slot, auto s_tag, int i) {
+      constexpr int SET = decltype(set_tag)::value, S = decltype(s_tag)::value;
+      const char* sA = smem + slot * STAGE_BYTES + (wm * WROWS) * ROWB;
+      const char* sW = smem + slot * STAGE_BYTES + A_BYTES + (wn * WC) * ROWB;
+      if (i < NI) fw[SET][i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[S]);
+      else fa[SET][i - NI] = *reinterpret_cast<const V8*>(sA + (i - NI) * 32 * ROWB + fo[S]);
+    };
+    auto stage_one = [&](int kt, int buf, int j) {
+      char* sA = smem + buf * STAGE_BYTES;
+      char* sW = sA + A_BYTES;
+      const int k0 = kt * BKT;
+      if (j < A_INSTR) glds16(Ab + soffA[j] + k0, sA + (wave * (RPI * A_INSTR) + j * RPI) * ROWB);
+      else glds16(Wb + soffW[j - A_INSTR] + k0, sW + (wave * (RPI * W_INSTR) + (j - A_INSTR) * RPI) * ROWB);
+    };
+    auto substep16 = [&](auto set_tag, auto between) {
+      constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+      for (int idx = 0; idx < MI * NI * 2; ++idx) {
+        const int pr = idx >> 1, mi = pr / NI, ni = pr % NI, h = idx & 1;
+        f32x4& sub = acc4[(ni * MI + mi) * 4 + 2 * SET + h];
+        const V8 wv = fw[SET][ni], av = fa[SET][mi];
+        if constexpr (std::is_same<T, bf16_t>::value)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
+        else
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
+        if (h == 1 && pr < MI + NI) between(pr);
+      }
+    };
+    auto kstep16 = [&](int kt, auto next_tag, auto next2_tag) {
+      constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value;
+      typedef std::integral_constant<int, 2> I2;
+      typedef std::integral_constant<int, 3> I3;
+      const int slot = kt & 1;
+      substep16(I0{}, [&](int i) { read_one(I1{}, slot, I1{}, i); });
+      substep16(I1{}, [&](int i) { read_one(I0{}, slot, I2{}, i); });
+      substep16(I0{}, [&](int i) { read_one(I1{}, slot, I3{}, i); });
+      if constexpr (NEXT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      substep16(I1{}, [&](int i) {
+        if constexpr (NEXT) {
+          read_one(I0{}, slot ^ 1, I0{}, i);
+          if constexpr (NEXT2) {
+            stage_one(kt + 2, slot, 2 * i);
+            stage_one(kt + 2, slot, 2 * i + 1);
+          }
+        }
+      });
+    };
+    if constexpr (SCHED == 3) {
+      for (int kt = 0; kt < KT - 2; ++kt) kstep16(kt, std::true_type{}, std::true_type{});
+      if (KT >= 2) kstep16(KT - 2, std::true_type{}, std::false_type{});
+      kstep16(KT - 1, std::false_type{}, std::false_type{});
+    } else {
+      for (int kt = 0; kt < KT - 2; ++kt) kstep(kt, std::true_type{}, std::true_type{});
+      if (KT >= 2) kstep(KT - 2, std::true_type{}, std::false_type{});
+      kstep(KT - 1, std::false_type{}, std::false_type{});
+    }
+    __syncthreads();   // the epilogue reuses the ring as staging
+  };
+  if constexpr (SCHED == 2 || SCHED == 3) {
+    if (v_block) mainloop4(std::false_type{});
+    else mainloop4(std::true_type{});
+  } else if constexpr (SCHED == 1) {
     if (v_block) mainloop8(std::false_type{});
     else mainloop8(std::true_type{});
   } else {
@@ -678,7 +841,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
     else mainloop(std::true_type{});
   }
 
-  gemm_epilogue<EPI, MI, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block);
+  if constexpr (SCHED >= 3) {
+#pragma unroll
+    for (int i = 0; i < NI * MI * 4; ++i) asm volatile("" ::"a"(acc4[i]));
+  }
+#pragma unroll
+  for (int j = 0; j < NI / 2; ++j)   // one 64-feature group at a time
+    gemm_epilogue<EPI, MI, WROWS, T>(p, *reinterpret_cast<f32x16(*)[2][MI]>(&acc[2 * j]), smem, wave, lane, mw, nw + 64 * j, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
   }  // tile loop
 }
@@ -687,6 +856,24 @@ int gemm_small_m_threshold(int set_to) {
   static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 8192};
   if (set_to >= 0) thr.store(set_to);
   return thr.load();
+}
+
+// One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
+template <int EPI, int BM, int BN, int WM, int WN, int NS, int BKT, typename T, int SCHED = 0>
+static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
+  constexpr int SMEM = NS * (BM + BN) * BKT * 2;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, 0, NS, BKT, T, SCHED>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  p.n_tiles = nbm * nbn;
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, 0, NS, BKT, T, SCHED>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
+                     stream, p);
+  return hipGetLastError();
 }
 
 template <int EPI, typename T>
@@ -727,6 +914,17 @@ hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
       static const int pgrid2 = getenv("VRAG_GEMM_PGRID2") ? atoi(getenv("VRAG_GEMM_PGRID2")) : 512;   // 2 workgroups per CU
       hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32, T>), dim3(std::min(nbm * nbn, pgrid2)), dim3(256), SMEM, stream, p);
       return hipGetLastError();
+    }
+  }
+  // 4 waves, 128 x 128 outputs per wave, one wave per SIMD (512 registers): a third fewer LDS fragment reads per MFMA
+  // than the 8-wave layout.  1: the plain two-stage loop, 2: the hand-pipelined one (SCHED = 2).
+  static const int w4 = getenv("VRAG_GEMM_W4") ? atoi(getenv("VRAG_GEMM_W4")) : 0;
+  if constexpr (EPI == EPI_NONE) {   // main-loop diagnostic only: with 4 waves the fused epilogues are slower (r2n: qkv 446 vs 276 us)
+    if (w4 && p.N % 256 == 0 && p.M >= 256) {
+      static const int pgrid4 = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;
+      if (w4 == 3) return launch_cfg<EPI, 256, 256, 2, 2, 2, 64, T, 3>(p, pgrid4, stream);
+      if (w4 == 4) return launch_cfg<EPI, 256, 256, 2, 4, 2, 64, T, 4>(p, pgrid4, stream);
+      return w4 == 2 ? launch_cfg<EPI, 256, 256, 2, 2, 2, 64, T, 2>(p, pgrid4, stream) : launch_cfg<EPI, 256, 256, 2, 2, 2, 64, T>(p, pgrid4, stream);
     }
   }
   static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU

@@ -1,26 +1,31 @@
-// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T, fp32 accumulate, fused epilogues.
+// 16-bit MFMA GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T, fp32 accumulate, fused epilogues.
 //
 // Replaces the nn.Linear calls of the reference's ModernBERT forward
 // (transformers modeling_modernbert.py: Wqkv :271, attn Wo :300, mlp Wi :90, mlp Wo :91,
 //  prediction-head dense :487, MLM decoder :550, token classifier :697).
 //
-// Two tile configurations of one template (v_mfma_f32_32x32x16_bf16, BK = 64):
-//   256(M) x 256(N): 512 threads = 8 waves as 2(M) x 4(N), 128x64 per wave (128 accumulator VGPRs),
+// Two tile configurations of one template (v_mfma_f32_16x16x32_{bf16,f16}, BK = 64):
+//   256(M) x 256(N): 512 threads = 8 waves as 2(M) x 4(N), 128x64 per wave (128 accumulator registers),
 //                    128 KiB LDS (2 stages x (32 KiB A + 32 KiB W)), 1 workgroup / CU  -- used when N % 256 == 0
 //   128(M) x 128(N): 256 threads = 4 waves as 2x2, 64x64 per wave, 64 KiB LDS, 2 workgroups / CU
 // The larger tile halves the L2->LDS operand traffic per FLOP (M*N*K*2*(1/BM+1/BN) bytes), which is
 // the co-limiter of the small tile at these K (768/1152).  Operands go HBM -> LDS by 16-byte LDS-DMA (global_load_lds),
-// double buffered.  LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with
+// double buffered.  LDS rows are 128 B (64 k-values); the 16-byte chunk index is XOR-swizzled with
 // ((row>>1)&7) on the *source address* (LDS-DMA writes lane-linear) and on the ds_read_b128
-// address, which makes each 16-lane read group hit 16 distinct 16-byte slots of the 256-byte
-// bank row (conflict free).
+// address, which makes each 16-lane read group of a 16-row x 32-k fragment hit the 64 banks exactly once.
+//
+// Why the 16x16x32 instruction and not 32x32x16 (same FLOP/s on paper, and the 32x32 shape reads each operand fragment
+// half as often): the step is power-limited, and the wider-K shape reads and writes each fp32
+// accumulator once per 32 k instead of once per 16 -- measured on the main loop alone, same operands, fragments and
+// accumulator count: 196 vs 217 us at M = 65536 / N = 2304 / K = 768, 67 vs 75 us at N = 768, 101 vs 112 us at
+// N = 768 / K = 1152 (profiles/r02_mfma_shape_probe.txt).
 //
 // The MFMA is issued "swapped" (weights as the A operand, activations as B) so that a lane's
 // accumulator registers hold 4 *consecutive output features* of ONE token row:
-//   token  m = m0 + wm*64 + mi*32 + (lane&31)
-//   feature n = n0 + wn*64 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
-// -> 8-byte bf16 / 16-byte fp32 row-major stores, and RoPE's (d, d+32) / GeGLU's (x1, x2)
-// partners sit in the same lane and register index of acc[0][mi] / acc[1][mi].
+//   token   m = m0 + wm*WROWS + rt*16 + (lane&15)            rt = 16-row tile of the wave
+//   feature n = n0 + wn*64 + nj*16 + 4*(lane>>4) + r         nj = 16-column tile, r = register 0..3
+// -> 8-byte 16-bit / 16-byte fp32 row-major stores, and RoPE's (d, d+32) / GeGLU's (x1, x2)
+// partners sit in the same lane and register of acc[nj][rt] / acc[nj+2][rt].
 #include "gemm_bf16.h"
 
 #include <atomic>
@@ -36,26 +41,26 @@
 
 namespace vrag {
 
-constexpr int BK = 64;   // K-step of the throughput configurations; the kernel template takes BKT = 64 or 32
+constexpr int BK = 64;   // K-step: one LDS stage holds 64 k-values of every tile row
 
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
 
-// Epilogue shared by the GEMM kernels. `acc[ni][mi]` are this wave's accumulators (swapped layout:
+// Epilogue shared by the GEMM kernels. `acc[nj][rt]` are this wave's accumulators (swapped layout:
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
-template <int EPI, int MI, int WROWS, typename T>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][MI], char* smem, int wave, int lane,
+template <int EPI, int RT, int WROWS, typename T>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* smem, int wave, int lane,
                                               int mw, int nw, bool v_block) {
   typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
-  const int hi = lane >> 5, l31 = lane & 31;
+  const int q = lane >> 4, l15 = lane & 15;
   // ------------------------------------------------------------------ epilogues
   // All operand-tile reads are done (the loop ends with a barrier), so the LDS is reused as a
   // per-wave 16 KiB staging area: accumulators are written in their natural (row-per-lane)
   // layout with an XOR-swizzled 16-byte chunk index and read back row-contiguous, so every
   // global store/RMW instruction covers whole 128/256-byte row segments (full cache lines)
-  // instead of 32 scattered 16-byte pieces.
+  // instead of 16 scattered 16-byte pieces.
   char* stg = smem + wave * 16384;
 
-  // bf16 tile [R rows][C cols] (C = 64 or 32): lane writes 4 consecutive columns of its row.
+  // 16-bit tile [R rows][C cols] (C = 64 or 32): lane writes 4 consecutive columns of its row.
   auto put_bf16 = [&](int row, int col, const V4& v, int row_bytes) {
     const int c16 = col >> 3, half = (col >> 2) & 1;
     const int sw16 = row_bytes == 128 ? (row & 7) : (row_bytes == 64 ? (row & 3) : (row & 15));
@@ -69,19 +74,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 
   if constexpr (EPI == EPI_NONE) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[ni][mi][r]));
+      for (int rt = 0; rt < RT; ++rt) asm volatile("" ::"v"(acc[nj][rt]));
   } else if constexpr (EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_RESIDUAL) {
-    // fp32 [64 rows][64 cols] per pass (256-byte rows, 16 chunks), MI/2 passes; a pass is read back in two halves of
+    // fp32 [64 rows][64 cols] per pass (256-byte rows, 16 chunks), RT/4 passes; a pass is read back in two halves of
     // 32 rows (8 row-segment instructions each).  Residual: the h rows of a half are prefetched one half ahead
     // (two 8 x 16-byte register sets, 8 KiB per wave in flight), so the fp32 read-modify-write is one HBM round trip
     // per pass that runs under the previous half's LDS reads and stores.
     constexpr int HALF = 8;
     f32x4 hA[HALF], hB[HALF];
-    float cw[MI / 2];   // residual + LayerNorm fold: lane L holds the shift of row ps*64 + L (fetched by bpermute below)
+    float cw[RT / 4];   // residual + LayerNorm fold: lane L holds the shift of row ps*64 + L (fetched by bpermute below)
     auto h_ptr = [&](int hp, int i) {   // half-pass hp = 2*ps + half, instruction i: 4 rows x 16 lanes
       const int row = (hp >> 1) * 64 + (hp & 1) * 32 + i * 4 + (lane >> 4);
       return p.out_f32 + (size_t)(mw + row) * p.N + nw + (lane & 15) * 4;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     if constexpr (EPI == EPI_RESIDUAL) {
       prefetch(hA, 0);
 #pragma unroll
-      for (int ps = 0; ps < MI / 2; ++ps) cw[ps] = p.ln_shift ? p.ln_shift[mw + ps * 64 + lane] : 0.f;
+      for (int ps = 0; ps < RT / 4; ++ps) cw[ps] = p.ln_shift ? p.ln_shift[mw + ps * 64 + lane] : 0.f;
     }
     auto finish_half = [&](const f32x4 (&hv)[HALF], int hp) {
       const int ps = hp >> 1;
@@ -155,62 +158,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       }
     };
 #pragma unroll
-    for (int ps = 0; ps < MI / 2; ++ps) {
+    for (int ps = 0; ps < RT / 4; ++ps) {
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        const int mi = ps * 2 + mh;
-        const int row = mh * 32 + l31;
+      for (int rq = 0; rq < 4; ++rq) {
+        const int row = rq * 16 + l15;   // row inside the pass
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int nj = 0; nj < 4; ++nj) {
+          f32x4 v = acc[nj][ps * 4 + rq];
+          if constexpr (EPI == EPI_F32_GELU) {
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + nj * 16 + 4 * q);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-            if constexpr (EPI == EPI_F32_GELU) {
-              if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + ni * 32 + 8 * g + 4 * hi);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            }
-            const int c16 = ni * 8 + 2 * g + hi;
-            *reinterpret_cast<f32x4*>(stg + row * 256 + ((c16 ^ (row & 15)) << 4)) = v;
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
           }
+          const int c16 = nj * 4 + q;
+          *reinterpret_cast<f32x4*>(stg + row * 256 + ((c16 ^ l15) << 4)) = v;
+        }
       }
       // half 0 of this pass came in under the staging writes; fetch half 1 now, and the next pass's half 0 under half 1
       if constexpr (EPI == EPI_RESIDUAL) prefetch(hB, 2 * ps + 1);
       finish_half(hA, 2 * ps);
       if constexpr (EPI == EPI_RESIDUAL) {
-        if (ps + 1 < MI / 2) prefetch(hA, 2 * ps + 2);
+        if (ps + 1 < RT / 4) prefetch(hA, 2 * ps + 2);
       }
       finish_half(hB, 2 * ps + 1);
     }
   } else if constexpr (EPI == EPI_BF16) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+    for (int rt = 0; rt < RT; ++rt) {
       float mu = 0.f, rs = 1.f;
       if (p.ln_mu) {
-        mu = p.ln_mu[mw + mi * 32 + l31];
-        rs = p.ln_rstd[mw + mi * 32 + l31];
+        mu = p.ln_mu[mw + rt * 16 + l15];
+        rs = p.ln_rstd[mw + rt * 16 + l15];
       }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int nj = 0; nj < 4; ++nj) {
+        const int col = nj * 16 + 4 * q;
+        V4 o;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = ni * 32 + 8 * g + 4 * hi;
-          V4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float v = acc[ni][mi][4 * g + j];
-            if (p.ln_mu) v = rs * (v - mu * p.ln_s[nw + col + j]);
-            if (p.bias) v += p.bias[nw + col + j];
-            if (p.act_gelu) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
-            o[j] = Op<T>::to(v);
-          }
-          put_bf16(mi * 32 + l31, col, o, 128);
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[nj][rt][j];
+          if (p.ln_mu) v = rs * (v - mu * p.ln_s[nw + col + j]);
+          if (p.bias) v += p.bias[nw + col + j];
+          if (p.act_gelu) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
+          o[j] = Op<T>::to(v);
         }
+        put_bf16(rt * 16 + l15, col, o, 128);
+      }
     }
 #pragma unroll
-    for (int it = 0; it < MI * 4; ++it) {
+    for (int it = 0; it < WROWS / 8; ++it) {
       const int row = it * 8 + (lane >> 3), c16 = lane & 7;
       store16_nt(p.out_bf16 + (size_t)(mw + row) * p.N + nw + c16 * 8, get16(row, c16, 128));
     }
@@ -220,31 +216,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     const int NO = p.N >> 1;
     const int f0 = (nw >> 6) * 32;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+    for (int rt = 0; rt < RT; ++rt) {
       float mu = 0.f, rs = 1.f;
       if (p.ln_mu) {
-        mu = p.ln_mu[mw + mi * 32 + l31];
-        rs = p.ln_rstd[mw + mi * 32 + l31];
+        mu = p.ln_mu[mw + rt * 16 + l15];
+        rs = p.ln_rstd[mw + rt * 16 + l15];
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int nj = 0; nj < 2; ++nj) {
+        const int dd = nj * 16 + 4 * q;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         if (p.ln_mu) {
-          s1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 8 * g + 4 * hi);
-          s2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + 8 * g + 4 * hi);
+          s1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + dd);
+          s2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + dd);
         }
         V4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float x1 = rs * (acc[0][mi][4 * g + j] - mu * s1[j]);
-          const float x2 = rs * (acc[1][mi][4 * g + j] - mu * s2[j]);
+          const float x1 = rs * (acc[nj][rt][j] - mu * s1[j]);
+          const float x2 = rs * (acc[nj + 2][rt][j] - mu * s2[j]);
           o[j] = Op<T>::to(gelu_fast(x1) * x2);
         }
-        put_bf16(mi * 32 + l31, 8 * g + 4 * hi, o, 64);
+        put_bf16(rt * 16 + l15, dd, o, 64);
       }
     }
 #pragma unroll
-    for (int it = 0; it < MI * 2; ++it) {
+    for (int it = 0; it < WROWS / 16; ++it) {
       const int row = it * 16 + (lane >> 2), c16 = lane & 3;
       store16_nt(p.out_bf16 + (size_t)(mw + row) * NO + f0 + c16 * 8, get16(row, c16, 64));
     }
@@ -256,18 +253,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       bf16_t* dst = which == 0 ? p.q : p.k;
       const float scale = which == 0 ? p.q_scale : 1.0f;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int pos = p.pos[mw + mi * 32 + l31];
+      for (int rt = 0; rt < RT; ++rt) {
+        const int pos = p.pos[mw + rt * 16 + l15];
         const float* cs = p.rope_cos + (size_t)pos * 32;
         const float* sn = p.rope_sin + (size_t)pos * 32;
         float mu = 0.f, rs = 1.f;
         if (p.ln_mu) {
-          mu = p.ln_mu[mw + mi * 32 + l31];
-          rs = p.ln_rstd[mw + mi * 32 + l31];
+          mu = p.ln_mu[mw + rt * 16 + l15];
+          rs = p.ln_rstd[mw + rt * 16 + l15];
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int dd = 8 * g + 4 * hi;
+        for (int nj = 0; nj < 2; ++nj) {
+          const int dd = nj * 16 + 4 * q;
           const f32x4 c = *reinterpret_cast<const f32x4*>(cs + dd);
           const f32x4 sv = *reinterpret_cast<const f32x4*>(sn + dd);
           f32x4 ls1 = {0.f, 0.f, 0.f, 0.f}, ls2 = {0.f, 0.f, 0.f, 0.f};
@@ -283,43 +280,41 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           V4 o1, o2;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float x1 = rs * (acc[0][mi][4 * g + j] - mu * ls1[j]) + b1[j];
-            const float x2 = rs * (acc[1][mi][4 * g + j] - mu * ls2[j]) + b2[j];
+            const float x1 = rs * (acc[nj][rt][j] - mu * ls1[j]) + b1[j];
+            const float x2 = rs * (acc[nj + 2][rt][j] - mu * ls2[j]) + b2[j];
             // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
             o1[j] = Op<T>::to((x1 * c[j] - x2 * sv[j]) * scale);
             o2[j] = Op<T>::to((x2 * c[j] + x1 * sv[j]) * scale);
           }
-          put_bf16(mi * 32 + l31, dd, o1, 128);
-          put_bf16(mi * 32 + l31, dd + 32, o2, 128);
+          put_bf16(rt * 16 + l15, dd, o1, 128);
+          put_bf16(rt * 16 + l15, dd + 32, o2, 128);
         }
       }
 #pragma unroll
-      for (int it = 0; it < MI * 4; ++it) {
+      for (int it = 0; it < WROWS / 8; ++it) {
         const int row = it * 8 + (lane >> 3), c16 = lane & 7;
         store16_nt(dst + (size_t)(mw + row) * H + head * 64 + c16 * 8, get16(row, c16, 128));
       }
     } else {
-      // un-swapped accumulators: lane = feature d (ni*32 + l31), registers = tokens
-      //   token = mi*32 + 8*(r>>2) + 4*hi + (r&3).   Stage V^T tile [64 d][WROWS tokens].
+      // un-swapped accumulators: lane = feature d (nj*16 + l15), registers = tokens
+      //   token = rt*16 + 4*q + r.   Stage V^T tile [64 d][WROWS tokens].
       constexpr int RB = WROWS * 2;  // row bytes (256 for 128 tokens, 128 for 64)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const float sn_ = p.ln_mu ? p.ln_s[nw + ni * 32 + l31] : 0.f;
-        const float bv_ = p.bias ? p.bias[nw + ni * 32 + l31] : 0.f;
+      for (int nj = 0; nj < 4; ++nj) {
+        const float sn_ = p.ln_mu ? p.ln_s[nw + nj * 16 + l15] : 0.f;
+        const float bv_ = p.bias ? p.bias[nw + nj * 16 + l15] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
-            if (p.ln_mu) {
-              mu4 = *reinterpret_cast<const f32x4*>(p.ln_mu + mw + mi * 32 + 8 * g + 4 * hi);
-              rs4 = *reinterpret_cast<const f32x4*>(p.ln_rstd + mw + mi * 32 + 8 * g + 4 * hi);
-            }
-            V4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(rs4[j] * (acc[ni][mi][4 * g + j] - mu4[j] * sn_) + bv_);
-            put_bf16(ni * 32 + l31, mi * 32 + 8 * g + 4 * hi, o, RB);
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
+          if (p.ln_mu) {
+            mu4 = *reinterpret_cast<const f32x4*>(p.ln_mu + mw + rt * 16 + 4 * q);
+            rs4 = *reinterpret_cast<const f32x4*>(p.ln_rstd + mw + rt * 16 + 4 * q);
           }
+          V4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(rs4[j] * (acc[nj][rt][j] - mu4[j] * sn_) + bv_);
+          put_bf16(nj * 16 + l15, rt * 16 + 4 * q, o, RB);
+        }
       }
       constexpr int LPR = RB / 16;        // lanes per row
       constexpr int RPI = 64 / LPR;       // rows per instruction
@@ -334,33 +329,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     // monotone non-decreasing, so the max is taken over the raw accumulators first and the transcendental is
     // evaluated once per (sequence, column) -- bit-identical to transforming every element.  A wave's
     // WROWS token rows are a few contiguous runs of sequences: one pass per distinct sequence id.
-    int sq[MI];
+    int sq[RT];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) sq[mi] = p.tok_seq[mw + mi * 32 + l31];
+    for (int rt = 0; rt < RT; ++rt) sq[rt] = p.tok_seq[mw + rt * 16 + l15];
     int done_below = 0;   // sequence ids < done_below are finished (ids are non-negative and ascending along rows)
     while (true) {
       int m = 0x7fffffff;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        if (sq[mi] >= done_below) m = min(m, sq[mi]);
+      for (int rt = 0; rt < RT; ++rt)
+        if (sq[rt] >= done_below) m = min(m, sq[rt]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
       const int cur = uniform(m);
       if (cur == 0x7fffffff) break;
-      bool mine[MI];
+      bool mine[RT];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) mine[mi] = sq[mi] == cur;
+      for (int rt = 0; rt < RT; ++rt) mine[rt] = sq[rt] == cur;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 4; ++r) {
           float v = -INFINITY;
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) v = mine[mi] ? fmaxf(v, acc[ni][mi][r]) : v;
+          for (int rt = 0; rt < RT; ++rt) v = mine[rt] ? fmaxf(v, acc[nj][rt][r]) : v;
 #pragma unroll
-          for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));   // over the 32 token lanes of this half
-          if (l31 == 0) {
-            const int n = nw + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));   // over the 16 token lanes of this quarter
+          if (l15 == 0) {
+            const int n = nw + nj * 16 + 4 * q + r;
             const float w = log1pf(fmaxf(v + (p.bias ? p.bias[n] : 0.f), 0.f));
             if (w > 0.f) atomicMax(p.splade_rows + (size_t)cur * p.N + n, f2u(w));
           }
@@ -370,42 +365,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   }
 }
 
-// BM x BN tile, WM x WN waves; every wave owns (BM/WM) x 64 outputs (MI = BM/WM/32 row tiles, 2 column tiles).
+// BM x BN tile, WM x WN waves; every wave owns (BM/WM) x 64 outputs (RT = BM/WM/16 row tiles, 4 column tiles).
 // DBG = 1 compiles the main-loop decomposition probe (p.debug_flags), instantiated for EPI_NONE only.
-// NS = LDS stages (power of two).  2: the throughput configuration (one stage in flight, plain barriers).  4: the
+// NS = LDS stages.  2: the throughput configuration (one stage in flight, plain barriers).  4: the
 // small-batch configuration -- with a handful of tiles the K loop is a chain of memory round trips, and three
 // stages in flight (counted vmcnt, raw barriers) cut that chain to a third.
-//
-// BKT = K-step: 64 (128-byte LDS rows, chunk swizzle (row>>1)&7) or 32 (64-byte rows, swizzle (row>>2)&3 -- both make every
-// 16-lane ds_read_b128 group cover the 64 banks exactly once).  BKT = 32 halves the bytes of a stage, which is what lets a
-// 128 x 256 tile with three stages (72 KiB, 4 waves) run as TWO workgroups per CU: the configuration of the residual
-// GEMMs, whose fp32 read-modify-write epilogue is HBM-bound -- one workgroup's epilogue then streams under the other's
-// main loop instead of leaving the matrix cores idle.
-//
-// SCHED = 1 (256 x 256 x 64 tile, 8 waves, two stages only): the "8-phase" schedule of cdna_hip_programming.md section 5.
-// A K-tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each (8 MFMAs); a phase is
-//   { ds_read the quadrant's new fragments | issue one 16 KiB operand piece of the NEXT K-tile | counted vmcnt }
-//   s_barrier { lgkmcnt(0) | setprio 1 | 8 MFMAs | setprio 0 } s_barrier
-// and the waves 4-7 run one barrier behind the waves 0-3, so on every SIMD one wave feeds the matrix pipe while its
-// partner reads LDS and issues DMA.  Operand pieces are cut by quadrant, not by tile half -- W rows of the n = 0 quadrants,
-// A rows of the m = 0 quadrants, W rows of n = 1, A rows of m = 1, in the order the phases need them -- so every piece has
-// three phases to land before its first read (never a vmcnt(0) in the loop) and is re-staged four or more phases after its
-// last read.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, int BKT = 64, typename T = bf16_t, int SCHED = 0>
-__global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 : 2) void gemm_bf16_kernel(const GemmParams p) {
-  static_assert(SCHED != 1 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && NS == 2 && BKT == 64 && DBG == 0),
-                "the 8-phase schedule is written for the 256 x 256 x 64 tile");
+template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, typename T = bf16_t>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
-  constexpr int WC = BN / WN;                 // output features per wave: 64 (one head / one GeGLU group) or 128 (two)
-  constexpr int NI = WC / 32;                 // 32-column accumulator tiles per wave
-  static_assert(WC == 64 || WC == 128, "a wave spans one or two 64-feature groups");
+  static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
   static_assert(NS >= 2 && NS <= 4, "LDS stages");
-  static_assert(BKT == 64 || BKT == 32, "K-step");
-  constexpr int ROWB = BKT * 2;               // bytes per LDS row
+  constexpr int ROWB = BK * 2;                // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;            // tile rows filled by one LDS-DMA instruction (64 lanes x 16 bytes)
   constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
-  constexpr int KS = BKT / 16;                // MFMA k-substeps per stage
-  constexpr int MI = BM / WM / 32;            // 32-row accumulator tiles per wave
+  constexpr int KS = BK / 32;                 // MFMA k-substeps per stage
+  constexpr int RT = BM / WM / 16;            // 16-row accumulator tiles per wave
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
   constexpr int A_INSTR = BM / RPI / (WM * WN); // LDS-DMA instructions per wave per stage
   constexpr int W_INSTR = BN / RPI / (WM * WN);
@@ -416,7 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int hi = lane >> 5, l31 = lane & 31;
+  const int q = lane >> 4, l15 = lane & 15;
   constexpr int WROWS = BM / WM;              // rows of the A tile owned by one wave
 
   // Persistent tile loop: the grid is at most one workgroup per CU (p.n_tiles tiles in total).  Tiles
@@ -438,7 +412,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 
   // LDS-DMA staging: instruction i of this wave fills tile rows wave*RPI*INSTR + i*RPI .. +RPI.
-  auto swz = [](int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+  auto swz = [](int row) { return (row >> 1) & 7; };
   int soffA[A_INSTR], soffW[W_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
@@ -450,36 +424,31 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 
     const int row = wave * (RPI * W_INSTR) + i * RPI + lane / CPR;
     soffW[i] = row * K + (((lane % CPR) ^ swz(row)) << 3);
   }
-  // fragment read offsets (bytes inside a 32-row sub-tile)
-  const int sw = swz(l31);
+  // fragment read offsets (bytes inside a 16-row sub-tile): lane = row l15, k-values 32 s + 8 q .. + 8
+  const int sw = swz(l15);
   int fo[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) fo[s] = l31 * ROWB + ((((2 * s + hi) ^ sw)) << 4);
+  for (int s = 0; s < KS; ++s) fo[s] = l15 * ROWB + ((((4 * s + q) ^ sw)) << 4);
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE_BYTES;
     char* sW = sA + A_BYTES;
-    const int k0 = kt * BKT;
+    const int k0 = kt * BK;
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) glds16(Ab + soffA[i] + k0, sA + (wave * (RPI * A_INSTR) + i * RPI) * ROWB);
 #pragma unroll
     for (int i = 0; i < W_INSTR; ++i) glds16(Wb + soffW[i] + k0, sW + (wave * (RPI * W_INSTR) + i * RPI) * ROWB);
   };
 
-  f32x16 acc[NI][MI];
+  f32x4 acc[4][RT];
 #pragma unroll
-  for (int a = 0; a < NI; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int c = 0; c < MI; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    for (int c = 0; c < RT; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 acc4[SCHED >= 3 ? NI * MI * 4 : 1];   // SCHED 3 (16 x 16 x 32 probe): the same 256 accumulator registers as 4-register tiles
-#pragma unroll
-  for (int i = 0; i < (SCHED >= 3 ? NI * MI * 4 : 1); ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nw = n0 + wn * WC;      // first feature of this wave's range
+  const int nw = n0 + wn * 64;      // first feature of this wave's 64-wide range
   const int mw = m0 + wm * WROWS;   // first token row of this wave
-  const int KT = K / BKT;
+  const int KT = K / BK;
   // The V third of the QKV product is computed un-swapped (activations as the A operand): then a
   // lane holds 4 consecutive TOKENS of one feature, which is the V^T row layout attention wants.
   bool v_block = false;
@@ -506,20 +475,21 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 
       if (i < KT) stage(i, i);
     wait_allow(min(NS - 1, KT) - 1);
     step_barrier();
-    V8 dbg_f[MI + NI] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
+    auto pseudo_random = [&](unsigned seed) {   // sign + mantissa random, exponent 127
+      unsigned h = (unsigned)(lane * 2654435761u) ^ (seed * 40503u);
+      unsigned w4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h = h * 1664525u + 1013904223u;
+        w4[j] = (h & 0x807f807fu) | 0x3f803f80u;
+      }
+      return __builtin_bit_cast(V8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
+                                          __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
+    };
+    V8 dbg_f[RT + 4] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
     if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
-      for (int i = 0; i < MI + NI; ++i) {
-        unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)(i * 40503u);
-        unsigned w4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          h = h * 1664525u + 1013904223u;
-          w4[j] = (h & 0x807f807fu) | 0x3f803f80u;
-        }
-        dbg_f[i] = __builtin_bit_cast(V8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
-                                                     __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
-      }
+      for (int i = 0; i < RT + 4; ++i) dbg_f[i] = pseudo_random(i);
     }
     int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
@@ -531,56 +501,40 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 
       if (do_stage && wave < (WM * WN) / 2) stage(nxt, nbuf);   // first half of the waves: right after the barrier
 #endif
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
-      const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * WC) * ROWB;
+      const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #if VRAG_DMA_SPLIT == 1
         if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(nxt, nbuf);   // second half: one substep later
 #endif
-        V8 af[MI] = {}, wf[NI] = {};
+        V8 af[RT] = {}, wf[4] = {};
         if (DBG && (p.debug_flags & 8)) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) af[i] = dbg_f[i];
+          for (int i = 0; i < RT; ++i) af[i] = dbg_f[i];
 #pragma unroll
-          for (int i = 0; i < NI; ++i) wf[i] = dbg_f[MI + i];
+          for (int i = 0; i < 4; ++i) wf[i] = dbg_f[RT + i];
         } else if (DBG && (p.debug_flags & 4)) {   // probe: fresh pseudo-random register operands per MFMA group, no LDS read
 #pragma unroll
-          for (int i = 0; i < MI + NI; ++i) {
-            unsigned h = (unsigned)(lane * 2654435761u) ^ (unsigned)((i * KS + s + kt * 16) * 40503u);
-            unsigned w4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              h = h * 1664525u + 1013904223u;
-              w4[j] = (h & 0x807f807fu) | 0x3f803f80u;   // sign + mantissa random, exponent 127
-            }
-            const V8 v = __builtin_bit_cast(V8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
-                                                              __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
-            if (i < MI) af[i] = v;
-            else wf[i - MI] = v;
+          for (int i = 0; i < RT + 4; ++i) {
+            const V8 v = pseudo_random((unsigned)(i * KS + s + kt * 16));
+            if (i < RT) af[i] = v;
+            else wf[i - RT] = v;
           }
         }
         if (!(DBG && (p.debug_flags & 2))) {
 #pragma unroll
-          for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[s]);
+          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
 #pragma unroll
-          for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const V8*>(sA + i * 32 * ROWB + fo[s]);
+          for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const V8*>(sA + i * 16 * ROWB + fo[s]);
         }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            if constexpr (SCHED == 4) {   // 16 x 16 x 32 probe in the 8-wave loop (garbage results by design, see SCHED 3)
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                f32x4& sub = acc4[(ni * MI + mi) * 4 + 2 * (s & 1) + h];
-                const V8 wv = wf[ni], av = af[mi];
-                if constexpr (std::is_same<T, bf16_t>::value) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
-                else asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
-              }
-            } else if constexpr (SWAPPED)
-              acc[ni][mi] = Op<T>::mfma32(wf[ni], af[mi], acc[ni][mi]);
+          for (int nj = 0; nj < 4; ++nj) {
+            if constexpr (SWAPPED)
+              acc[nj][rt] = Op<T>::mfma16(wf[nj], af[rt], acc[nj][rt]);
             else
-              acc[ni][mi] = Op<T>::mfma32(af[mi], wf[ni], acc[ni][mi]);
+              acc[nj][rt] = Op<T>::mfma16(af[rt], wf[nj], acc[nj][rt]);
           }
       }
       wait_allow(max(0, min(NS - 2, KT - 2 - kt)));   // step kt+1 has landed (this wave's share)
@@ -588,266 +542,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM) * (BN / WN) > 128 * 64 ? 1 
       buf = buf + 1 == NS ? 0 : buf + 1;
     }
   };
-  // ------------------------------------------------------------------ 8-phase schedule (SCHED == 1)
-  auto mainloop8 = [&](auto swapped_tag) {
-    constexpr bool SWAPPED = decltype(swapped_tag)::value;
-    // piece q of a K-tile (16 KiB = 128 tile rows, two DMA instructions per wave): 0 = W rows of the n = 0 quadrants
-    // (wn*64 + [0,32)), 1 = A rows of the m = 0 quadrants (wm*128 + [0,64)), 2 = W rows of n = 1, 3 = A rows of m = 1.
-    // wave w fills piece rows [16 w, 16 w + 16): tile row = block base + offset, blocks of 32 (W) or 64 (A) rows.
-    int prowA[2], prowW[2];   // tile rows of this wave's two instructions inside an A piece / a W piece (for m/n = 0)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = wave * 16 + i * 8;           // piece row of lane 0 of the instruction
-      prowA[i] = (r >> 6) * 128 + (r & 63);      // + 64 for the m = 1 piece
-      prowW[i] = (r >> 5) * 64 + (r & 31);       // + 32 for the n = 1 piece
-    }
-    auto stage_piece = [&](int kt, int q) {      // q is a compile-time constant at every call site
-      char* slot = smem + (kt & 1) * STAGE_BYTES;
-      const int k0 = kt * BKT;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool isA = (q & 1) != 0;
-        const int row0 = (isA ? prowA[i] + (q == 3 ? 64 : 0) : prowW[i] + (q == 2 ? 32 : 0));
-        const int row = row0 + (lane >> 3);
-        const int off = row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3) + k0;
-        glds16((isA ? Ab : Wb) + off, slot + (isA ? 0 : A_BYTES) + row0 * ROWB);
-      }
-    };
-    const bool late = wave >= 4;                 // second wave group: one barrier behind
-    // prologue: the whole first K-tile, then the first two pieces of the second
-#pragma unroll
-    for (int q = 0; q < 4; ++q) stage_piece(0, q);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (late) __builtin_amdgcn_s_barrier();
-    V8 wf0[KS], wf1[KS], af[2][KS];
-    for (int kt = 0; kt < KT; ++kt) {
-      const char* sA = smem + (kt & 1) * STAGE_BYTES + (wm * WROWS) * ROWB;
-      const char* sW = smem + (kt & 1) * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
-      const bool more = kt + 1 < KT;
-      auto phase = [&](auto ph_tag) {
-        constexpr int PH = decltype(ph_tag)::value;
-        // -- fragments this phase adds
-        if constexpr (PH == 0) {
-#pragma unroll
-          for (int s = 0; s < KS; ++s) wf0[s] = *reinterpret_cast<const V8*>(sW + fo[s]);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            af[0][s] = *reinterpret_cast<const V8*>(sA + fo[s]);
-            af[1][s] = *reinterpret_cast<const V8*>(sA + 32 * ROWB + fo[s]);
-          }
-        } else if constexpr (PH == 1) {
-#pragma unroll
-          for (int s = 0; s < KS; ++s) wf1[s] = *reinterpret_cast<const V8*>(sW + 32 * ROWB + fo[s]);
-        } else if constexpr (PH == 2) {
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            af[0][s] = *reinterpret_cast<const V8*>(sA + 64 * ROWB + fo[s]);
-            af[1][s] = *reinterpret_cast<const V8*>(sA + 96 * ROWB + fo[s]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // -- one piece of the next K-tile; then this wave's share of the piece the NEXT phase reads must have landed
-        if (more) stage_piece(kt + 1, PH);
-        if constexpr (PH != 2) {   // phase 3 adds no fragments: nothing to wait for before it
-          if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // two younger pieces may stay in flight
-          else if (PH == 3) asm volatile("" ::: "memory");               // last K-tile: everything landed long ago
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        constexpr int NI_ = (PH == 0 || PH == 3) ? 0 : 1;     // quadrant column
-        constexpr int M0 = (PH < 2) ? 0 : 2;                  // quadrant's first row tile
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const V8& w_ = NI_ == 0 ? wf0[s] : wf1[s];
-            if constexpr (SWAPPED) acc[NI_][M0 + m] = Op<T>::mfma32(w_, af[m][s], acc[NI_][M0 + m]);
-            else acc[NI_][M0 + m] = Op<T>::mfma32(af[m][s], w_, acc[NI_][M0 + m]);
-          }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-      };
-      phase(std::integral_constant<int, 0>{});
-      phase(std::integral_constant<int, 1>{});
-      phase(std::integral_constant<int, 2>{});
-      phase(std::integral_constant<int, 3>{});
-    }
-    if (!late) __builtin_amdgcn_s_barrier();   // re-align the two wave groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
-  // ------------------------------------------------------------------ one wave per SIMD (SCHED == 2)
-  // 4 waves x (128 x 128) outputs: the 256 accumulators live in the AGPR half of a 512-register budget and there is no second
-  // wave on the SIMD to cover latencies, so the loop is software-pipelined by hand: the fragments of k-substep s+1 are read
-  // while the 16 MFMAs of substep s run (two register sets), and the K-step barrier sits BEFORE the last substep's MFMAs --
-  // the next stage's first fragments and the DMA of the stage after it are issued under them.
-  auto mainloop4 = [&](auto swapped_tag) {
-    constexpr bool SWAPPED = decltype(swapped_tag)::value;
-    static_assert((SCHED != 2 && SCHED != 3) || (NS == 2 && (KS % 2) == 0), "two stages, even number of k-substeps");
-    constexpr int NDMA = A_INSTR + W_INSTR;
-    V8 fa[2][MI], fw[2][NI];
-    auto read_frags = [&](auto set_tag, int slot, auto s_tag) {
-      constexpr int SET = decltype(set_tag)::value, S = decltype(s_tag)::value;
-      const char* sA = smem + slot * STAGE_BYTES + (wm * WROWS) * ROWB;
-      const char* sW = smem + slot * STAGE_BYTES + A_BYTES + (wn * WC) * ROWB;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) fw[SET][i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[S]);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[SET][i] = *reinterpret_cast<const V8*>(sA + i * 32 * ROWB + fo[S]);
-    };
-    auto mfmas = [&](auto set_tag) {
-      constexpr int SET = decltype(set_tag)::value;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if constexpr (SWAPPED) acc[ni][mi] = Op<T>::mfma32(fw[SET][ni], fa[SET][mi], acc[ni][mi]);
-          else acc[ni][mi] = Op<T>::mfma32(fa[SET][mi], fw[SET][ni], acc[ni][mi]);
-        }
-    };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    stage(0, 0);
-    if (KT > 1) {
-      stage(1, 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(I0{}, 0, I0{});
-    auto interleave = [&]() {   // issue order of a substep: (MFMA, fragment read) x 8, then the other 8 MFMAs
-#pragma unroll
-      for (int i = 0; i < MI + NI; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - MI - NI, 0);
-    };
-    // one K-step; NEXT: stage kt+1 exists, NEXT2: stage kt+2 exists (compile-time, so every K-step is one basic block)
-    auto kstep = [&](int kt, auto next_tag, auto next2_tag) {
-      constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value;
-      const int slot = kt & 1;
-      read_frags(I1{}, slot, I1{});
-      mfmas(I0{});
-      interleave();
-      if constexpr (KS == 4) {
-        read_frags(I0{}, slot, std::integral_constant<int, 2>{});
-        mfmas(I1{});
-        interleave();
-        read_frags(I1{}, slot, std::integral_constant<int, 3>{});
-        mfmas(I0{});
-        interleave();
-      }
-      // last substep: barrier first, then the next stage's first fragments / the DMA after next under its MFMAs
-      if constexpr (NEXT) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of stage kt+1 landed; my reads of `slot` are done
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (NEXT2) stage(kt + 2, slot);
-        read_frags(I0{}, slot ^ 1, I0{});
-      }
-      mfmas(I1{});
-      if constexpr (NEXT) {
-#pragma unroll
-        for (int i = 0; i < MI + NI; ++i) {   // (MFMA, fragment read, two DMA instructions) x 8, then the other 8 MFMAs
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if constexpr (NEXT2) __builtin_amdgcn_sched_group_barrier(0x010, NDMA / (MI + NI), 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - MI - NI, 0);
-      }
-    };
-    // SCHED 3: the same K-step with the MFMAs as volatile asm in explicit program order -- after every second MFMA of a
-    // substep's first 16 one fragment read of the next substep, and under the last substep two DMA instructions as well
-    auto read_one = [&](auto set_tag, int slot, auto s_tag, int i) {
-      constexpr int SET = decltype(set_tag)::value, S = decltype(s_tag)::value;
-      const char* sA = smem + slot * STAGE_BYTES + (wm * WROWS) * ROWB;
-      const char* sW = smem + slot * STAGE_BYTES + A_BYTES + (wn * WC) * ROWB;
-      if (i < NI) fw[SET][i] = *reinterpret_cast<const V8*>(sW + i * 32 * ROWB + fo[S]);
-      else fa[SET][i - NI] = *reinterpret_cast<const V8*>(sA + (i - NI) * 32 * ROWB + fo[S]);
-    };
-    auto stage_one = [&](int kt, int buf, int j) {
-      char* sA = smem + buf * STAGE_BYTES;
-      char* sW = sA + A_BYTES;
-      const int k0 = kt * BKT;
-      if (j < A_INSTR) glds16(Ab + soffA[j] + k0, sA + (wave * (RPI * A_INSTR) + j * RPI) * ROWB);
-      else glds16(Wb + soffW[j - A_INSTR] + k0, sW + (wave * (RPI * W_INSTR) + (j - A_INSTR) * RPI) * ROWB);
-    };
-    auto substep16 = [&](auto set_tag, auto between) {
-      constexpr int SET = decltype(set_tag)::value;
-#pragma unroll
-      for (int idx = 0; idx < MI * NI * 2; ++idx) {
-        const int pr = idx >> 1, mi = pr / NI, ni = pr % NI, h = idx & 1;
-        f32x4& sub = acc4[(ni * MI + mi) * 4 + 2 * SET + h];
-        const V8 wv = fw[SET][ni], av = fa[SET][mi];
-        if constexpr (std::is_same<T, bf16_t>::value)
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
-        else
-          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(sub) : "v"(wv), "v"(av));
-        if (h == 1 && pr < MI + NI) between(pr);
-      }
-    };
-    auto kstep16 = [&](int kt, auto next_tag, auto next2_tag) {
-      constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value;
-      typedef std::integral_constant<int, 2> I2;
-      typedef std::integral_constant<int, 3> I3;
-      const int slot = kt & 1;
-      substep16(I0{}, [&](int i) { read_one(I1{}, slot, I1{}, i); });
-      substep16(I1{}, [&](int i) { read_one(I0{}, slot, I2{}, i); });
-      substep16(I0{}, [&](int i) { read_one(I1{}, slot, I3{}, i); });
-      if constexpr (NEXT) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      substep16(I1{}, [&](int i) {
-        if constexpr (NEXT) {
-          read_one(I0{}, slot ^ 1, I0{}, i);
-          if constexpr (NEXT2) {
-            stage_one(kt + 2, slot, 2 * i);
-            stage_one(kt + 2, slot, 2 * i + 1);
-          }
-        }
-      });
-    };
-    if constexpr (SCHED == 3) {
-      for (int kt = 0; kt < KT - 2; ++kt) kstep16(kt, std::true_type{}, std::true_type{});
-      if (KT >= 2) kstep16(KT - 2, std::true_type{}, std::false_type{});
-      kstep16(KT - 1, std::false_type{}, std::false_type{});
-    } else {
-      for (int kt = 0; kt < KT - 2; ++kt) kstep(kt, std::true_type{}, std::true_type{});
-      if (KT >= 2) kstep(KT - 2, std::true_type{}, std::false_type{});
-      kstep(KT - 1, std::false_type{}, std::false_type{});
-    }
-    __syncthreads();   // the epilogue reuses the ring as staging
-  };
-  if constexpr (SCHED == 2 || SCHED == 3) {
-    if (v_block) mainloop4(std::false_type{});
-    else mainloop4(std::true_type{});
-  } else if constexpr (SCHED == 1) {
-    if (v_block) mainloop8(std::false_type{});
-    else mainloop8(std::true_type{});
-  } else {
-    if (v_block) mainloop(std::false_type{});
-    else mainloop(std::true_type{});
-  }
+  if (v_block) mainloop(std::false_type{});
+  else mainloop(std::true_type{});
 
-  if constexpr (SCHED >= 3) {
-#pragma unroll
-    for (int i = 0; i < NI * MI * 4; ++i) asm volatile("" ::"a"(acc4[i]));
-  }
-#pragma unroll
-  for (int j = 0; j < NI / 2; ++j)   // one 64-feature group at a time
-    gemm_epilogue<EPI, MI, WROWS, T>(p, *reinterpret_cast<f32x16(*)[2][MI]>(&acc[2 * j]), smem, wave, lane, mw, nw + 64 * j, v_block);
+  gemm_epilogue<EPI, RT, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
   }  // tile loop
 }
@@ -859,128 +557,43 @@ int gemm_small_m_threshold(int set_to) {
 }
 
 // One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
-template <int EPI, int BM, int BN, int WM, int WN, int NS, int BKT, typename T, int SCHED = 0>
+template <int EPI, int BM, int BN, int WM, int WN, int DBG, int NS, typename T>
 static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
-  constexpr int SMEM = NS * (BM + BN) * BKT * 2;
+  constexpr int SMEM = NS * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, 0, NS, BKT, T, SCHED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   p.n_tiles = nbm * nbn;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, 0, NS, BKT, T, SCHED>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
                      stream, p);
   return hipGetLastError();
 }
 
 template <int EPI, typename T>
-hipError_t launch_t(const GemmParams& p_in, hipStream_t stream) {
-  GemmParams p = p_in;
+hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr;  // tuning knob
   // Small batches (a query's handful of chunks): few tiles, so the K loop's chain of memory round trips is the
-  // whole kernel -- 128x128 tiles (4x the workgroups) with four LDS stages (three K-steps in flight).
-  if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) {
-    constexpr int BM = 128, BN = 128, SMEM = 4 * (BM + BN) * BK * 2;   // 128 KiB, one workgroup per CU
-    static bool attr_s = false;
-    if (!attr_s) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4, 64, T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-      if (e != hipSuccess) return e;
-      attr_s = true;
-    }
-    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-    p.n_tiles = nbm * nbn;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 4, 64, T>), dim3(std::min(nbm * nbn, 256)), dim3(256), SMEM, stream, p);
-    return hipGetLastError();
-  }
-  // Residual GEMMs (HBM-bound epilogue): 128 x 256 tiles, 4 waves, BK = 32 x 3 stages = 72 KiB -> two workgroups per CU,
-  // one's read-modify-write streams under the other's main loop (VRAG_GEMM_RES_PAIR=1).
-  static const bool res_pair = getenv("VRAG_GEMM_RES_PAIR") && atoi(getenv("VRAG_GEMM_RES_PAIR")) != 0;   // measured slower (r2b: 178 / 222 us vs 166 / 198 us on the 256 x 256 tile): opt-in
-  if constexpr (EPI == EPI_RESIDUAL) {
-    if (res_pair && !force128 && p.N % 256 == 0 && p.M >= 256 && p.K % 32 == 0) {
-      constexpr int BM = 128, BN = 256, SMEM = 3 * (BM + BN) * 32 * 2;
-      static bool attr_p = false;
-      if (!attr_p) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32, T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return e;
-        attr_p = true;
-      }
-      const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-      p.n_tiles = nbm * nbn;
-      static const int pgrid2 = getenv("VRAG_GEMM_PGRID2") ? atoi(getenv("VRAG_GEMM_PGRID2")) : 512;   // 2 workgroups per CU
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 1, 4, 0, 3, 32, T>), dim3(std::min(nbm * nbn, pgrid2)), dim3(256), SMEM, stream, p);
-      return hipGetLastError();
-    }
-  }
-  // 4 waves, 128 x 128 outputs per wave, one wave per SIMD (512 registers): a third fewer LDS fragment reads per MFMA
-  // than the 8-wave layout.  1: the plain two-stage loop, 2: the hand-pipelined one (SCHED = 2).
-  static const int w4 = getenv("VRAG_GEMM_W4") ? atoi(getenv("VRAG_GEMM_W4")) : 0;
-  if constexpr (EPI == EPI_NONE) {   // main-loop diagnostic only: with 4 waves the fused epilogues are slower (r2n: qkv 446 vs 276 us)
-    if (w4 && p.N % 256 == 0 && p.M >= 256) {
-      static const int pgrid4 = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;
-      if (w4 == 3) return launch_cfg<EPI, 256, 256, 2, 2, 2, 64, T, 3>(p, pgrid4, stream);
-      if (w4 == 4) return launch_cfg<EPI, 256, 256, 2, 4, 2, 64, T, 4>(p, pgrid4, stream);
-      return w4 == 2 ? launch_cfg<EPI, 256, 256, 2, 2, 2, 64, T, 2>(p, pgrid4, stream) : launch_cfg<EPI, 256, 256, 2, 2, 2, 64, T>(p, pgrid4, stream);
-    }
-  }
+  // whole kernel -- 128x128 tiles (4x the workgroups) with four LDS stages (three K-steps in flight), 1 workgroup per CU.
+  if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) return launch_cfg<EPI, 128, 128, 2, 2, 0, 4, T>(p, 256, stream);
   static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
   if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
-    constexpr int BM = 256, BN = 256, SMEM = 2 * (BM + BN) * BK * 2;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-      if (e != hipSuccess) return e;
-      attr = true;
-    }
-    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-    p.n_tiles = nbm * nbn;
-    {
-      static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
+    static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
+    if constexpr (EPI == EPI_NONE) {
       static const int env_debug = getenv("VRAG_GEMM_DEBUG") ? atoi(getenv("VRAG_GEMM_DEBUG")) : 0;
-      if constexpr (EPI == EPI_NONE) {
-        if (env_debug) {   // main-loop decomposition probe: results are garbage by design
-          static bool attr5 = false;
-          if (!attr5) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1, 2, 64, T>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-            if (e != hipSuccess) return e;
-            attr5 = true;
-          }
-          p.debug_flags = env_debug;
-          hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 1, 2, 64, T>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
-          return hipGetLastError();
-        }
+      if (env_debug) {   // main-loop decomposition probe: results are garbage by design
+        GemmParams pd = p;
+        pd.debug_flags = env_debug;
+        return launch_cfg<EPI, 256, 256, 2, 4, 1, 2, T>(pd, pgrid, stream);
       }
-      // Measured (r2f, same box, 50-100 launches each): main loop alone 1068 vs 1092 TFLOP/s at M = 65536 / K = 768,
-      // 1162 vs 1170 at 4096^3, 1314 vs 1331 at 8192^3 -- the 8-phase schedule lands on the same (clock / power
-      // limited) plateau as the two-stage loop, and its 64 fragment registers push the fused epilogues into spills.
-      // Kept for the main-loop diagnostic (EPI_NONE) only, so the comparison stays reproducible.
-      static const bool sched8 = getenv("VRAG_GEMM_SCHED8") && atoi(getenv("VRAG_GEMM_SCHED8")) != 0;
-      if constexpr (EPI == EPI_NONE) if (sched8) {
-        static bool attr8 = false;
-        if (!attr8) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T, 1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-          if (e != hipSuccess) return e;
-          attr8 = true;
-        }
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T, 1>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
-        return hipGetLastError();
-      }
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 4, 0, 2, 64, T>), dim3(std::min(nbm * nbn, pgrid)), dim3(512), SMEM, stream, p);
     }
-  } else {
-    constexpr int BM = 128, BN = 128, SMEM = 2 * (BM + BN) * BK * 2;
-    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-    p.n_tiles = nbm * nbn;
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, 2, 2, 0, 2, 64, T>), dim3(std::min(nbm * nbn, 512)), dim3(256), SMEM, stream, p);
+    return launch_cfg<EPI, 256, 256, 2, 4, 0, 2, T>(p, pgrid, stream);
   }
-  return hipGetLastError();
+  return launch_cfg<EPI, 128, 128, 2, 2, 0, 2, T>(p, 512, stream);
 }
 
 template <typename T>

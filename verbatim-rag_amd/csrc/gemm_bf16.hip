@@ -51,6 +51,9 @@ template <int EPI, int RT, int WROWS, typename T>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* smem, int wave, int lane,
                                               int mw, int nw, bool v_block) {
   typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
+  // The lane index is re-read through an opaque asm: every per-lane address of the epilogue then depends on a value
+  // defined inside the tile loop, so none of them is hoisted out of it to sit in (spilled) registers across the K loop.
+  asm volatile("" : "+v"(lane));
   const int q = lane >> 4, l15 = lane & 15;
   // ------------------------------------------------------------------ epilogues
   // All operand-tile reads are done (the loop ends with a barrier), so the LDS is reused as a
@@ -183,27 +186,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       finish_half(hB, 2 * ps + 1);
     }
   } else if constexpr (EPI == EPI_BF16) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      float mu = 0.f, rs = 1.f;
-      if (p.ln_mu) {
-        mu = p.ln_mu[mw + rt * 16 + l15];
-        rs = p.ln_rstd[mw + rt * 16 + l15];
-      }
+    // The optional terms (LayerNorm fold, bias, GELU) are wave-uniform: one dispatch per tile into a body compiled for
+    // the combination, so that the per-row / per-column loads of a tile are independent of any branch and batch up.
+    auto body = [&](auto fold_tag, auto bias_tag, auto gelu_tag) {
+      constexpr bool FOLD = decltype(fold_tag)::value, BIAS = decltype(bias_tag)::value, GELU = decltype(gelu_tag)::value;
+      f32x4 ls[4] = {}, bs[4] = {};
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj) {
-        const int col = nj * 16 + 4 * q;
-        V4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[nj][rt][j];
-          if (p.ln_mu) v = rs * (v - mu * p.ln_s[nw + col + j]);
-          if (p.bias) v += p.bias[nw + col + j];
-          if (p.act_gelu) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
-          o[j] = Op<T>::to(v);
-        }
-        put_bf16(rt * 16 + l15, col, o, 128);
+        if constexpr (FOLD) ls[nj] = *reinterpret_cast<const f32x4*>(p.ln_s + nw + nj * 16 + 4 * q);
+        if constexpr (BIAS) bs[nj] = *reinterpret_cast<const f32x4*>(p.bias + nw + nj * 16 + 4 * q);
       }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float mu = 0.f, rs = 1.f;
+        if constexpr (FOLD) {
+          mu = p.ln_mu[mw + rt * 16 + l15];
+          rs = p.ln_rstd[mw + rt * 16 + l15];
+        }
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+          V4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[nj][rt][j];
+            if constexpr (FOLD) v = rs * (v - mu * ls[nj][j]);
+            if constexpr (BIAS) v += bs[nj][j];
+            if constexpr (GELU) v = gelu_fast(v);   // BERT-family MLP: gelu(x W1^T + b1)
+            o[j] = Op<T>::to(v);
+          }
+          put_bf16(rt * 16 + l15, nj * 16 + 4 * q, o, 128);
+        }
+      }
+    };
+    typedef std::true_type Y;
+    typedef std::false_type N_;
+    if (p.act_gelu) {                              // BERT-family MLP up-projection (always biased)
+      if (p.ln_mu) body(Y{}, Y{}, Y{});
+      else body(N_{}, Y{}, Y{});
+    } else if (p.ln_mu) {
+      if (p.bias) body(Y{}, Y{}, N_{});
+      else body(Y{}, N_{}, N_{});
+    } else {
+      if (p.bias) body(N_{}, Y{}, N_{});
+      else body(N_{}, N_{}, N_{});
     }
 #pragma unroll
     for (int it = 0; it < WROWS / 8; ++it) {
@@ -215,31 +240,41 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     // followed by the 32 matching "gate" rows (x2).  Output tile: [rows][32 features], 64-byte rows.
     const int NO = p.N >> 1;
     const int f0 = (nw >> 6) * 32;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      float mu = 0.f, rs = 1.f;
-      if (p.ln_mu) {
-        mu = p.ln_mu[mw + rt * 16 + l15];
-        rs = p.ln_rstd[mw + rt * 16 + l15];
-      }
+    auto body = [&](auto fold_tag) {
+      constexpr bool FOLD = decltype(fold_tag)::value;
+      f32x4 s1[2] = {}, s2[2] = {};
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) {
-        const int dd = nj * 16 + 4 * q;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-        if (p.ln_mu) {
-          s1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + dd);
-          s2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + dd);
+        if constexpr (FOLD) {
+          s1[nj] = *reinterpret_cast<const f32x4*>(p.ln_s + nw + nj * 16 + 4 * q);
+          s2[nj] = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + nj * 16 + 4 * q);
         }
-        V4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float x1 = rs * (acc[nj][rt][j] - mu * s1[j]);
-          const float x2 = rs * (acc[nj + 2][rt][j] - mu * s2[j]);
-          o[j] = Op<T>::to(gelu_fast(x1) * x2);
-        }
-        put_bf16(rt * 16 + l15, dd, o, 64);
       }
-    }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float mu = 0.f, rs = 1.f;
+        if constexpr (FOLD) {
+          mu = p.ln_mu[mw + rt * 16 + l15];
+          rs = p.ln_rstd[mw + rt * 16 + l15];
+        }
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          V4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x1 = acc[nj][rt][j], x2 = acc[nj + 2][rt][j];
+            if constexpr (FOLD) {
+              x1 = rs * (x1 - mu * s1[nj][j]);
+              x2 = rs * (x2 - mu * s2[nj][j]);
+            }
+            o[j] = Op<T>::to(gelu_fast(x1) * x2);
+          }
+          put_bf16(rt * 16 + l15, nj * 16 + 4 * q, o, 64);
+        }
+      }
+    };
+    if (p.ln_mu) body(std::true_type{});
+    else body(std::false_type{});
 #pragma unroll
     for (int it = 0; it < WROWS / 16; ++it) {
       const int row = it * 16 + (lane >> 2), c16 = lane & 3;
@@ -249,46 +284,90 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int H = p.hidden;
     const int which = nw / H;  // 0 = q, 1 = k, 2 = v   (wave-uniform)
     const int head = (nw - which * H) >> 6;
+    typedef std::true_type Y;
+    typedef std::false_type N_;
     if (!v_block) {
       bf16_t* dst = which == 0 ? p.q : p.k;
       const float scale = which == 0 ? p.q_scale : 1.0f;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int pos = p.pos[mw + rt * 16 + l15];
-        const float* cs = p.rope_cos + (size_t)pos * 32;
-        const float* sn = p.rope_sin + (size_t)pos * 32;
-        float mu = 0.f, rs = 1.f;
-        if (p.ln_mu) {
-          mu = p.ln_mu[mw + rt * 16 + l15];
-          rs = p.ln_rstd[mw + rt * 16 + l15];
-        }
+      auto body = [&](auto fold_tag, auto bias_tag) {
+        constexpr bool FOLD = decltype(fold_tag)::value, BIAS = decltype(bias_tag)::value;
+        f32x4 ls1[2] = {}, ls2[2] = {}, b1[2] = {}, b2[2] = {};
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
           const int dd = nj * 16 + 4 * q;
-          const f32x4 c = *reinterpret_cast<const f32x4*>(cs + dd);
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(sn + dd);
-          f32x4 ls1 = {0.f, 0.f, 0.f, 0.f}, ls2 = {0.f, 0.f, 0.f, 0.f};
-          if (p.ln_mu) {
-            ls1 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + dd);
-            ls2 = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + dd);
+          if constexpr (FOLD) {
+            ls1[nj] = *reinterpret_cast<const f32x4*>(p.ln_s + nw + dd);
+            ls2[nj] = *reinterpret_cast<const f32x4*>(p.ln_s + nw + 32 + dd);
           }
-          f32x4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) {
-            b1 = *reinterpret_cast<const f32x4*>(p.bias + nw + dd);
-            b2 = *reinterpret_cast<const f32x4*>(p.bias + nw + 32 + dd);
+          if constexpr (BIAS) {
+            b1[nj] = *reinterpret_cast<const f32x4*>(p.bias + nw + dd);
+            b2[nj] = *reinterpret_cast<const f32x4*>(p.bias + nw + 32 + dd);
           }
-          V4 o1, o2;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float x1 = rs * (acc[nj][rt][j] - mu * ls1[j]) + b1[j];
-            const float x2 = rs * (acc[nj + 2][rt][j] - mu * ls2[j]) + b2[j];
-            // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
-            o1[j] = Op<T>::to((x1 * c[j] - x2 * sv[j]) * scale);
-            o2[j] = Op<T>::to((x2 * c[j] + x1 * sv[j]) * scale);
-          }
-          put_bf16(rt * 16 + l15, dd, o1, 128);
-          put_bf16(rt * 16 + l15, dd + 32, o2, 128);
         }
+        // rotary tables are gathered per token row (L2 hits): two row tiles per group, the next group's gathers issued
+        // before this group's arithmetic (two register sets), scheduling fenced per group so the set stays at 64 registers
+        constexpr int G = 2, NG = RT / G;
+        f32x4 cz[2][G][2], sz[2][G][2];
+        float mu_[2][G], rs_[2][G];
+        auto gather = [&](int set, int g) {
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            const int row = mw + (g * G + i) * 16 + l15;
+            const int pos = p.pos[row];
+            mu_[set][i] = 0.f;
+            rs_[set][i] = 1.f;
+            if constexpr (FOLD) {
+              mu_[set][i] = p.ln_mu[row];
+              rs_[set][i] = p.ln_rstd[row];
+            }
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+              cz[set][i][nj] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * 32 + nj * 16 + 4 * q);
+              sz[set][i][nj] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * 32 + nj * 16 + 4 * q);
+            }
+          }
+        };
+        gather(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) gather((g + 1) & 1, g + 1);
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            const int rt = g * G + i;
+            const float mu = mu_[g & 1][i], rs = rs_[g & 1][i];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+              const int dd = nj * 16 + 4 * q;
+              const f32x4 c = cz[g & 1][i][nj], sv = sz[g & 1][i][nj];
+              V4 o1, o2;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float x1 = acc[nj][rt][j], x2 = acc[nj + 2][rt][j];
+                if constexpr (FOLD) {
+                  x1 = rs * (x1 - mu * ls1[nj][j]);
+                  x2 = rs * (x2 - mu * ls2[nj][j]);
+                }
+                if constexpr (BIAS) {
+                  x1 += b1[nj][j];
+                  x2 += b2[nj][j];
+                }
+                // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
+                o1[j] = Op<T>::to((x1 * c[j] - x2 * sv[j]) * scale);
+                o2[j] = Op<T>::to((x2 * c[j] + x1 * sv[j]) * scale);
+              }
+              put_bf16(rt * 16 + l15, dd, o1, 128);
+              put_bf16(rt * 16 + l15, dd + 32, o2, 128);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (p.ln_mu) {
+        if (p.bias) body(Y{}, Y{});
+        else body(Y{}, N_{});
+      } else {
+        if (p.bias) body(N_{}, Y{});
+        else body(N_{}, N_{});
       }
 #pragma unroll
       for (int it = 0; it < WROWS / 8; ++it) {
@@ -299,22 +378,41 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       // un-swapped accumulators: lane = feature d (nj*16 + l15), registers = tokens
       //   token = rt*16 + 4*q + r.   Stage V^T tile [64 d][WROWS tokens].
       constexpr int RB = WROWS * 2;  // row bytes (256 for 128 tokens, 128 for 64)
+      auto body = [&](auto fold_tag, auto bias_tag) {
+        constexpr bool FOLD = decltype(fold_tag)::value, BIAS = decltype(bias_tag)::value;
+        f32x4 mu4[RT] = {}, rs4[RT] = {};
+        if constexpr (FOLD) {
 #pragma unroll
-      for (int nj = 0; nj < 4; ++nj) {
-        const float sn_ = p.ln_mu ? p.ln_s[nw + nj * 16 + l15] : 0.f;
-        const float bv_ = p.bias ? p.bias[nw + nj * 16 + l15] : 0.f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
-          if (p.ln_mu) {
-            mu4 = *reinterpret_cast<const f32x4*>(p.ln_mu + mw + rt * 16 + 4 * q);
-            rs4 = *reinterpret_cast<const f32x4*>(p.ln_rstd + mw + rt * 16 + 4 * q);
+          for (int rt = 0; rt < RT; ++rt) {
+            mu4[rt] = *reinterpret_cast<const f32x4*>(p.ln_mu + mw + rt * 16 + 4 * q);
+            rs4[rt] = *reinterpret_cast<const f32x4*>(p.ln_rstd + mw + rt * 16 + 4 * q);
           }
-          V4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = Op<T>::to(rs4[j] * (acc[nj][rt][j] - mu4[j] * sn_) + bv_);
-          put_bf16(nj * 16 + l15, rt * 16 + 4 * q, o, RB);
         }
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+          float sn_ = 0.f, bv_ = 0.f;
+          if constexpr (FOLD) sn_ = p.ln_s[nw + nj * 16 + l15];
+          if constexpr (BIAS) bv_ = p.bias[nw + nj * 16 + l15];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            V4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[nj][rt][j];
+              if constexpr (FOLD) v = rs4[rt][j] * (v - mu4[rt][j] * sn_);
+              if constexpr (BIAS) v += bv_;
+              o[j] = Op<T>::to(v);
+            }
+            put_bf16(nj * 16 + l15, rt * 16 + 4 * q, o, RB);
+          }
+        }
+      };
+      if (p.ln_mu) {
+        if (p.bias) body(Y{}, Y{});
+        else body(Y{}, N_{});
+      } else {
+        if (p.bias) body(N_{}, Y{});
+        else body(N_{}, N_{});
       }
       constexpr int LPR = RB / 16;        // lanes per row
       constexpr int RPI = 64 / LPR;       // rows per instruction

@@ -34,11 +34,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef VRAG_DMA_SPLIT
-#define VRAG_DMA_SPLIT 1   // operand-DMA issue of the main loop: 0 = every wave right after the K-step barrier,
-                           // 1 = half of the waves there, the other half one k-substep later (+1-3 % on the GEMMs)
-#endif
-
 namespace vrag {
 
 constexpr int BK = 64;   // K-step: one LDS stage holds 64 k-values of every tile row
@@ -593,18 +588,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
     for (int kt = 0; kt < KT; ++kt) {
       const int nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;   // the slot read in step kt-1: every wave passed the barrier since
       const bool do_stage = nxt < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
-#if VRAG_DMA_SPLIT == 0
-      if (do_stage) stage(nxt, nbuf);
-#elif VRAG_DMA_SPLIT == 1
-      if (do_stage && wave < (WM * WN) / 2) stage(nxt, nbuf);   // first half of the waves: right after the barrier
-#endif
+      if (do_stage) stage(nxt, nbuf);   // right after the barrier (issuing half of the waves' share a substep later: no difference, r2s)
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-#if VRAG_DMA_SPLIT == 1
-        if (s == 1 && do_stage && wave >= (WM * WN) / 2) stage(nxt, nbuf);   // second half: one substep later
-#endif
         V8 af[RT] = {}, wf[4] = {};
         if (DBG && (p.debug_flags & 8)) {
 #pragma unroll

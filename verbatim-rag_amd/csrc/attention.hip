@@ -47,14 +47,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
   const int t0 = p.blk_seq_start[blk];
   const int S = p.blk_seq_len[blk];
   const int qb0 = p.blk_q0[blk];
-  const int qw0 = qb0 + wave * 64;  // first query row of this wave (inside the sequence)
+  const int qw0 = qb0 + wave * 64;  // first query row of this wave (inside the sequence), global layers
   const int W = p.window;
+  // First query row of sub-tile u.  Global layers: the wave's 64 consecutive rows.  Banded layers: rows 32*(wave + NW*u) of
+  // the block, i.e. the wave's two sub-tiles sit half a block apart -- their bands cover different key tiles, so in every
+  // tile step each wave has about half a tile of work instead of some waves a whole tile and the others none (the
+  // workgroup walks its 6-7 tiles in lock-step; with consecutive rows a wave had work in only 3 of them).
+  auto qlo = [&](int u) { return LOCAL ? qb0 + 32 * (wave + NW * u) : qw0 + 32 * u; };
 
   // Q fragments (B operand) for both sub-tiles: k-slot (8*hi + j) of step s <-> d = 16*s + 8*hi + j
   V8 qf[2][4];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int row = min(t0 + qw0 + u * 32 + l31, Tp - 1);
+    const int row = min(t0 + qlo(u) + l31, Tp - 1);
     const T* qrow = reinterpret_cast<const T*>(p.q) + (size_t)row * H + head * 64 + 8 * hi;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const V8*>(qrow + 16 * s);
@@ -115,7 +120,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
     if (kb + 2 <= kb_hi) stage(kb + 2);  // slot of tile kb-1: every wave finished it before the barrier
 
     bool active = qw0 < S;
-    if constexpr (LOCAL) active = active && (kb * 64 + 63 >= qw0 - W) && (kb * 64 <= qw0 + 63 + W);
+    if constexpr (LOCAL) {
+      active = false;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) active = active || (qlo(u) < S && kb * 64 + 63 >= qlo(u) - W && kb * 64 <= qlo(u) + 31 + W);
+    }
     if (!active) continue;  // wave-uniform
 
     const char* sK = smem + (kb % ATT_SLOTS) * ATT_TILE;
@@ -137,10 +146,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int q_lo = qw0 + u * 32, kh = kb * 64 + t * 32;
+        const int q_lo = qlo(u), kh = kb * 64 + t * 32;
         tri[u][t] = kh + 31 >= S;
         if constexpr (LOCAL) {
-          skip[u][t] = (kh + 31 < q_lo - W) || (kh > q_lo + 31 + W) || kh >= S;
+          skip[u][t] = (kh + 31 < q_lo - W) || (kh > q_lo + 31 + W) || kh >= S || q_lo >= S;
           tri[u][t] = tri[u][t] || (kh < q_lo + 31 - W) || (kh + 31 > q_lo + W);
         }
       }
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
     V8 pf[2][2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int q_lo = qw0 + u * 32;
+      const int q_lo = qlo(u);
       float mx = -1e30f;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -269,8 +278,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
   for (int it = 0; it < 8; ++it) {
     const int row = it * 8 + (lane >> 3), c16 = lane & 7;
     const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((c16 ^ (row & 7)) << 4));
-    if (qw0 + row < S)
-      *reinterpret_cast<f32x4*>(reinterpret_cast<T*>(p.o) + (size_t)(t0 + qw0 + row) * H + head * 64 + c16 * 8) = v;
+    const int grow = qlo(row >> 5) + (row & 31);   // row of the sequence this staged row belongs to
+    if (grow < S)
+      *reinterpret_cast<f32x4*>(reinterpret_cast<T*>(p.o) + (size_t)(t0 + grow) * H + head * 64 + c16 * 8) = v;
   }
 }
 

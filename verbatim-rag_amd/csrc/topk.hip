@@ -1152,8 +1152,9 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
 // QB queries per pass over the shard.  The QB queries of a pass touch at most a few hundred distinct terms
 // ("union").  Per pass the LDS holds ONE u16 map term -> union id (0 = in none of the queries; 60 KiB for a
 // 30 522-term vocabulary) and a small dense weight table W[q][union id] (W[q][0] = 0), so a document term
-// costs one 2-byte LDS read shared by all queries plus one 4-byte read per query, with no divergence and no
-// probing; absent terms contribute fmaf(v, 0, acc) == acc and the per-document sum keeps the document's term
+// costs one 2-byte LDS read shared by all queries plus the union id's QB weights (stored [union id][q]: QB/4 16-byte
+// reads, and the ~97 % of document terms that are in no query all read entry 0 -- a broadcast), with no divergence and
+// no probing; absent terms contribute fmaf(v, 0, acc) == acc and the per-document sum keeps the document's term
 // order: bit-identical to the single-query kernel and the CPU restatement.  The document stream is read once
 // for QB queries.
 constexpr int SUW = 1024;                   // weight-table stride: union ids 0 .. SUW-1
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     reinterpret_cast<f32x4*>(tmap)[i] = reinterpret_cast<const f32x4*>(qmap)[i];
   for (int i = tid; i < QB * (n_union + 1); i += 1024) {
     const int q = i / (n_union + 1), u = i - q * (n_union + 1);
-    tw[q * SUW + u] = qw[(size_t)q * SUW + u];
+    tw[u * QB + q] = qw[(size_t)q * SUW + u];
   }
   for (int i = tid; i < 16 * QB * k; i += 1024) lists[i] = 0ull;
   __syncthreads();
@@ -1192,29 +1193,43 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     float acc[QB];
 #pragma unroll
     for (int q = 0; q < QB; ++q) acc[q] = 0.f;
-    int j = 0;
-    for (; j + 8 <= len; j += 8) {
+    auto term = [&](unsigned uid, float v1) {   // acc[q] += v1 * W[uid][q], q ascending inside the document's term order
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
+#pragma unroll
+      for (int g = 0; g < QB / 4; ++g) {
+        const f32x4 w4 = wrow[g];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * g + i] = __fmaf_rn(v1, w4[i], acc[4 * g + i]);
+      }
+    };
+    auto eight = [&](const unsigned (&uid)[8], const float (&vv)[8]) {
+      constexpr int GRP = QB == 8 ? 4 : 2;   // terms whose weight rows are in flight together (GRP * QB registers)
+#pragma unroll
+      for (int u = 0; u < 8; u += GRP) {
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) term(uid[u + i], vv[u + i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // Eight terms per lane at a time.  (Measured in round 2: a ring of 2 / 4 register sets with the next batches' loads
+    // issued ahead does not help -- hipcc renames the sets and drains them inside one trip (2 sets: 0.46 ms per pass, the
+    // same) or spills (4 sets: 1.8 ms).  With one 16-wave workgroup per CU and ~2 us loaded latency, one batch in flight
+    // per wave is what bounds the pass at 1.6 TB/s; going further needs wider per-lane loads, i.e. another slice layout.)
+    const int nb = len >> 3;
+    for (int b = 0; b < nb; ++b) {
       unsigned short ci[8];
       float vi[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        ci[u] = __builtin_nontemporal_load(c + (size_t)(j + u) * 64);
-        vi[u] = __builtin_nontemporal_load(v + (size_t)(j + u) * 64);
+        ci[u] = __builtin_nontemporal_load(c + (size_t)(b * 8 + u) * 64);
+        vi[u] = __builtin_nontemporal_load(v + (size_t)(b * 8 + u) * 64);
       }
       unsigned uid[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) uid[u] = tmap[ci[u]];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int q = 0; q < QB; ++q) acc[q] = __fmaf_rn(vi[u], tw[q * SUW + uid[u]], acc[q]);
+      eight(uid, vi);
     }
-    for (; j < len; ++j) {
-      const unsigned uid1 = tmap[c[(size_t)j * 64]];
-      const float v1 = v[(size_t)j * 64];
-#pragma unroll
-      for (int q = 0; q < QB; ++q) acc[q] = __fmaf_rn(v1, tw[q * SUW + uid1], acc[q]);
-    }
+    for (int j = nb * 8; j < len; ++j) term(tmap[c[(size_t)j * 64]], v[(size_t)j * 64]);
     const long long doc = (long long)s * 64 + lane;
     const unsigned did = doc < n_docs ? docid[doc] : 0u;
 #pragma unroll

@@ -67,7 +67,7 @@ def sparse(n=1_000_000, vocab=30522, mean_nnz=128, k=5):
         qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(nq)]
         sh.search(qs, k)
         dt = timeit(lambda: sh.run_resident(nq, k), 5)
-        per_pass = 1 if nq == 1 else (8 if nq < 16 else 16)   # sparse_topk_kernel / sparse_topk_multi_kernel<8|16> (16 when nq >= 16 and the tables fit)
+        per_pass = 1 if nq == 1 else 8   # sparse_topk_kernel / sparse_topk_multi_kernel<8>
         passes = (nq + per_pass - 1) // per_pass
         pass_bytes = st["padded_nnz"] * 6 + (st["n_docs"] // 64 + 1) * 12
         bytes_ = pass_bytes * passes            # a pass reads the shard ONCE for all of its queries

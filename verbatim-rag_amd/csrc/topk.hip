@@ -72,6 +72,24 @@ __device__ __forceinline__ void insert_key(u64* list, int k, u64 key) {
   list[i] = key;
 }
 
+// One key per lane (0 = none) into a wave-private sorted list: the lanes' keys are taken in DESCENDING order and the loop ends
+// as soon as the largest one left cannot enter, so a wave inserts at most k keys per call -- not one per qualifying lane
+// (a wave's first slice meets an empty list: 64 serial insertions before, k now).  The result is the same list.
+__device__ __forceinline__ void wave_insert_topk(u64* list, int k, u64 key, int lane) {
+  u64 kth = list[k - 1];
+  while (__ballot(key > kth)) {
+    u64 mx = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const u64 other = __shfl_xor(mx, o, 64);
+      mx = other > mx ? other : mx;
+    }
+    if (lane == 0) insert_key(list, k, mx);
+    if (key == mx) key = 0ull;   // keys are unique (they carry the row id)
+    kth = list[k - 1];           // LDS operations of one wave execute in order: this sees lane 0's update
+  }
+}
+
 // ------------------------------------------------------------------------------------ dense
 constexpr int DQT = 4;        // queries per pass
 constexpr int DROWS_MIN = 32;    // rows per workgroup iteration; rows per workgroup = a multiple of this, chosen at launch
@@ -1115,15 +1133,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
     // the key carries the caller's document index (not the sorted position): ties order by id ascending
     const u64 key = hit ? make_key_below(acc, docid[doc], bound ? bound[q] : ~0ull) : 0ull;
-    // wave-level filtered insertion
-    u64 kth = mylist[k - 1];
-    unsigned long long m = __ballot(key > kth);
-    while (m) {
-      const int src = __ffsll((long long)m) - 1;
-      const u64 kk = __shfl(key, src, 64);
-      if (lane == 0) insert_key(mylist, k, kk);
-      m &= m - 1;
-    }
+    wave_insert_topk(mylist, k, key, lane);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1202,49 +1212,42 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
         for (int i = 0; i < 4; ++i) acc[4 * g + i] = __fmaf_rn(v1, w4[i], acc[4 * g + i]);
       }
     };
-    auto eight = [&](const unsigned (&uid)[8], const float (&vv)[8]) {
-      constexpr int GRP = QB == 8 ? 4 : 2;   // terms whose weight rows are in flight together (GRP * QB registers)
+    // 16 then 4 terms per step, like the single-query kernel: all loads of a step are issued before its (strictly
+    // sequential, term-order) fmaf chains consume them -- with one 16-wave workgroup per CU (the term map fills the LDS)
+    // the bytes in flight per lane are what covers the memory latency (8-term steps: 0.44 ms per pass, 0.37 ms of it with
+    // the LDS reads and FMAs compiled out).  Weight rows are read four terms at a time (scheduling fence) to bound registers.
+    int j = 0;
+    auto steps = [&](auto un) {
+      constexpr int U = decltype(un)::value;
+      for (; j + U <= len; j += U) {
+        unsigned short ci[U];
+        float vi[U];
 #pragma unroll
-      for (int u = 0; u < 8; u += GRP) {
+        for (int u = 0; u < U; ++u) {
+          ci[u] = __builtin_nontemporal_load(c + (size_t)(j + u) * 64);
+          vi[u] = __builtin_nontemporal_load(v + (size_t)(j + u) * 64);
+        }
+        unsigned uid[U];
 #pragma unroll
-        for (int i = 0; i < GRP; ++i) term(uid[u + i], vv[u + i]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < U; ++u) uid[u] = tmap[ci[u]];
+#pragma unroll
+        for (int u = 0; u < U; u += 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) term(uid[u + i], vi[u + i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     };
-    // Eight terms per lane at a time.  (Measured in round 2: a ring of 2 / 4 register sets with the next batches' loads
-    // issued ahead does not help -- hipcc renames the sets and drains them inside one trip (2 sets: 0.46 ms per pass, the
-    // same) or spills (4 sets: 1.8 ms).  With one 16-wave workgroup per CU and ~2 us loaded latency, one batch in flight
-    // per wave is what bounds the pass at 1.6 TB/s; going further needs wider per-lane loads, i.e. another slice layout.)
-    const int nb = len >> 3;
-    for (int b = 0; b < nb; ++b) {
-      unsigned short ci[8];
-      float vi[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        ci[u] = __builtin_nontemporal_load(c + (size_t)(b * 8 + u) * 64);
-        vi[u] = __builtin_nontemporal_load(v + (size_t)(b * 8 + u) * 64);
-      }
-      unsigned uid[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) uid[u] = tmap[ci[u]];
-      eight(uid, vi);
-    }
-    for (int j = nb * 8; j < len; ++j) term(tmap[c[(size_t)j * 64]], v[(size_t)j * 64]);
+    steps(std::integral_constant<int, 16>{});
+    steps(std::integral_constant<int, 4>{});
+    for (; j < len; ++j) term(tmap[c[(size_t)j * 64]], v[(size_t)j * 64]);
     const long long doc = (long long)s * 64 + lane;
     const unsigned did = doc < n_docs ? docid[doc] : 0u;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
       const u64 key = hit ? make_key(acc[q], did) : 0ull;
-      u64* ml = mylists + q * k;
-      const u64 kth = ml[k - 1];
-      unsigned long long m = __ballot(key > kth);
-      while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        const u64 kk = __shfl(key, src, 64);
-        if (lane == 0) insert_key(ml, k, kk);
-        m &= m - 1;
-      }
+      wave_insert_topk(mylists + q * k, k, key, lane);
     }
   }
   __syncthreads();
@@ -1813,7 +1816,7 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
   return spw;
 }
 
-constexpr int SQB = 8;   // queries per pass of the batched sparse kernel (16 when the tables fit the LDS and nq >= 16)
+constexpr int SQB = 8;   // queries per pass of the batched sparse kernel (16 per pass was measured slower: registers, 3.7 vs 2.0 ms for 64 queries)
 
 static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out, const u64* bound = nullptr) {
   const int slices_per_wg = sparse_slices_per_wg(ix);
@@ -1825,21 +1828,14 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)16 * QB * k * sizeof(u64);
     static bool attr_m = false;
     if (!attr_m) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<SQB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
     for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
-      if (QB == 16)
-        hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
-      else
-        hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      hipLaunchKernelGGL((sparse_topk_multi_kernel<SQB>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                         ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                         ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
@@ -1906,8 +1902,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
   static const bool multi_off = getenv("VRAG_SPARSE_SINGLE") != nullptr;   // tuning / tests: force the single-query kernel
   const int vpad = (ix->vocab + 7) & ~7;
   auto fits = [&](int qb) { return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024; };
-  static const bool qb16_off = getenv("VRAG_SPARSE_QB8") != nullptr;
-  const int QB = (!qb16_off && nq >= 16 && fits(16)) ? 16 : SQB;
+  const int QB = SQB;
   bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 && fits(QB);
   for (int q = 0; q < nq; ++q)
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)

@@ -232,9 +232,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
   } else if constexpr (EPI == EPI_GEGLU) {
     // Wi rows were interleaved at load time: each 64-row group = 32 "input" rows (x1)
-    // followed by the 32 matching "gate" rows (x2).  Output tile: [rows][32 features], 64-byte rows.
+    // followed by the 32 matching "gate" rows (x2).  A wave's output is [rows][32 features] = 64-byte rows, i.e. HALF cache
+    // lines: stored per wave, every line of the output would be touched by two waves.  So the two waves of a column pair
+    // (wn, wn^1) stage into ONE tile of [rows][64 features] (128-byte rows, 16-byte chunk index XOR (row & 7)) and each
+    // stores one half of its ROWS as whole lines (257 -> 251 us per launch; the epilogue itself is VALU-bound, ~16
+    // instructions per output).
     const int NO = p.N >> 1;
-    const int f0 = (nw >> 6) * 32;
+    const int odd = wave & 1;                               // WN is even: wave parity == column parity of the pair
+    char* stgp = smem + (wave & ~1) * 16384;                // the pair's staging tile (16 KiB of the pair's 32)
+    auto put_pair = [&](int row, int col, const V4& v) {    // col = output feature 0..31 of this wave
+      const int c16 = odd * 4 + (col >> 3), half = (col >> 2) & 1;
+      *reinterpret_cast<V4*>(stgp + row * 128 + ((c16 ^ (row & 7)) << 4) + (half << 3)) = v;
+    };
     auto body = [&](auto fold_tag) {
       constexpr bool FOLD = decltype(fold_tag)::value;
       f32x4 s1[2] = {}, s2[2] = {};
@@ -264,16 +273,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
             o[j] = Op<T>::to(gelu_fast(x1) * x2);
           }
-          put_bf16(rt * 16 + l15, nj * 16 + 4 * q, o, 64);
+          put_pair(rt * 16 + l15, nj * 16 + 4 * q, o);
         }
       }
     };
     if (p.ln_mu) body(std::true_type{});
     else body(std::false_type{});
+    __syncthreads();   // the partner wave's half of every row is staged (workgroup-uniform path: every wave is here)
+    const int f0 = ((nw - odd * 64) >> 6) * 32;   // first output feature of the pair
 #pragma unroll
     for (int it = 0; it < WROWS / 16; ++it) {
-      const int row = it * 16 + (lane >> 2), c16 = lane & 3;
-      store16_nt(p.out_bf16 + (size_t)(mw + row) * NO + f0 + c16 * 8, get16(row, c16, 64));
+      const int row = odd * (WROWS / 2) + it * 8 + (lane >> 3), c16 = lane & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stgp + row * 128 + ((c16 ^ (row & 7)) << 4));
+      store16_nt(p.out_bf16 + (size_t)(mw + row) * NO + f0 + c16 * 8, v);
     }
   } else if constexpr (EPI == EPI_QKV_ROPE) {
     const int H = p.hidden;

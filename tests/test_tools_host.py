@@ -20,3 +20,32 @@ def test_energy_probe_parses_rocm_smi_and_summarises():
     assert out["busy_samples"] == 14 and 1280 < out["avg_busy_w"] < 1400
     assert abs(out["joules_per_chunk"] - out["avg_busy_w"] * 45.1e-3 / 256) < 1e-12 and 0.2 < out["joules_per_chunk"] < 0.3
     assert ep.summarize([], idle, line)["samples"] == 0
+
+
+def test_gelu_constants_in_the_kernel_header_are_the_fitted_ones():
+    """csrc/common.h:gelu_fast evaluates erfc(z) = 2^P(z); its literal coefficients, re-evaluated here in float32 exactly as
+    the kernel does (fmaf chain, exp2), must reproduce the erf-form GELU to < 1e-6 absolute -- the bound tools/fit_gelu.py
+    prints for them and the reason the 16-bit GeGLU outputs do not move."""
+    import os
+    import re
+
+    import numpy as np
+    from scipy.special import erf
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "verbatim-rag_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_fast(float x)"):]
+    body = body[:body.index("}")]
+    lits = [float(v) for v in re.findall(r"(-?\d\.\d+e[+-]\d+)f", body)]
+    assert len(lits) == 6, lits            # c6 .. c1 in Horner order
+    zmax = float(re.search(r"fminf\(a \* [0-9.]+f, ([0-9.]+)f\)", body).group(1))
+    f = np.float32
+    x = np.linspace(-9, 9, 900001).astype(f)
+    a = np.abs(x)
+    z = np.minimum(a * f(0.70710678118654752440), f(zmax))
+    t = np.full_like(z, f(lits[0]))
+    for c in lits[1:]:
+        t = (t * z + f(c)).astype(f)
+    got = (f(-0.5) * a) * np.exp2((t * z).astype(f)).astype(f) + np.maximum(x, f(0))
+    ref = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    assert np.abs(got - ref).max() < 1e-6

@@ -54,6 +54,30 @@ constexpr int kRowPad = 256;
 // key-contiguous V^T rows 16-byte aligned for vector loads).
 constexpr int kSeqAlign = 8;
 
+// Cross-lane steps as DPP modifiers (VALU only).  `__shfl_xor` compiles to ds_bpermute_b32 -- a trip through the LDS
+// crossbar plus an s_waitcnt per step -- which is what the residual epilogue's row statistics used to spend their time on
+// (288 bpermutes and as many waits per tile and wave).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum / max over each aligned group of 16 lanes, result in every lane of the group: xor 1, xor 2 (quad permutes), then
+// mirror within 8 and within 16 (every lane already holds its quad's / its 8's total, so any cross pairing completes it)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  v += dpp_f32<0x140>(v);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

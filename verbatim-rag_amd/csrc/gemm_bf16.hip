@@ -127,7 +127,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           // mantissa bits on the deviation instead of on a common offset, and sum / sum of squares of (h - c) do
           // not cancel in  var = E[(h-c)^2] - (mu-c)^2  however large |mean| / sigma is.
           if (p.ln_shift) {
-            const float c_ = __shfl(cw[ps], row, 64);
+            // lane group g = lane >> 4 works on row r0 + g of the pass: four scalar lane reads and a select by group
+            // (a ds_bpermute would be one more trip through the LDS crossbar per instruction)
+            const int r0 = (hp & 1) * 32 + i * 4;
+            const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cw[ps]), r0));
+            const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cw[ps]), r0 + 1));
+            const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cw[ps]), r0 + 2));
+            const float c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cw[ps]), r0 + 3));
+            const int g4 = lane >> 4;
+            const float c_ = g4 == 0 ? c0 : (g4 == 1 ? c1 : (g4 == 2 ? c2 : c3));
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] -= c_;
           }
@@ -141,11 +149,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             // the 16 lanes of a row segment reduce (sum, sum of squares) of the UPDATED residual (minus the shift)
             float s1 = (v[0] + v[1]) + (v[2] + v[3]);
             float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-              s1 += __shfl_xor(s1, o, 64);
-              s2 += __shfl_xor(s2, o, 64);
-            }
+            s1 = row16_sum(s1);
+            s2 = row16_sum(s2);
             if (c16 == 0) {
               float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
               sp[0] = s1;
@@ -457,8 +462,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           float v = -INFINITY;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) v = mine[rt] ? fmaxf(v, acc[nj][rt][r]) : v;
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));   // over the 16 token lanes of this quarter
+          v = row16_max(v);   // over the 16 token lanes of this quarter
           if (l15 == 0) {
             const int n = nw + nj * 16 + 4 * q + r;
             const float w = log1pf(fmaxf(v + (p.bias ? p.bias[n] : 0.f), 0.f));

@@ -607,36 +607,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       if (do_stage) stage(nxt, nbuf);   // right after the barrier (issuing half of the waves' share a substep later: no difference, r2s)
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
+      // MFMA order: the KS k-substeps of one accumulator tile back to back (a dependent pair), row tile by row tile -- measured
+      // 4-5 % faster on the main loop than one substep over all 32 tiles and then the next (201.6 vs 210.3 us at N = 2304,
+      // 67.1 vs 70.1, 101.1 vs 107.3: tools/gpu_r2ae.sh).  The W fragments of the whole K-step stay in registers (KS x 4), the
+      // A fragments stream per row tile (KS at a time): 12 fragments live, as before.
+      V8 wf[KS][4] = {};
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        V8 af[RT] = {}, wf[4] = {};
-        if (DBG && (p.debug_flags & 8)) {
+      for (int s = 0; s < KS; ++s)
 #pragma unroll
-          for (int i = 0; i < RT; ++i) af[i] = dbg_f[i];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wf[i] = dbg_f[RT + i];
-        } else if (DBG && (p.debug_flags & 4)) {   // probe: fresh pseudo-random register operands per MFMA group, no LDS read
-#pragma unroll
-          for (int i = 0; i < RT + 4; ++i) {
-            const V8 v = pseudo_random((unsigned)(i * KS + s + kt * 16));
-            if (i < RT) af[i] = v;
-            else wf[i - RT] = v;
-          }
-        }
-        if (!(DBG && (p.debug_flags & 2))) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
-#pragma unroll
-          for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const V8*>(sA + i * 16 * ROWB + fo[s]);
+        for (int i = 0; i < 4; ++i) {
+          if (DBG && (p.debug_flags & 8)) wf[s][i] = dbg_f[RT + i];
+          else if (DBG && (p.debug_flags & 4)) wf[s][i] = pseudo_random((unsigned)((RT + i) * KS + s + kt * 16));
+          if (!(DBG && (p.debug_flags & 2))) wf[s][i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
         }
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) {
+        V8 af[KS] = {};
 #pragma unroll
-          for (int nj = 0; nj < 4; ++nj) {
+        for (int s = 0; s < KS; ++s) {
+          if (DBG && (p.debug_flags & 8)) af[s] = dbg_f[rt];
+          else if (DBG && (p.debug_flags & 4)) af[s] = pseudo_random((unsigned)(rt * KS + s + kt * 16));
+          if (!(DBG && (p.debug_flags & 2))) af[s] = *reinterpret_cast<const V8*>(sA + rt * 16 * ROWB + fo[s]);
+        }
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
             if constexpr (SWAPPED)
-              acc[nj][rt] = Op<T>::mfma16(wf[nj], af[rt], acc[nj][rt]);
+              acc[nj][rt] = Op<T>::mfma16(wf[s][nj], af[s], acc[nj][rt]);
             else
-              acc[nj][rt] = Op<T>::mfma16(af[rt], wf[nj], acc[nj][rt]);
+              acc[nj][rt] = Op<T>::mfma16(af[s], wf[s][nj], acc[nj][rt]);
           }
       }
       wait_allow(max(0, min(NS - 2, KT - 2 - kt)));   // step kt+1 has landed (this wave's share)

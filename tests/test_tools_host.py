@@ -49,3 +49,26 @@ def test_gelu_constants_in_the_kernel_header_are_the_fitted_ones():
     got = (f(-0.5) * a) * np.exp2((t * z).astype(f)).astype(f) + np.maximum(x, f(0))
     ref = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
     assert np.abs(got - ref).max() < 1e-6
+
+
+def test_committed_bench_line_follows_the_output_contract():
+    """profiles/r02_bench_line.json is what `python bench.py` printed on the GPU box: the keys the driver and the judge read must
+    be there with the right kinds (a guard against silently dropping one from bench.py's line)."""
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r02_bench_line.json")).read().strip().splitlines()[-1])
+    for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], kind), key
+    assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md holds no published number
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and "workload" in line["config"]
+    assert abs(line["value"] - 256 * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]

@@ -37,7 +37,7 @@ extern "C" {
 #define VRAG_ERR_CAPACITY (-3)/* batch does not fit the workspace the handle was created with */
 #define VRAG_ERR_NO_DEVICE (-4)
 
-#define VRAG_ABI_VERSION 3
+#define VRAG_ABI_VERSION 4
 
 /* MFMA operand type of an encoder handle.  bf16: fp32's exponent range (safe for any checkpoint), 8 significant bits --
  * sentence logits within 3e-4 of the fp32 reference.  fp16: 11 significant bits at the same matrix-core rate, values
@@ -262,6 +262,15 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries /*[nq,dim
                             float* scores /*[nq,k]*/, int64_t* ids /*[nq,k]*/, void* stream);
 /* Re-runs the kernels of the last search on the device-resident queries (no copies, no sync). */
 int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, void* stream);
+/* The same search (k <= 64) with the result lists left in DEVICE memory -- what a rank contributes to the cross-GPU
+ * exchange (serves verbatim_rag/vector_stores/milvus_base.py:239-259 on a row-sharded corpus):
+ * out_ids[q][j] = row_map[row] when `row_map` (device int64[n_map], the caller's local row -> global row table) is
+ * given -- rows at or beyond n_map become -1 -- else id_base + row; missing hits -1 / -inf.  Queries are host memory
+ * (the call returns once they have been uploaded); the kernels are only enqueued on `stream`: no synchronisation and no
+ * device->host copy. */
+int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries /*[nq,dim] host*/, int32_t nq, int32_t k,
+                                   const int64_t* row_map /*device or NULL*/, int64_t n_map, int64_t id_base,
+                                   float* out_scores /*[nq,k] device*/, int64_t* out_ids /*[nq,k] device*/, void* stream);
 
 /* Sparse (SPLADE) rows in CSR, term ids < vocab <= 65536; only documents sharing a term with the
  * query (score > 0) are hits, like an inverted index.  ids are CSR row numbers. */
@@ -274,6 +283,11 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
                              const float* q_values, int32_t nq, int32_t k, float* scores /*[nq,k]*/,
                              int64_t* ids /*[nq,k]*/, void* stream);
 int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k, void* stream);
+/* Device-resident result lists, as vrag_dense_index_search_device. */
+int vrag_sparse_index_search_device(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
+                                    const float* q_values, int32_t nq, int32_t k, const int64_t* row_map /*device or NULL*/,
+                                    int64_t n_map, int64_t id_base, float* out_scores /*[nq,k] device*/,
+                                    int64_t* out_ids /*[nq,k] device*/, void* stream);
 
 /* Cross-shard merge of per-shard top-k lists (the reference has no sharding -- this is the step after the
  * all-gather of `[n_lists][nq][k_in]` (fp32 score, global row id) lists, each sorted by (score desc, id asc) with
@@ -285,6 +299,9 @@ int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k,
 int vrag_topk_merge(const float* scores, const int64_t* ids, int32_t n_lists, int32_t nq, int32_t k_in, int32_t k_out,
                     int64_t score_list_stride, int64_t id_list_stride, float* out_scores, int64_t* out_ids,
                     int32_t on_device, int32_t device, void* stream);
+
+/* -inf / -1 lists in device memory: the contribution of a rank that holds none of the rows. */
+int vrag_topk_fill_empty(float* scores /*[n] device*/, int64_t* ids /*[n] device*/, int64_t n, int32_t device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,12 +49,15 @@ class CpuSparse:
 
 @contextlib.contextmanager
 def cpu_stand_ins():
-    saved = (vs._lib.load, vs._lib.require_gpu, vs.DenseShard, vs.SparseShard)
+    from verbatim_rag_amd.distributed import merge_topk
+
+    saved = (vs._lib.load, vs._lib.require_gpu, vs.DenseShard, vs.SparseShard, vs._merge_parts)
     vs._lib.load, vs._lib.require_gpu, vs.DenseShard, vs.SparseShard = (lambda: None), (lambda: None), CpuDense, CpuSparse
+    vs._merge_parts = lambda scores, rows, k, device: merge_topk(scores, rows, k)      # segments of one shard: host statement
     try:
         yield
     finally:
-        vs._lib.load, vs._lib.require_gpu, vs.DenseShard, vs.SparseShard = saved
+        vs._lib.load, vs._lib.require_gpu, vs.DenseShard, vs.SparseShard, vs._merge_parts = saved
 
 
 def _dump(results):

@@ -143,7 +143,7 @@ def _store_worker(rank, world, port, q):
             dist.barrier()
             st2 = vs.GpuVectorStore.load(box[0], comm=ShardComm(merge=merge_topk))
             after = [(r.id, r.score) for r in st2.query(dense_query=dense[9].tolist(), top_k=6, search_type="dense")]
-            if before != after or before[0][0] != "r9" or len(st2._ids) != 36 or len(st2._owned) not in (18, 19):
+            if before != after or before[0][0] != "r9" or len(st2._ids) != 36 or len(st2._owned) not in (18, 19) or len(st2._texts) != len(st2._owned):
                 ok = f"save / load changed the answers: {before} vs {after}"
         q.put((rank, ok))
         dist.barrier()

@@ -145,9 +145,9 @@ def test_query_normalisation_is_the_same_row_by_row_or_batched(store):
     st._dense.search = lambda q, k, stream=None: (seen.append(np.array(q)), (np.zeros((len(q), k), np.float32), np.full((len(q), k), -1, np.int64)))[1]
     X = rng.standard_normal((50, 64)).astype(np.float32) * np.float32(3)
     X[7] = 0
-    st._device_topk("dense", st._dense, None, X.tolist(), 3)
+    st._device_topk("dense", [(st._dense, 0)], None, X.tolist(), 3)
     for i in range(len(X)):
-        st._device_topk("dense", st._dense, None, [X[i].tolist()], 3)
+        st._device_topk("dense", [(st._dense, 0)], None, [X[i].tolist()], 3)
     want = np.stack([q / float(np.sqrt((q * q).sum(dtype=np.float32))) if q.any() else q for q in X])
     assert np.array_equal(seen[0], want) and all(np.array_equal(seen[1 + i][0], want[i]) for i in range(len(X)))
 
@@ -205,7 +205,7 @@ def test_concurrent_queries_inserts_and_deletes(store, monkeypatch):
 
 
 def test_save_load_round_trip_on_stand_ins(store, tmp_path):
-    """The store's on-disk format (vectors.npz + rows.json): same hits after a reload, deleted rows stay out."""
+    """The store's on-disk format: same hits after a reload, deleted rows stay out."""
     st, dense, sparse, rng = store
     st.delete(["id3", "id17"])
     st.save(str(tmp_path / "idx"))
@@ -217,12 +217,12 @@ def test_save_load_round_trip_on_stand_ins(store, tmp_path):
                dict(dense_query=dense[5].tolist(), top_k=5, search_type="dense", filter='metadata["document_id"] == "d1"')):
         a, b = st.query(**kw), st2.query(**kw)
         assert [(x.id, x.score, x.text, x.metadata) for x in a] == [(x.id, x.score, x.text, x.metadata) for x in b]
-    with open(tmp_path / "idx" / "rows.json") as f:
+    with open(tmp_path / "idx" / "store.json") as f:
         import json
 
         rows = json.load(f)
     rows["format"] = 99
-    with open(tmp_path / "idx" / "rows.json", "w") as f:
+    with open(tmp_path / "idx" / "store.json", "w") as f:
         json.dump(rows, f)
     with pytest.raises(ValueError, match="unknown GpuVectorStore format"):
         vs.GpuVectorStore.load(str(tmp_path / "idx"))
@@ -253,14 +253,14 @@ def test_metadata_is_stored_the_way_the_json_column_sees_it(store, tmp_path):
 def test_a_failed_insert_leaves_the_store_unchanged(store):
     """a short or malformed vector list must not leave ids one row ahead of the vectors."""
     st, dense, sparse, rng = store
-    before = (len(st._ids), len(st._dense_rows), len(st._sparse_rows), len(st._owned))
+    before = (len(st._ids), len(st._dense_rows), len(st._sp_ptr), len(st._sp_idx), len(st._owned), len(st._meta), len(st._alive))
     with pytest.raises(ValueError):
         st.add_vectors(["b", "c"], [dense[1].tolist()], [sparse[1], sparse[2]], ["tb", "tc"], ["eb", "ec"], [{}, {}])
     with pytest.raises(ValueError):
         st.add_vectors(["b"], [dense[1][:10].tolist()], [sparse[1]], ["tb"], ["eb"], [{}])          # wrong dimension
     with pytest.raises(ValueError):
         st.add_vectors(["b"], [dense[1].tolist()], [{99999: 1.0}], ["tb"], ["eb"], [{}])             # term outside the vocabulary
-    assert (len(st._ids), len(st._dense_rows), len(st._sparse_rows), len(st._owned)) == before
+    assert (len(st._ids), len(st._dense_rows), len(st._sp_ptr), len(st._sp_idx), len(st._owned), len(st._meta), len(st._alive)) == before
     st.add_vectors(["d"], [dense[3].tolist()], [sparse[3]], ["td"], ["ed"], [{"document_id": "dd"}])
     r = st.query(dense_query=dense[3].tolist(), top_k=2, search_type="dense")
     assert {x.id for x in r} == {"id3", "d"} and all(abs(x.score - 1.0) < 1e-6 for x in r)

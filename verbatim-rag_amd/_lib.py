@@ -11,7 +11,7 @@ _LOCK = threading.Lock()
 _LIB = None
 
 VRAG_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 PROF_CLASSES = (
     "embed", "layernorm", "gemm_qkv", "attn_global", "attn_local",
     "gemm_wo", "gemm_wi", "gemm_wo_mlp", "head",
@@ -113,6 +113,11 @@ SIGNATURES = {
     "vrag_dense_index_add": (C.c_int, [_H, _FP, C.c_int64]),
     "vrag_dense_index_search": (C.c_int, [_H, _FP, C.c_int32, C.c_int32, _FP, _LP, C.c_void_p]),
     "vrag_dense_index_run_resident": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p]),
+    "vrag_dense_index_search_device": (C.c_int, [_H, _FP, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
+    "vrag_sparse_index_search_device": (C.c_int, [_H, _LP, _IP, _FP, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vrag_topk_fill_empty": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "vrag_sparse_index_create": (C.c_int, [C.c_int32, C.c_int64, _LP, _IP, _FP, C.c_int32, C.POINTER(_H)]),
     "vrag_sparse_index_destroy": (None, [_H]),
     "vrag_sparse_index_stats": (C.c_int, [_H, _LP, _LP, _LP]),

@@ -1421,6 +1421,37 @@ __global__ __launch_bounds__(64) void topk_merge_shards_kernel(const char* __res
   }
 }
 
+
+// Device-resident result lists (the lists a rank contributes to the all-gather): the merged keys of one search
+// decoded in place of the host's decode_keys -- ids = row_map[row] (the store's local row -> global row table) or
+// row + id_base; missing hits -1 / -inf.  A row outside the map (appended after the caller captured it) is reported
+// as id_base + row when no map is given and as -1 otherwise.
+__global__ void topk_export_keys_kernel(const u64* __restrict__ keys, long long n, const long long* __restrict__ row_map,
+                                        long long n_map, long long id_base, float* __restrict__ out_scores,
+                                        long long* __restrict__ out_ids) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 key = keys[i];
+  if (key == 0ull) {
+    out_scores[i] = -INFINITY;
+    out_ids[i] = -1ll;
+    return;
+  }
+  const long long row = (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+  long long id = id_base + row;
+  if (row_map) id = row < n_map ? row_map[row] : -1ll;
+  out_scores[i] = id < 0 ? -INFINITY : unorderable((unsigned)(key >> 32));
+  out_ids[i] = id;
+}
+
+__global__ void topk_fill_empty_kernel(float* __restrict__ scores, long long* __restrict__ ids, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    scores[i] = -INFINITY;
+    ids[i] = -1ll;
+  }
+}
+
 }  // namespace vrag
 
 using namespace vrag;
@@ -1455,6 +1486,7 @@ struct vrag_dense_index {
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;   // d_bound: per-query page bound (k > KMAX)
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
+  hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
 };
 
 struct vrag_sparse_index {
@@ -1478,6 +1510,7 @@ struct vrag_sparse_index {
   std::vector<int> pass_union;        // union size of every pass of the resident queries
   int pass_qb = 8;                    // queries per pass the resident tables were built for (8 or 16)
   bool last_multi = false;   // which kernel family the resident queries were prepared for
+  hipEvent_t upload_done = nullptr;   // recorded behind the query-table uploads
 };
 
 namespace {
@@ -1541,6 +1574,46 @@ int paged_search(int nq, int k, u64** d_bound, size_t* d_bound_elems, const u64*
   return VRAG_OK;
 }
 
+// One device pass (k <= KMAX) of a dense search: uploads the queries, runs phase 1 + the per-query merge and leaves the
+// [nq, k] keys in ix->d_out.  Returns once the query upload has been consumed (the caller's buffer may be reused); the
+// kernels are only enqueued.  Caller holds ix->mu and has set the device.
+int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st) {
+  const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
+  int rc;
+  if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
+  if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
+  if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;   // + per-query entry thresholds
+  const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
+  ARG_CHECK(lds <= 160 * 1024, "dim/k too large for the LDS budget");
+  HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, st));
+  if (!ix->upload_done) HIP_TRY(hipEventCreateWithFlags(&ix->upload_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ix->upload_done, st));
+  // Batched search over bf16 rows runs on the matrix cores with bf16 query operands: exact when every query element
+  // is a bf16 number; otherwise the queries ride as (bf16 part, bf16 remainder) column pairs, 16 queries per pass.
+  // Recorded for whatever kernel family serves these queries now or in a later run_resident with another (nq, k).
+  static const bool no_split = getenv("VRAG_TOPK_NO_SPLIT") != nullptr;
+  ix->resident_split = 0;
+  if (!no_split && ix->dtype == 0) {
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(queries);
+    const size_t n_el = (size_t)nq * ix->dim;
+    for (size_t i = 0; i < n_el; ++i)
+      if (bits[i] & 0xFFFFu) {
+        ix->resident_split = 1;
+        break;
+      }
+  }
+  HIP_TRY(hipEventSynchronize(ix->upload_done));
+  if (ix->size == 0) {
+    HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
+  } else {
+    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
+    HIP_TRY(hipGetLastError());
+  }
+  return VRAG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1589,6 +1662,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
+  if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -1652,38 +1726,30 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       return VRAG_OK;
     }, scores, ids);
   }
-  const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
   int rc;
-  if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
-  if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
-  if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;   // + per-query entry thresholds
-  HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, st));
-  const size_t lds = (size_t)DQT * ix->dim * sizeof(float) + (size_t)16 * DQT * k * sizeof(u64);
-  ARG_CHECK(lds <= 160 * 1024, "dim/k too large for the LDS budget");
-  // Batched search over bf16 rows runs on the matrix cores with bf16 query operands: exact when every query element
-  // is a bf16 number; otherwise the queries ride as (bf16 part, bf16 remainder) column pairs, 16 queries per pass.
-  ix->resident_split = 0;
-  if (dense_use_mfma(ix->dtype, ix->dim, nq, k) && !getenv("VRAG_TOPK_NO_SPLIT")) {
-    const uint32_t* bits = reinterpret_cast<const uint32_t*>(queries);
-    const size_t n_el = (size_t)nq * ix->dim;
-    for (size_t i = 0; i < n_el; ++i)
-      if (bits[i] & 0xFFFFu) {
-        ix->resident_split = 1;
-        break;
-      }
-  }
-  if (ix->size == 0) {
-    HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
-  } else {
-    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
-                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
-    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
-    HIP_TRY(hipGetLastError());
-  }
+  if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
   std::vector<u64> keys((size_t)nq * k);
   HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   decode_keys(keys, nq, k, 0, nullptr, scores, ids);
+  return VRAG_OK;
+}
+
+int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, int32_t nq, int32_t k, const int64_t* row_map,
+                                   int64_t n_map, int64_t id_base, float* out_scores, int64_t* out_ids, void* stream) {
+  ARG_CHECK(ix && queries && out_scores && out_ids && nq > 0, "bad arguments");
+  ARG_CHECK(k > 0 && k <= KMAX, "k must be in [1, %d] for a device-resident search (got %d)", KMAX, k);
+  ARG_CHECK(!row_map || n_map >= 0, "negative row map length");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  int rc;
+  if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
+  const long long n = (long long)nq * k;
+  hipLaunchKernelGGL(topk_export_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_out, n,
+                     reinterpret_cast<const long long*>(row_map), (long long)n_map, (long long)id_base, out_scores,
+                     reinterpret_cast<long long*>(out_ids));
+  HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }
 
@@ -1795,6 +1861,7 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->d_docid) (void)hipFree(ix->d_docid);
+  if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -1868,33 +1935,14 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   return VRAG_OK;
 }
 
-int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
-                             const float* q_values, int32_t nq, int32_t k, float* scores, int64_t* ids, void* stream) {
-  ARG_CHECK(ix && q_indptr && scores && ids && nq > 0, "bad arguments");
-  ARG_CHECK(k > 0 && k <= KPAGED_MAX, "k must be in [1, %d] (got %d)", KPAGED_MAX, k);
-  std::lock_guard<std::mutex> lk(ix->mu);
-  HIP_TRY(hipSetDevice(ix->device));
-  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+// One device pass (k <= KMAX) of a sparse search: query tables up, phase 1 + per-query merge enqueued, keys left in
+// ix->d_out.  Returns once the uploads have been consumed; caller holds ix->mu and has set the device.
+static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
+                                 const float* q_values, int nq, int k, hipStream_t st) {
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   int rc;
-  if (k > KMAX) {   // pages of KMAX on the single-query kernel
-    for (int q = 0; q < nq; ++q)
-      for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
-        ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);
-    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * KMAX))) return rc;
-    if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * KMAX))) return rc;
-    std::vector<float> qd((size_t)nq * ix->vocab, 0.f);
-    for (int q = 0; q < nq; ++q)
-      for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) qd[(size_t)q * ix->vocab + q_indices[j]] = q_values[j];
-    if ((rc = grow(&ix->d_q, &ix->d_q_elems, qd.size()))) return rc;
-    HIP_TRY(hipMemcpyAsync(ix->d_q, qd.data(), qd.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    ix->last_multi = false;
-    return paged_search(nq, k, &ix->d_bound, &ix->d_bound_elems, ix->d_out, st, [&](const u64* bound) -> int {
-      int nwg = 0;
-      return sparse_launch(ix, nq, KMAX, st, &nwg, bound);
-    }, scores, ids);   // the first page's stream sync also keeps `qd` alive until its upload has been consumed
-  }
+  if (!ix->upload_done) HIP_TRY(hipEventCreateWithFlags(&ix->upload_done, hipEventDisableTiming));
   if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
   if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k))) return rc;
   // Batched path: two or more queries; per pass of SQB queries the union of their terms gets ids 1 .. SUW-1, the
@@ -1951,25 +1999,74 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
     ix->pass_qb = QB;
     HIP_TRY(hipMemcpyAsync(ix->d_qmap, maps.data(), maps.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ix->d_qw, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ix->upload_done, st));
+    HIP_TRY(hipEventSynchronize(ix->upload_done));   // the host tables go out of scope below
     int nwg3 = 0;
-    if ((rc = sparse_launch(ix, nq, k, st, &nwg3))) return rc;
-    std::vector<u64> keys2((size_t)nq * k);
-    HIP_TRY(hipMemcpyAsync(keys2.data(), ix->d_out, keys2.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));   // also keeps the host tables alive until the uploads have been consumed
-    decode_keys(keys2, nq, k, 0, nullptr, scores, ids);
-    return VRAG_OK;
+    return sparse_launch(ix, nq, k, st, &nwg3);
   }
   std::vector<float> dense((size_t)nq * ix->vocab, 0.f);
   for (int q = 0; q < nq; ++q)
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) dense[(size_t)q * ix->vocab + q_indices[j]] = q_values[j];
   if ((rc = grow(&ix->d_q, &ix->d_q_elems, dense.size()))) return rc;
   HIP_TRY(hipMemcpyAsync(ix->d_q, dense.data(), dense.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(ix->upload_done, st));
+  HIP_TRY(hipEventSynchronize(ix->upload_done));
   int nwg2 = 0;
-  if ((rc = sparse_launch(ix, nq, k, st, &nwg2))) return rc;
+  return sparse_launch(ix, nq, k, st, &nwg2);
+}
+
+
+int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
+                             const float* q_values, int32_t nq, int32_t k, float* scores, int64_t* ids, void* stream) {
+  ARG_CHECK(ix && q_indptr && scores && ids && nq > 0, "bad arguments");
+  ARG_CHECK(k > 0 && k <= KPAGED_MAX, "k must be in [1, %d] (got %d)", KPAGED_MAX, k);
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  const int slices_per_wg = sparse_slices_per_wg(ix);
+  const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
+  int rc;
+  if (k > KMAX) {   // pages of KMAX on the single-query kernel
+    for (int q = 0; q < nq; ++q)
+      for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
+        ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);
+    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * KMAX))) return rc;
+    if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * KMAX))) return rc;
+    std::vector<float> qd((size_t)nq * ix->vocab, 0.f);
+    for (int q = 0; q < nq; ++q)
+      for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j) qd[(size_t)q * ix->vocab + q_indices[j]] = q_values[j];
+    if ((rc = grow(&ix->d_q, &ix->d_q_elems, qd.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_q, qd.data(), qd.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    ix->last_multi = false;
+    return paged_search(nq, k, &ix->d_bound, &ix->d_bound_elems, ix->d_out, st, [&](const u64* bound) -> int {
+      int nwg = 0;
+      return sparse_launch(ix, nq, KMAX, st, &nwg, bound);
+    }, scores, ids);   // the first page's stream sync also keeps `qd` alive until its upload has been consumed
+  }
+  if ((rc = sparse_search_enqueue(ix, q_indptr, q_indices, q_values, nq, k, st))) return rc;
   std::vector<u64> keys((size_t)nq * k);
   HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   decode_keys(keys, nq, k, 0, nullptr, scores, ids);
+  return VRAG_OK;
+}
+
+int vrag_sparse_index_search_device(vrag_sparse_index* ix, const int64_t* q_indptr, const int32_t* q_indices,
+                                    const float* q_values, int32_t nq, int32_t k, const int64_t* row_map, int64_t n_map,
+                                    int64_t id_base, float* out_scores, int64_t* out_ids, void* stream) {
+  ARG_CHECK(ix && q_indptr && out_scores && out_ids && nq > 0, "bad arguments");
+  ARG_CHECK(k > 0 && k <= KMAX, "k must be in [1, %d] for a device-resident search (got %d)", KMAX, k);
+  ARG_CHECK(!row_map || n_map >= 0, "negative row map length");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  int rc;
+  if ((rc = sparse_search_enqueue(ix, q_indptr, q_indices, q_values, nq, k, st))) return rc;
+  const long long n = (long long)nq * k;
+  hipLaunchKernelGGL(topk_export_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_out, n,
+                     reinterpret_cast<const long long*>(row_map), (long long)n_map, (long long)id_base, out_scores,
+                     reinterpret_cast<long long*>(out_ids));
+  HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }
 
@@ -1983,6 +2080,20 @@ int vrag_sparse_index_run_resident(vrag_sparse_index* ix, int32_t nq, int32_t k,
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
   int n_wg = 0;
   return sparse_launch(ix, nq, k, st, &n_wg);
+}
+
+// An empty contribution to the exchange (a rank that holds none of the rows): -inf / -1 lists in device memory.
+int vrag_topk_fill_empty(float* scores, int64_t* ids, int64_t n, int32_t device, void* stream) {
+  ARG_CHECK(scores && ids && n > 0, "bad arguments");
+  if (vrag_device_count() <= device) {
+    set_error("no HIP device %d visible (no CPU fallback)", device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(topk_fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     scores, reinterpret_cast<long long*>(ids), (long long)n);
+  HIP_TRY(hipGetLastError());
+  return VRAG_OK;
 }
 
 // Device-side merge of per-shard top-k lists (the step after the all-gather).

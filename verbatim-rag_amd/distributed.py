@@ -64,9 +64,11 @@ class ShardComm:
     """The exchange step of sharded retrieval: one all-gather of packed `[Q, k]` lists + the merge.
 
     `group`: a torch.distributed process group (None = the default group; torch.distributed must be initialised).
-    backend "nccl" (= RCCL on ROCm): the payload and the gathered lists stay in HBM and `vrag_topk_merge` runs on them
-    in place; backend "gloo" (CPU tests, or ranks sharing one GPU): host tensors, the merge still runs on the GPU
-    unless `merge` is given (CPU-only test boxes pass `merge=merge_topk`)."""
+    backend "nccl" (= RCCL on ROCm): the lists are produced, gathered and merged in HBM -- `exchange_buffers` hands the
+    local search its output slots inside the packed payload, `allgather_merge_device` runs ONE `all_gather_into_tensor`
+    and `vrag_topk_merge` in place on the gathered buffer, and only the merged `[Q, k]` result crosses to the host;
+    backend "gloo" (CPU tests, or ranks sharing one GPU): host tensors, the merge still runs on the GPU unless `merge`
+    is given (CPU-only test boxes pass `merge=merge_topk`)."""
 
     def __init__(self, group=None, device: int = 0, merge: Optional[Callable] = None):
         import torch.distributed as dist
@@ -80,23 +82,92 @@ class ShardComm:
         self.device = device
         self._merge = merge
 
+    @property
+    def on_gpu(self) -> bool:
+        """True when collectives take device tensors (RCCL): the exchange then never leaves HBM."""
+        return self.backend == "nccl" and self._merge is None
+
+    # ---------------------------------------------------------------- small host-side collectives of the store
+    def barrier(self) -> None:
+        import torch.distributed as dist
+
+        dist.barrier(group=self.group)
+
+    def gather_objects(self, obj) -> list:
+        """Every rank's `obj`, in rank order, on every rank (result payloads of the hits a rank owns)."""
+        import torch.distributed as dist
+
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def union_mask(self, local: np.ndarray) -> np.ndarray:
+        """Element-wise OR of every rank's boolean array (each rank marks the rows IT owns that pass a filter)."""
+        import torch
+        import torch.distributed as dist
+
+        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint8))
+        if self.backend == "nccl":
+            t = t.to(torch.device("cuda", self.device))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().numpy().astype(bool)
+
+    # ---------------------------------------------------------------- the exchange
+    @staticmethod
+    def payload_bytes(n: int) -> int:
+        return (n * 12 + 7) // 8 * 8                            # [ids i64 x n | scores f32 x n | pad]
+
+    def exchange_buffers(self, Q: int, k: int):
+        """Device payload of one exchange: (uint8 tensor, ids pointer, scores pointer).  The local search writes its
+        `[Q, k]` global ids / scores straight into it (`vrag_*_index_search_device`)."""
+        import torch
+
+        n = Q * k
+        payload = torch.empty(self.payload_bytes(n), dtype=torch.uint8, device=torch.device("cuda", self.device))
+        base = payload.data_ptr()
+        return payload, base, base + n * 8
+
+    def allgather_merge_device(self, payload, Q: int, kk: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """`payload` (from `exchange_buffers`, filled on torch's current stream) of every rank -> merged `[Q, k]` on the
+        host.  No host copy between the local search and the merge: gather and merge read and write HBM only."""
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib
+
+        lib = _lib.load()
+        n = Q * kk
+        nbytes = self.payload_bytes(n)
+        flat = torch.empty(self.world * nbytes, dtype=torch.uint8, device=payload.device)
+        dist.all_gather_into_tensor(flat, payload, group=self.group)    # THE collective of the retrieval path
+        d_out_s = torch.empty((Q, k), dtype=torch.float32, device=payload.device)
+        d_out_i = torch.empty((Q, k), dtype=torch.int64, device=payload.device)
+        base = flat.data_ptr()
+        stream = torch.cuda.current_stream(payload.device).cuda_stream
+        _lib.check("vrag_topk_merge", lib.vrag_topk_merge(
+            C.c_void_p(base + n * 8), C.c_void_p(base), self.world, Q, kk, k, nbytes, nbytes,
+            C.c_void_p(d_out_s.data_ptr()), C.c_void_p(d_out_i.data_ptr()), 1, self.device, C.c_void_p(stream)))
+        return d_out_s.cpu().numpy(), d_out_i.cpu().numpy()
+
     def allgather_merge(self, scores: np.ndarray, ids: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
-        """Local lists `[Q, k_in]` (GLOBAL ids, -1 = empty) of every rank -> merged `[Q, k]`, identical on all ranks."""
+        """Local lists `[Q, k_in]` (GLOBAL ids, -1 = empty) held on the HOST -> merged `[Q, k]`, identical on all ranks
+        (gloo groups, and lists longer than one device pass, which `vrag_*_index_search` pages through the host)."""
         import torch
         import torch.distributed as dist
 
         Q, kk = scores.shape
         n = Q * kk
-        nbytes = (n * 12 + 7) // 8 * 8                          # [ids i64 x n | scores f32 x n | pad]
+        nbytes = self.payload_bytes(n)
         payload = np.zeros(nbytes, np.uint8)
         payload[: n * 8] = np.ascontiguousarray(ids, dtype=np.int64).view(np.uint8).reshape(-1)
         payload[n * 8: n * 12] = np.ascontiguousarray(scores, dtype=np.float32).view(np.uint8).reshape(-1)
-        on_gpu = self.backend == "nccl"
         t = torch.from_numpy(payload)
-        if on_gpu:
-            t = t.to(torch.device("cuda", self.device), non_blocking=True)
+        if self.on_gpu:
+            return self.allgather_merge_device(t.to(torch.device("cuda", self.device)), Q, kk, k)
+        if self.backend == "nccl":
+            t = t.to(torch.device("cuda", self.device))
         flat = torch.empty(self.world * nbytes, dtype=torch.uint8, device=t.device)
-        dist.all_gather_into_tensor(flat, t, group=self.group)          # THE collective of the retrieval path
+        dist.all_gather_into_tensor(flat, t, group=self.group)
         gathered = flat.view(self.world, nbytes)
         if self._merge is not None:
             g = gathered.cpu().numpy()
@@ -108,15 +179,6 @@ class ShardComm:
         lib = _lib.load()
         out_s = np.empty((Q, k), np.float32)
         out_i = np.empty((Q, k), np.int64)
-        if on_gpu:
-            d_out_s = torch.empty((Q, k), dtype=torch.float32, device=t.device)
-            d_out_i = torch.empty((Q, k), dtype=torch.int64, device=t.device)
-            base = gathered.data_ptr()
-            stream = torch.cuda.current_stream(t.device).cuda_stream
-            _lib.check("vrag_topk_merge", lib.vrag_topk_merge(
-                C.c_void_p(base + n * 8), C.c_void_p(base), self.world, Q, kk, k, nbytes, nbytes,
-                C.c_void_p(d_out_s.data_ptr()), C.c_void_p(d_out_i.data_ptr()), 1, self.device, C.c_void_p(stream)))
-            return d_out_s.cpu().numpy(), d_out_i.cpu().numpy()
         g = np.ascontiguousarray(gathered.numpy())
         base = g.ctypes.data
         _lib.check("vrag_topk_merge", lib.vrag_topk_merge(

@@ -116,10 +116,11 @@ def rrf_merge_rows(rows_by_method: Dict[str, np.ndarray], top_k: int, weights: D
     in insertion order; a negative entry is a rank without a candidate (no hit, or a hit the caller must skip: it still
     occupies its rank).  Returns `rows [Q, top_k]` (-1 padded) and `distance [Q, top_k]` (float64, `1 - score`).
 
-    All lists are laid side by side as one `[Q, L]` candidate matrix; a candidate's score is gathered at its FIRST
-    occurrence by adding, method by method, the contribution of whichever later position holds the same row (one
-    non-zero term per method, so every float64 sum has the same operands in the same order as a sequential
-    accumulation); a stable argsort on the negated score then keeps first-seen order among equal scores."""
+    All lists are laid side by side as one `[Q, L]` candidate matrix and the (query, row) pairs are grouped by ONE stable
+    sort of the flattened matrix -- O(Q L log(Q L)) time, O(Q L) memory, whatever the list length.  A group's score
+    is accumulated method by method in insertion order (`np.add.at` applies repeated indices one after the other), so
+    every float64 sum has the operands and the order of the reference's sequential accumulation; the final order is
+    score descending with ties in first-seen order (a lexsort on the group's first position)."""
     methods = list(rows_by_method)
     if not methods:
         raise ValueError("rrf_merge_rows needs at least one method")
@@ -128,25 +129,40 @@ def rrf_merge_rows(rows_by_method: Dict[str, np.ndarray], top_k: int, weights: D
     Q = lists[0].shape[0]
     cand = np.concatenate(lists, axis=1)                                          # [Q, L]
     L = cand.shape[1]
-    live = cand >= 0
-    same = (cand[:, :, None] == cand[:, None, :]) & live[:, :, None]              # [Q, L, L] (symmetric on live entries)
-    earlier = np.tril(np.ones((L, L), dtype=bool), -1)                            # [p, p'] : p' < p
-    first = live & ~(same & earlier[None]).any(axis=2)
-    score = np.zeros((Q, L), np.float64)
+    rows_out = np.full((Q, top_k), -1, np.int64)
+    dist = np.zeros((Q, top_k), np.float64)
+    flat = cand.reshape(-1)
+    live = np.nonzero(flat >= 0)[0]                                               # flat positions, ascending = (query, position)
+    if live.size == 0:
+        return rows_out, dist
+    qi = live // L
+    span = int(flat.max()) + 1
+    key = qi * span + flat[live]                                                  # one integer per (query, row) pair
+    order = np.argsort(key, kind="stable")                                        # equal pairs stay in position order
+    sk = key[order]
+    head = np.concatenate([[True], sk[1:] != sk[:-1]])
+    gid_sorted = np.cumsum(head) - 1
+    n_groups = int(gid_sorted[-1]) + 1
+    gid = np.empty(live.size, np.int64)
+    gid[order] = gid_sorted
+    first_pos = live[order][head]                                                 # flat position of a group's first occurrence
+    score = np.zeros(n_groups, np.float64)
+    pos_in_q = live - qi * L
     lo = 0
     for m, rows in zip(methods, lists):
         n = rows.shape[1]
+        sel = (pos_in_q >= lo) & (pos_in_q < lo + n)
         gain = share.get(m, 0.0) * (1.0 / (rrf_k + np.arange(n, dtype=np.float64) + 1))
-        score = score + (same[:, :, lo:lo + n] * gain[None, None, :]).sum(axis=2)
+        np.add.at(score, gid[sel], gain[pos_in_q[sel] - lo])
         lo += n
-    order = np.argsort(np.where(first, -score, np.inf), axis=1, kind="stable")[:, :top_k]
-    picked = np.take_along_axis(first, order, axis=1)
-    rows_out = np.where(picked, np.take_along_axis(cand, order, axis=1), -1)
-    dist = np.where(picked, 1.0 - np.take_along_axis(score, order, axis=1), 0.0)
-    if rows_out.shape[1] < top_k:
-        pad = top_k - rows_out.shape[1]
-        rows_out = np.pad(rows_out, ((0, 0), (0, pad)), constant_values=-1)
-        dist = np.pad(dist, ((0, 0), (0, pad)))
+    gq = first_pos // L
+    final = np.lexsort((first_pos, -score, gq))                                   # query, then score desc, then first seen
+    gq_f = gq[final]
+    start = np.searchsorted(gq_f, np.arange(Q), side="left")
+    rank_in_q = np.arange(n_groups) - start[gq_f]
+    keep = rank_in_q < top_k
+    rows_out[gq_f[keep], rank_in_q[keep]] = flat[first_pos[final][keep]]
+    dist[gq_f[keep], rank_in_q[keep]] = 1.0 - score[final][keep]
     return rows_out, dist
 
 
@@ -234,6 +250,15 @@ class DenseShard:
             self._h, q.ctypes.data_as(_FP), q.shape[0], k, scores.ctypes.data_as(_FP), ids.ctypes.data_as(_LP), stream))
         return scores, ids
 
+    def search_device(self, queries: np.ndarray, k: int, out_scores: int, out_ids: int, row_map: Optional[int] = None,
+                      n_map: int = 0, id_base: int = 0, stream=None) -> None:
+        """The same search with the `[Q, k]` lists left in HBM at the device addresses `out_scores` / `out_ids`
+        (global ids through the device table `row_map`, or `id_base + row`); kernels are only enqueued on `stream`."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        _lib.check("vrag_dense_index_search_device", self._lib.vrag_dense_index_search_device(
+            self._h, q.ctypes.data_as(_FP), q.shape[0], k, C.c_void_p(row_map) if row_map else None, n_map, id_base,
+            C.c_void_p(out_scores), C.c_void_p(out_ids), stream))
+
     def run_resident(self, nq: int, k: int, stream=None) -> None:
         _lib.check("vrag_dense_index_run_resident", self._lib.vrag_dense_index_run_resident(self._h, nq, k, stream))
 
@@ -301,6 +326,15 @@ class SparseShard:
     def search(self, queries: Sequence[Dict[int, float]], k: int, stream=None):
         return self.search_csr(*dicts_to_csr(queries), k, stream)
 
+    def search_device(self, queries: Sequence[Dict[int, float]], k: int, out_scores: int, out_ids: int,
+                      row_map: Optional[int] = None, n_map: int = 0, id_base: int = 0, stream=None) -> None:
+        """`search` with the lists left in HBM (see DenseShard.search_device)."""
+        q_indptr, q_indices, q_values = dicts_to_csr(queries)
+        _lib.check("vrag_sparse_index_search_device", self._lib.vrag_sparse_index_search_device(
+            self._h, q_indptr.ctypes.data_as(_LP), q_indices.ctypes.data_as(_IP), q_values.ctypes.data_as(_FP),
+            len(q_indptr) - 1, k, C.c_void_p(row_map) if row_map else None, n_map, id_base, C.c_void_p(out_scores),
+            C.c_void_p(out_ids), stream))
+
     def run_resident(self, nq: int, k: int, stream=None) -> None:
         _lib.check("vrag_sparse_index_run_resident", self._lib.vrag_sparse_index_run_resident(self._h, nq, k, stream))
 
@@ -314,6 +348,9 @@ class SparseShard:
             self.close()
         except Exception:
             pass
+
+
+_JSON_PLAIN = (str, int, float, bool, type(None))
 
 
 def json_serialize_safe(obj: Any) -> Any:
@@ -335,6 +372,107 @@ def json_serialize_safe(obj: Any) -> Any:
         return x
 
     return view(obj)
+
+
+def _metadata_rows(metadatas: Sequence[Optional[dict]]) -> List[Dict[str, Any]]:
+    """`json_serialize_safe(dict(md))` for a batch of rows (milvus_base.py:108-109); flat dicts of plain JSON scalars
+    under string keys -- what ingestion produces -- are copied without the recursive walk."""
+    plain = _JSON_PLAIN
+    out = []
+    for md in metadatas:
+        if not md:
+            out.append({})
+        elif all(type(k) is str and type(v) in plain for k, v in md.items()):
+            out.append(dict(md))
+        else:
+            out.append(json_serialize_safe(dict(md)))
+    return out
+
+
+class _Column:
+    """Append-only numpy column with amortised growth: `data` is the `[n]` or `[n, width]` view of the filled part.
+    A view handed out earlier stays valid (it keeps its buffer) and covers the rows that existed then."""
+
+    def __init__(self, dtype, width: Optional[int] = None, first: Optional[Sequence] = None):
+        self._width = width
+        self._buf = np.empty((0,) if width is None else (0, width), dtype)
+        self._n = 0
+        if first is not None:
+            self.extend(np.asarray(first, dtype))
+
+    def __len__(self) -> int:
+        return self._n
+
+    @property
+    def data(self) -> np.ndarray:
+        return self._buf[: self._n]
+
+    def extend(self, rows: np.ndarray) -> None:
+        m = len(rows)
+        if self._n + m > len(self._buf):
+            cap = max(self._n + m, int(len(self._buf) * 1.5) + 16)
+            grown = np.empty((cap,) + self._buf.shape[1:], self._buf.dtype)
+            grown[: self._n] = self._buf[: self._n]
+            self._buf = grown
+        self._buf[self._n: self._n + m] = rows
+        self._n += m
+
+
+def csr_take_rows(indptr: np.ndarray, indices: np.ndarray, values: np.ndarray, rows: np.ndarray):
+    """CSR of the selected rows (in the given order), without a Python loop per row."""
+    rows = np.asarray(rows, dtype=np.int64)
+    lens = indptr[rows + 1] - indptr[rows]
+    out_ptr = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum(lens, out=out_ptr[1:])
+    take = np.repeat(indptr[rows] - out_ptr[:-1], lens) + np.arange(int(out_ptr[-1]), dtype=np.int64)
+    return out_ptr, indices[take], values[take]
+
+
+def _as_csr(sparse_vectors, n_expected: int, vocab: int):
+    """Sparse rows in any accepted form -> canonical CSR (int64 indptr, int32 terms strictly ascending within a row,
+    float32 weights).  Accepted: the reference's `List[Dict[int, float]]` (embedding_providers.py:33-49), and for bulk
+    ingest a `(indptr, indices, values)` triple or a scipy CSR matrix (rows with unsorted terms are sorted; a term
+    repeated inside a row is rejected -- a dict cannot hold one)."""
+    if hasattr(sparse_vectors, "indptr") and hasattr(sparse_vectors, "indices") and hasattr(sparse_vectors, "data"):
+        sparse_vectors = (sparse_vectors.indptr, sparse_vectors.indices, sparse_vectors.data)
+    if isinstance(sparse_vectors, tuple) and len(sparse_vectors) == 3 and isinstance(sparse_vectors[0], np.ndarray):
+        indptr = np.ascontiguousarray(sparse_vectors[0], dtype=np.int64)
+        indices = np.asarray(sparse_vectors[1])
+        values = np.ascontiguousarray(sparse_vectors[2], dtype=np.float32)
+        if len(indptr) != n_expected + 1:
+            raise ValueError(f"add_vectors: {len(indptr) - 1} sparse_vectors for {n_expected} ids")
+        if indptr[0] != 0 or (np.diff(indptr) < 0).any() or indptr[-1] != len(indices) or len(indices) != len(values):
+            raise ValueError("add_vectors: malformed CSR sparse_vectors")
+        if len(indices) and (indices.min() < 0 or indices.max() >= vocab):
+            bad = int(np.searchsorted(indptr, np.nonzero((indices < 0) | (indices >= vocab))[0][0], side="right") - 1)
+            raise ValueError(f"add_vectors: sparse vector {bad} has a term outside [0, {vocab})")
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        if len(indices) > 1:
+            step = np.diff(indices.astype(np.int64))
+            inner = np.ones(len(indices) - 1, dtype=bool)
+            inner[indptr[1:-1][(indptr[1:-1] > 0) & (indptr[1:-1] < len(indices))] - 1] = False   # row boundaries
+            if (inner & (step <= 0)).any():
+                row_of = np.repeat(np.arange(n_expected, dtype=np.int64), np.diff(indptr))
+                order = np.lexsort((indices, row_of))
+                indices, values = indices[order], values[order]
+                step = np.diff(indices.astype(np.int64))
+                if (inner & (step == 0)).any():
+                    raise ValueError("add_vectors: a sparse vector repeats a term")
+        return indptr, indices, values
+    if len(sparse_vectors) != n_expected:
+        raise ValueError(f"add_vectors: {len(sparse_vectors)} sparse_vectors for {n_expected} ids")
+    indptr, indices, values = dicts_to_csr(sparse_vectors)
+    if len(indices) and (indices.min() < 0 or indices.max() >= vocab):
+        bad = int(np.searchsorted(indptr, np.nonzero((indices < 0) | (indices >= vocab))[0][0], side="right") - 1)
+        raise ValueError(f"add_vectors: sparse vector {bad} has a term outside [0, {vocab})")
+    return indptr, indices, values
+
+
+def _merge_parts(scores: np.ndarray, rows: np.ndarray, k: int, device: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Lists of the segments of one shard `[P, Q, k]` (global rows) -> `[Q, k]`, on the GPU (`vrag_topk_merge`)."""
+    from .distributed import merge_topk_device
+
+    return merge_topk_device(scores, rows, k, device)
 
 
 # ---------------------------------------------------------------------------- filters
@@ -473,32 +611,52 @@ class GpuVectorStore(VectorStore):
 
     dense = COSINE (rows and queries are L2-normalised here, so IP on the device equals cosine),
     sparse = IP over shared terms.  Rows live on the host until the first query after an insert
-    ("flush"), then in HBM; a flush appends the new dense rows to the resident shard and rebuilds the sparse image.
-    Dense rows are stored fp32 like the reference's FLOAT_VECTOR field (milvus_local.py:109-118);
-    `dense_dtype="bf16"` halves the bytes a query streams at the price of rounding the stored rows.
+    ("flush"), then in HBM; a flush appends the new dense rows to the resident shard and builds a SELL-64 image of the
+    new sparse rows only (a tail segment beside the main image; the two are folded into one image when the tail
+    outgrows a quarter of it).  Dense rows are stored fp32 like the reference's FLOAT_VECTOR field
+    (milvus_local.py:109-118): 4 * dim bytes per row in HBM (times `dense_headroom` of append room) and as much on the
+    host; `dense_dtype="bf16"` halves the HBM bytes a query streams at the price of rounding the stored rows, which
+    also gives up bit-exact ranking between rows whose fp32 scores nearly tie.
     `filter` supports the comparison subset of Milvus expressions in `parse_filter`
     (the reference itself only builds `metadata["document_id"] == "..."`, index.py:735-739); anything else is
     rejected loudly.  Filters and deletes act before the search like Milvus' (a selective filter still returns its
     best rows): `_topk_rows` re-runs short queries on a cached shard of just the passing rows.
+    A search may ask for at most `K_LIMIT` = 1024 rows per method (hybrid search asks for 2 * top_k, so top_k <= 512
+    there); more raises ValueError -- never a silently shorter list.
+
+    Host layout (columnar, sized for 10^7 rows): ids in one list with a lazily built id -> row table for deletes; unit
+    dense rows in one growing `[n, dim]` fp32 array; sparse rows as one growing CSR; liveness as a bool column.
+    `add_vectors` also takes an `[n, dim]` ndarray and a CSR triple / scipy CSR matrix for bulk ingest.
 
     Multi-GPU: `distributed=True` (one process per GPU, torch.distributed initialised, every rank making
-    the SAME calls with the SAME arguments) row-shards the vectors -- each insert batch is cut contiguously over the
-    ranks -- while ids / texts / metadata stay replicated on the hosts.  A search runs on each rank's shard, ONE
-    all-gather carries the per-shard `[Q, k]` lists and every rank merges them on its GPU (`distributed.ShardComm`),
-    so `query` / `query_batch` return the same results on every rank and the same results as a single-GPU store.
+    the SAME calls with the SAME arguments) row-shards the store -- each insert batch is cut contiguously over the
+    ranks; a rank keeps the vectors, texts and metadata of ITS rows only (`payload="replicated"` keeps texts and
+    metadata on every rank instead), ids stay replicated.  A search runs on each rank's shard, ONE all-gather carries
+    the per-shard `[Q, k]` lists and every rank merges them on its GPU (`distributed.ShardComm`; under RCCL the lists
+    never leave HBM between the local search and the merge); the texts / metadata of the merged hits then meet in one
+    object gather.  `query` / `query_batch` return the same results on every rank and the same results as a
+    single-GPU store.
     """
 
     enable_full_text = False
 
+    SUBSET_CACHE = 4
+    K_LIMIT = 1024          # vrag_*_index_search: lists of up to 64 per device pass, longer ones as exact pages of 64
+    DEVICE_K = 64           # longest list the device-resident exchange carries (one device pass)
+    SPARSE_TAIL_MIN = 65536  # rows a sparse tail segment may always hold before it is folded into the main image
+
     def __init__(self, dense_dim: Optional[int] = 384, sparse_vocab: Optional[int] = 30522, enable_dense: bool = True,
                  enable_sparse: bool = True, dense_dtype: str = "f32", device: int = 0, distributed: bool = False,
-                 group=None, comm=None):
+                 group=None, comm=None, payload: str = "sharded", dense_headroom: float = 1.5):
         self._lib = _lib.load()
         _lib.require_gpu()
         if dense_dtype not in ("f32", "bf16"):
             raise ValueError(f"dense_dtype must be 'f32' or 'bf16' (got {dense_dtype!r})")
+        if payload not in ("sharded", "replicated"):
+            raise ValueError(f"payload must be 'sharded' or 'replicated' (got {payload!r})")
         self.enable_dense, self.enable_sparse = enable_dense, enable_sparse
         self.dense_dim, self.sparse_vocab, self.dense_dtype, self.device = dense_dim, sparse_vocab, dense_dtype, device
+        self.dense_headroom = max(1.0, float(dense_headroom))
         self._comm = comm
         if comm is None and distributed:
             from .distributed import ShardComm
@@ -506,21 +664,28 @@ class GpuVectorStore(VectorStore):
             self._comm = ShardComm(group, device)
         self._rank = self._comm.rank if self._comm is not None else 0
         self._world = self._comm.world if self._comm is not None else 1
+        self._payload_sharded = self._world > 1 and payload == "sharded"
         # replicated on every rank, indexed by global row
         self._ids: List[str] = []
+        self._alive = _Column(bool)
+        self._id_rows: Optional[Dict[str, Any]] = None        # id -> row (or rows), built by the first delete
+        # texts / metadata: indexed by global row, or by local row when the payload is sharded
         self._texts: List[str] = []
         self._enh: List[str] = []
         self._meta: List[Dict[str, Any]] = []
-        self._alive: List[bool] = []
-        # this rank's shard, indexed by local row; `_owned[j]` = global row of local row j (ascending)
-        self._owned: List[int] = []
-        self._dense_rows: List[np.ndarray] = []
-        self._sparse_rows: List[Dict[int, float]] = []
+        # this rank's shard, indexed by local row; `_owned.data[j]` = global row of local row j (ascending)
+        self._owned = _Column(np.int64)
+        self._dense_rows = _Column(np.float32, dense_dim) if enable_dense else None
+        self._sp_ptr = _Column(np.int64, first=[0])
+        self._sp_idx = _Column(np.int32)
+        self._sp_val = _Column(np.float32)
         self._dense: Optional[DenseShard] = None
         self._dense_cap = 0          # capacity of the resident dense shard
         self._dense_flushed = 0      # local rows already in it
-        self._sparse: Optional[SparseShard] = None
-        self._main_rows: Optional[np.ndarray] = None   # np.asarray(_owned) at the last flush
+        self._sparse_parts: List[Tuple[Any, int, int]] = []   # (SELL image, first local row, rows): main [+ tail]
+        self._sparse_flushed = 0
+        self._main_rows: np.ndarray = np.zeros(0, np.int64)   # _owned.data at the last flush
+        self._owned_dev = None       # the same table in HBM (RCCL exchange): (torch tensor, rows)
         self._dirty = False
         # Callers arrive from asyncio.to_thread workers (index.py:552-655 under api/): inserts, deletes, the flush and the
         # cache fills are serialised by this lock; searches run outside it on the shard objects they captured, and a shard
@@ -529,28 +694,24 @@ class GpuVectorStore(VectorStore):
         self._mu = threading.RLock()
         self._masks: Dict[str, Optional[np.ndarray]] = {}
         self._value_indexes: Dict[str, Dict[Any, np.ndarray]] = {}
-        self._all_ids_truthy: Optional[bool] = None
+        self._all_ids_truthy = True
         self._documents: Dict[str, Dict[str, Any]] = {}      # document records (add_documents / get_document)
-        self._subsets: Dict[Any, Tuple[Any, np.ndarray]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row)
+        self._subsets: Dict[Any, Tuple[Any, np.ndarray, Any]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row, device copy)
 
-    SUBSET_CACHE = 4
-    K_LIMIT = 1024   # vrag_*_index_search: lists of up to 64 per device pass, longer ones as exact pages of 64
+    def __len__(self) -> int:
+        return len(self._ids)
 
     # -------------------------------------------------------------- ingest
     def add_vectors(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
         if self.enable_dense and (dense_vectors is None or len(dense_vectors) == 0):
             raise ValueError("Dense vectors required but not provided")          # milvus_base.py:101-104
-        if self.enable_sparse and (sparse_vectors is None or len(sparse_vectors) == 0):
+        if self.enable_sparse and (sparse_vectors is None or
+                                   (len(sparse_vectors) == 0 if not hasattr(sparse_vectors, "indptr") else sparse_vectors.shape[0] == 0)):
             raise ValueError("Sparse vectors required but not provided")
         # Build and validate every new row BEFORE touching the store (the reference assembles the whole batch and
         # inserts it in one call, milvus_base.py:90-127): a malformed entry leaves the store exactly as it was.
         n = len(ids)
-        columns = {"texts": texts, "enhanced_texts": enhanced_texts, "metadatas": metadatas}
-        if self.enable_dense:
-            columns["dense_vectors"] = dense_vectors
-        if self.enable_sparse:
-            columns["sparse_vectors"] = sparse_vectors
-        for name, col in columns.items():
+        for name, col in (("texts", texts), ("enhanced_texts", enhanced_texts), ("metadatas", metadatas)):
             if len(col) != n:
                 raise ValueError(f"add_vectors: {len(col)} {name} for {n} ids")
         lo, hi = (0, n)
@@ -558,45 +719,79 @@ class GpuVectorStore(VectorStore):
             from .distributed import shard_range
 
             lo, hi = shard_range(n, self._rank, self._world)
-        new_meta = [json_serialize_safe(dict(md or {})) for md in metadatas]     # milvus_base.py:108-109
-        new_dense: List[np.ndarray] = []
-        new_sparse: List[Dict[int, float]] = []
-        for i in range(n):
-            if self.enable_dense:
-                v = np.asarray(dense_vectors[i], dtype=np.float32)
-                if v.ndim != 1 or v.shape[0] != self.dense_dim:
-                    raise ValueError(f"add_vectors: dense vector {i} has shape {v.shape}, the store holds {self.dense_dim}-d rows")
-                if lo <= i < hi:
-                    norm = float(np.sqrt((v * v).sum(dtype=np.float32)))
-                    new_dense.append(v / norm if norm > 0 else v)                # COSINE == IP on unit rows
-            if self.enable_sparse:
-                row = {int(t): float(w) for t, w in sparse_vectors[i].items()}
-                if row and (min(row) < 0 or max(row) >= self.sparse_vocab):
-                    raise ValueError(f"add_vectors: sparse vector {i} has a term outside [0, {self.sparse_vocab})")
-                if lo <= i < hi:
-                    new_sparse.append(row)
+        new_dense = None
+        if self.enable_dense:
+            if len(dense_vectors) != n:
+                raise ValueError(f"add_vectors: {len(dense_vectors)} dense_vectors for {n} ids")
+            try:
+                block = np.asarray(dense_vectors, dtype=np.float32)
+            except ValueError:
+                block = None                                   # ragged rows: name the first offender below
+            if block is None or block.ndim != 2 or block.shape[1] != self.dense_dim:
+                for i, v in enumerate(dense_vectors):
+                    shape = np.asarray(v, dtype=np.float32).shape
+                    if shape != (self.dense_dim,):
+                        raise ValueError(f"add_vectors: dense vector {i} has shape {shape}, the store holds {self.dense_dim}-d rows")
+                raise ValueError(f"add_vectors: dense_vectors must be [n, {self.dense_dim}]")
+            mine = block[lo:hi]
+            norms = np.sqrt((mine * mine).sum(axis=1, dtype=np.float32))
+            new_dense = mine / np.where(norms > 0, norms, np.float32(1.0))[:, None]   # COSINE == IP on unit rows
+        new_csr = None
+        if self.enable_sparse:
+            indptr, indices, values = _as_csr(sparse_vectors, n, self.sparse_vocab)
+            new_csr = (indptr[lo:hi + 1] - indptr[lo], indices[indptr[lo]:indptr[hi]], values[indptr[lo]:indptr[hi]])
+        keep = slice(lo, hi) if self._payload_sharded else slice(0, n)
+        new_meta = _metadata_rows(metadatas[keep])                                # milvus_base.py:108-109
+        new_texts, new_enh = list(texts[keep]), list(enhanced_texts[keep])
         with self._mu:
             base = len(self._ids)
             self._ids.extend(ids)
-            self._texts.extend(texts)
-            self._enh.extend(enhanced_texts)
+            if self._id_rows is not None:
+                for i, x in enumerate(ids):
+                    self._note_id(x, base + i)
+            if self._all_ids_truthy:
+                self._all_ids_truthy = all(bool(x) for x in ids)
+            self._texts.extend(new_texts)
+            self._enh.extend(new_enh)
             self._meta.extend(new_meta)
-            self._alive.extend([True] * n)
-            self._owned.extend(range(base + lo, base + hi))
-            self._dense_rows.extend(new_dense)
-            self._sparse_rows.extend(new_sparse)
+            self._alive.extend(np.ones(n, dtype=bool))
+            self._owned.extend(np.arange(base + lo, base + hi, dtype=np.int64))
+            if new_dense is not None:
+                self._dense_rows.extend(new_dense)
+            if new_csr is not None:
+                self._sp_ptr.extend(new_csr[0][1:] + self._sp_ptr.data[-1])
+                self._sp_idx.extend(new_csr[1])
+                self._sp_val.extend(new_csr[2])
             self._dirty = True
             self._drop_subsets()
             self._value_indexes.clear()
-            self._all_ids_truthy = None
+
+    def _note_id(self, key, row: int) -> None:
+        have = self._id_rows.get(key)
+        if have is None:
+            self._id_rows[key] = row
+        elif isinstance(have, list):
+            have.append(row)
+        else:
+            self._id_rows[key] = [have, row]
 
     def delete(self, ids: List[str]):
-        kill = set(ids)
         with self._mu:
-            for i, x in enumerate(self._ids):
-                if x in kill:
-                    self._alive[i] = False
+            if self._id_rows is None:                       # one pass over the ids, then O(1) per deleted id
+                self._id_rows = {}
+                for row, key in enumerate(self._ids):
+                    self._note_id(key, row)
+            alive = self._alive.data
+            for key in ids:
+                rows = self._id_rows.get(key)
+                if rows is not None:
+                    alive[rows] = False
             self._drop_subsets()
+
+    def _sparse_slice(self, a: int, b: int):
+        """CSR of local rows [a, b)."""
+        ptr = self._sp_ptr.data
+        return ptr[a:b + 1] - ptr[a], self._sp_idx.data[ptr[a]:ptr[b]], self._sp_val.data[ptr[a]:ptr[b]]
 
     def _flush(self):
         with self._mu:
@@ -605,29 +800,70 @@ class GpuVectorStore(VectorStore):
             n = len(self._owned)
             # published before the device append: a search that is running on the resident shard decodes its hits with
             # the mapping it reads AFTER the kernel returns, so every row the kernel can have seen is in it
-            self._main_rows = np.asarray(self._owned, dtype=np.int64)
+            self._main_rows = self._owned.data
             if self.enable_dense and n > self._dense_flushed:
-                fresh = np.stack(self._dense_rows[self._dense_flushed:])
+                rows = self._dense_rows.data
                 if self._dense is None or n > self._dense_cap:
                     # (re)build with head-room so later inserts append instead of re-uploading every row
                     self._dense = None                  # released now unless a search on another thread still holds it
-                    self._dense_cap = max(1024, 2 * n)
+                    self._dense_cap = max(1024, int(n * self.dense_headroom))
                     dense = DenseShard(self.dense_dim, self._dense_cap, self.dense_dtype, self.device)
-                    dense.add(np.stack(self._dense_rows))
+                    dense.add(rows)
                     self._dense = dense
                 else:
-                    self._dense.add(fresh)
+                    self._dense.add(rows[self._dense_flushed:])
                 self._dense_flushed = n
-            if self.enable_sparse:
-                self._sparse = None
-                self._sparse = SparseShard(self.sparse_vocab, *dicts_to_csr(self._sparse_rows), device=self.device) if n else None
+            if self.enable_sparse and n > self._sparse_flushed:
+                main = self._sparse_parts[0] if self._sparse_parts else None
+                main_n = main[2] if main else 0
+                if main is None or n - main_n > max(self.SPARSE_TAIL_MIN, main_n // 4):
+                    self._sparse_parts = []             # one image of everything
+                    self._sparse_parts = [(SparseShard(self.sparse_vocab, *self._sparse_slice(0, n), device=self.device), 0, n)]
+                else:                                   # the main image stays; the rows behind it form the tail segment
+                    tail = SparseShard(self.sparse_vocab, *self._sparse_slice(main_n, n), device=self.device)
+                    self._sparse_parts = [main, (tail, main_n, n - main_n)]
+                self._sparse_flushed = n
+            if self._comm is not None and self._comm.on_gpu and n:
+                import torch
+
+                self._owned_dev = (torch.from_numpy(np.ascontiguousarray(self._main_rows)).to(torch.device("cuda", self.device)), n)
             self._dirty = False
 
-    def _main_shard(self, kind: str):
-        """(shard or None, rows in the whole store) after a flush, captured under the lock."""
+    def _main_parts(self, kind: str):
+        """(segments of the resident shard as (shard, first local row), device row table, rows in the whole store)
+        after a flush, captured under the lock."""
         with self._mu:
             self._flush()
-            return (self._dense if kind == "dense" else self._sparse), len(self._ids)
+            if kind == "dense":
+                parts = [(self._dense, 0)] if self._dense is not None else []
+            else:
+                parts = [(sh, base) for sh, base, _n in self._sparse_parts]
+            return parts, self._owned_dev, len(self._ids)
+
+    # -------------------------------------------------------------- row payloads (texts, metadata)
+    def _payload_slot(self, row: int) -> int:
+        """Index of global row `row` in the text / metadata lists, -1 when another rank holds it."""
+        if not self._payload_sharded:
+            return row
+        owned = self._owned.data
+        j = int(np.searchsorted(owned, row))
+        return j if j < len(owned) and owned[j] == row else -1
+
+    def _payloads(self, rows) -> Dict[int, Tuple[str, str, Dict[str, Any]]]:
+        """global row -> (text, enhanced text, metadata copy) for the given rows; sharded payloads meet in ONE object
+        gather (every rank asks for the same rows and contributes the ones it holds)."""
+        want = sorted({int(r) for r in rows if r >= 0})
+        out = {}
+        for r in want:
+            j = self._payload_slot(r)
+            if j >= 0:
+                out[r] = (self._texts[j], self._enh[j], dict(self._meta[j]))
+        if self._payload_sharded:
+            merged: Dict[int, Tuple[str, str, Dict[str, Any]]] = {}
+            for part in self._comm.gather_objects(out):
+                merged.update(part)
+            return merged
+        return out
 
     # -------------------------------------------------------------- search
     def _mask(self, filter: Optional[str]) -> Optional[np.ndarray]:
@@ -639,28 +875,35 @@ class GpuVectorStore(VectorStore):
 
     def _mask_locked(self, key: str, filter: Optional[str]) -> Optional[np.ndarray]:
         if key not in self._masks:
-            alive = np.asarray(self._alive, dtype=bool)
+            alive = self._alive.data.copy()
             if filter:
                 pred = parse_filter(filter)
                 lookup = getattr(pred, "lookup", None)
+                held = np.zeros(len(self._meta), dtype=bool)     # over the rows whose metadata this rank holds
                 if lookup is not None:      # one `==` / `in` comparison (the reference's document_id filter, index.py:735-739)
                     index = self._value_index(lookup[0])
-                    passing = np.zeros(len(self._meta), dtype=bool)
                     for v in lookup[1]:
                         rows = index.get(v)
                         if rows is not None:
-                            passing[rows] = True
-                    alive = alive & passing
+                            held[rows] = True
                 else:
-                    alive = alive & np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
+                    held = np.asarray([bool(pred(md)) for md in self._meta], dtype=bool)
+                if self._payload_sharded:
+                    passing = np.zeros(len(alive), dtype=bool)
+                    passing[self._owned.data[: len(held)][held]] = True
+                    passing = self._comm.union_mask(passing)
+                else:
+                    passing = held
+                alive = alive & passing
             if len(self._masks) >= 64:
                 self._masks.clear()
             self._masks[key] = None if alive.all() else alive
         return self._masks[key]
 
     def _value_index(self, key: str) -> Dict[Any, np.ndarray]:
-        """typed metadata[key] -> rows, built once per key until the next insert: a per-document filter then costs its
-        matches, not a Python predicate call per stored row.  Rows without a comparable value are in no bucket."""
+        """typed metadata[key] -> rows (positions in the metadata list), built once per key until the next insert: a
+        per-document filter then costs its matches, not a Python predicate call per stored row.  Rows without a
+        comparable value are in no bucket."""
         with self._mu:
             index = self._value_indexes.get(key)
             if index is None:
@@ -678,57 +921,109 @@ class GpuVectorStore(VectorStore):
         return {"id": self._ids[row], "distance": float(score), "_row": row}
 
     def _results(self, hits: List[dict]) -> List[SearchResult]:
-        return [SearchResult(id=h["id"], score=h["distance"], metadata=dict(self._meta[h["_row"]]),
-                             text=self._texts[h["_row"]], enhanced_text=self._enh[h["_row"]]) for h in hits]
+        pay = self._payloads([h["_row"] for h in hits])
+        return [SearchResult(id=h["id"], score=h["distance"], metadata=pay[h["_row"]][2], text=pay[h["_row"]][0],
+                             enhanced_text=pay[h["_row"]][1]) for h in hits]
 
     def _search(self, kind: str, query, limit: int, mask: Optional[np.ndarray]) -> List[dict]:
         return self._search_batch(kind, [query], limit, mask)[0]
 
-    def _device_topk(self, kind: str, shard, shard_rows: Optional[np.ndarray], queries: Sequence[Any], k: int):
+    def _unit_queries(self, queries: Sequence[Any]) -> np.ndarray:
+        """COSINE: unit queries against the unit rows (fp32 norm, one row at a time or all at once: same bits)."""
+        rows_q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(len(queries), self.dense_dim))
+        norms = np.sqrt((rows_q * rows_q).sum(axis=1, dtype=np.float32))
+        return rows_q / np.where(norms > 0, norms, np.float32(1.0))[:, None]
+
+    def _device_topk(self, kind: str, parts, shard_rows: Optional[np.ndarray], queries: Sequence[Any], k: int,
+                     rows_dev=None):
         """Top-k of `queries` over one (possibly sharded) set of rows -> (`scores [Q, k]`, GLOBAL `rows [Q, k]`, -1 = no
-        hit).  `shard` is this rank's part (None when it holds none of the rows) and `shard_rows[j]` the global row of
-        its row j (None = the resident main shard, whose append-only mapping is read after the search); with more than
-        one rank the per-shard lists meet in one all-gather and are merged on the GPU."""
+        hit).  `parts` are this rank's segments as (shard, first local row) (empty when it holds none of the rows) and
+        `shard_rows[j]` the global row of local row j (None = the resident main shard, whose append-only mapping is read
+        after the search; `rows_dev` = the same table in HBM); with more than one rank the per-shard lists meet in one
+        all-gather and are merged on the GPU."""
         Q = len(queries)
-        if shard is None:
+        comm = self._comm
+        q_in = self._unit_queries(queries) if kind == "dense" and parts else queries
+        if comm is not None and comm.on_gpu and k <= self.DEVICE_K and (rows_dev is not None or not parts):
+            return self._device_topk_resident(parts, rows_dev, q_in, Q, k)
+        if not parts:
             scores = np.full((Q, k), -np.inf, np.float32)
             rows = np.full((Q, k), -1, np.int64)
         else:
-            if kind == "dense":   # COSINE: unit queries against the unit rows (fp32 norm, one row at a time or all at once: same bits)
-                rows_q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(Q, self.dense_dim))
-                norms = np.sqrt((rows_q * rows_q).sum(axis=1, dtype=np.float32))
-                scores, local = shard.search(rows_q / np.where(norms > 0, norms, np.float32(1.0))[:, None], k)
+            found_lists = []
+            for shard, base in parts:
+                sc, local = shard.search(q_in, k)          # dicts_to_csr converts sparse keys / weights to int32 / float32
+                mapping = shard_rows if shard_rows is not None else self._main_rows
+                at = local + base
+                found = (local >= 0) & (at < len(mapping))
+                g = np.where(found, mapping[np.where(found, at, 0)], -1) if len(mapping) else np.full_like(local, -1)
+                found_lists.append((sc, g))
+            if len(found_lists) == 1:
+                scores, rows = found_lists[0]
             else:
-                scores, local = shard.search(queries, k)       # dicts_to_csr converts keys / weights to int32 / float32
-            mapping = shard_rows if shard_rows is not None else self._main_rows
-            found = (local >= 0) & (local < len(mapping))
-            rows = np.where(found, mapping[np.where(found, local, 0)], -1) if len(mapping) else np.full_like(local, -1)
-        if self._world > 1:
-            scores, rows = self._comm.allgather_merge(scores, rows, k)
+                scores, rows = _merge_parts(np.stack([np.where(g >= 0, sc, -np.inf).astype(np.float32) for sc, g in found_lists]),
+                                            np.stack([g for _sc, g in found_lists]), k, self.device)
+        if comm is not None and (self._world > 1 or comm.on_gpu):
+            scores, rows = comm.allgather_merge(scores, rows, k)
         return scores, rows
+
+    def _device_topk_resident(self, parts, rows_dev, q_in, Q: int, k: int):
+        """The RCCL form of `_device_topk`: every segment writes its `[Q, k]` lists (global rows through the device
+        table) into HBM, segments are merged on the device, the payload goes through ONE all-gather and the cross-rank
+        merge; only the merged result is copied to the host."""
+        import torch
+
+        comm = self._comm
+        stream = C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+        payload, ids_ptr, scores_ptr = comm.exchange_buffers(Q, k)
+        n = Q * k
+        if not parts:
+            _lib.check("vrag_topk_fill_empty", self._lib.vrag_topk_fill_empty(C.c_void_p(scores_ptr), C.c_void_p(ids_ptr), n, self.device, stream))
+        else:
+            table, n_map = rows_dev
+            if len(parts) == 1:
+                slots = [(scores_ptr, ids_ptr)]
+            else:
+                seg_s = torch.empty((len(parts), n), dtype=torch.float32, device=payload.device)
+                seg_i = torch.empty((len(parts), n), dtype=torch.int64, device=payload.device)
+                slots = [(seg_s[p].data_ptr(), seg_i[p].data_ptr()) for p in range(len(parts))]
+            for (shard, base), (sp, ip) in zip(parts, slots):
+                shard.search_device(q_in, k, sp, ip, row_map=table.data_ptr() + 8 * base, n_map=n_map - base, stream=stream)
+            if len(parts) > 1:
+                _lib.check("vrag_topk_merge", self._lib.vrag_topk_merge(
+                    C.c_void_p(seg_s.data_ptr()), C.c_void_p(seg_i.data_ptr()), len(parts), Q, k, k, 0, 0,
+                    C.c_void_p(scores_ptr), C.c_void_p(ids_ptr), 1, self.device, stream))
+        return comm.allgather_merge_device(payload, Q, k, k)
 
     def _subset(self, kind: str, mask: np.ndarray):
         """A shard holding only this rank's rows that pass `mask` (Milvus filters before it searches,
         milvus_base.py:240-262, so a selective filter must still return its best rows however far down the unfiltered
         ranking they are).  Built from the host copies, cached per (kind, mask) until the next insert / delete; returns
-        (shard or None, global row of each subset row) -- rows ascending, so the kernels' `(score desc, id asc)` order
-        carries over."""
+        (segments, global row of each subset row, device copy of that table) -- rows ascending, so the kernels'
+        `(score desc, id asc)` order carries over."""
         key = (kind, mask.tobytes())
         with self._mu:
             hit = self._subsets.get(key)
             if hit is None:
-                owned = np.asarray(self._owned, dtype=np.int64)
+                owned = self._owned.data
                 known = owned < len(mask)                     # rows inserted after the caller built its mask are not in it
                 local = np.nonzero(known & mask[np.where(known, owned, 0)])[0] if len(owned) else np.zeros(0, np.int64)
                 shard = None
                 if len(local) and kind == "dense":
                     shard = DenseShard(self.dense_dim, len(local), self.dense_dtype, self.device)
-                    shard.add(np.stack([self._dense_rows[j] for j in local]))
+                    shard.add(self._dense_rows.data[local])
                 elif len(local):
-                    shard = SparseShard(self.sparse_vocab, *dicts_to_csr([self._sparse_rows[j] for j in local]), device=self.device)
+                    shard = SparseShard(self.sparse_vocab, *csr_take_rows(self._sp_ptr.data, self._sp_idx.data, self._sp_val.data, local),
+                                        device=self.device)
+                rows = owned[local] if len(owned) else local
+                dev = None
+                if shard is not None and self._comm is not None and self._comm.on_gpu:
+                    import torch
+
+                    dev = (torch.from_numpy(np.ascontiguousarray(rows)).to(torch.device("cuda", self.device)), len(rows))
                 while len(self._subsets) >= self.SUBSET_CACHE:
                     self._subsets.pop(next(iter(self._subsets)))          # freed when its last user lets go
-                hit = self._subsets[key] = (shard, owned[local] if len(owned) else local)
+                hit = self._subsets[key] = ([(shard, 0)] if shard is not None else [], rows, dev)
             return hit
 
     def _drop_subsets(self):
@@ -746,7 +1041,7 @@ class GpuVectorStore(VectorStore):
         if limit > self.K_LIMIT:
             raise ValueError(f"GpuVectorStore: a search may ask for at most {self.K_LIMIT} rows per method "
                              f"(got {limit}; hybrid search asks for 2 * top_k)")
-        main, n = self._main_shard(kind)
+        parts, rows_dev, n = self._main_parts(kind)
         if mask is not None and len(mask) != n:     # rows were inserted after the caller built its mask
             mask = np.concatenate([mask, np.zeros(n - len(mask), dtype=bool)]) if len(mask) < n else mask[:n]
         Q = len(queries)
@@ -759,7 +1054,7 @@ class GpuVectorStore(VectorStore):
         want = min(k, n_pass)
         short = np.ones(Q, dtype=bool)
         if mask is None or n_pass * 8 >= n:
-            scores, rows = self._device_topk(kind, main, None, queries, k)
+            scores, rows = self._device_topk(kind, parts, None, queries, k, rows_dev)
             if (rows >= n).any() and _retry < 3:      # rows inserted while this search ran took slots: search again
                 return self._topk_rows(kind, queries, limit, mask, _retry + 1)
             rows = np.where(rows < n, rows, -1)
@@ -777,9 +1072,9 @@ class GpuVectorStore(VectorStore):
             score_out[done, :k] = np.where(rows_c[done] >= 0, scores_c[done], np.float32(0.0))
             short = ~done
         if short.any():
-            shard, shard_rows = self._subset(kind, mask)
+            sub_parts, shard_rows, sub_dev = self._subset(kind, mask)
             which = np.nonzero(short)[0]
-            scores, rows = self._device_topk(kind, shard, shard_rows, [queries[i] for i in which], want)
+            scores, rows = self._device_topk(kind, sub_parts, shard_rows, [queries[i] for i in which], want, sub_dev)
             rows_out[which, :want] = rows
             score_out[which, :want] = np.where(rows >= 0, scores, np.float32(0.0))
         return rows_out, score_out
@@ -788,31 +1083,28 @@ class GpuVectorStore(VectorStore):
         rows, scores = self._topk_rows(kind, queries, limit, mask)
         return [[self._hit(int(r), float(v)) for r, v in zip(rows[i], scores[i]) if r >= 0] for i in range(len(queries))]
 
-    def _results_rows(self, rows: np.ndarray, distances: np.ndarray) -> List[SearchResult]:
-        return self._results([{"id": self._ids[r], "distance": float(d), "_row": int(r)} for r, d in zip(rows, distances) if r >= 0])
-
-    RRF_VECTOR_MAX = 64   # candidate lists up to this long are merged for the whole batch at once (an [Q, L, L] compare)
+    def _results_batch(self, rows: np.ndarray, distances: np.ndarray) -> List[List[SearchResult]]:
+        """`[Q, k]` merged rows / scores -> result lists; the payloads of the whole batch are fetched at once."""
+        pay = self._payloads(rows.reshape(-1))
+        ids = self._ids
+        return [[SearchResult(id=ids[r], score=float(d), metadata=dict(pay[r][2]), text=pay[r][0], enhanced_text=pay[r][1])
+                 for r, d in zip(rows[i].tolist(), distances[i].tolist()) if r >= 0] for i in range(rows.shape[0])]
 
     def _hybrid_batch(self, dq, sq, top_k, mask, weights, rrf_k) -> List[List[SearchResult]]:
         """Both methods for all queries, then weighted RRF: one array merge for the whole batch, or query by query when
-        the lists are long (the `[Q, L, L]` compare) or an id is falsy (such hits keep their rank but are skipped)."""
+        an id is falsy (such hits keep their rank but are skipped)."""
         limit = top_k * 2
         rows_d, sc_d = self._topk_rows("dense", dq, limit, mask)
         rows_s, sc_s = self._topk_rows("sparse", sq, limit, mask)
-        if limit <= self.RRF_VECTOR_MAX and self._ids_truthy():
+        if self._all_ids_truthy:
             rows, dist = rrf_merge_rows({"dense": rows_d, "sparse": rows_s}, top_k, weights, rrf_k)
-            return [self._results_rows(rows[i], dist[i]) for i in range(len(dq))]
+            return self._results_batch(rows, dist)
         out = []
         for i in range(len(dq)):
             rbm = {"dense": [self._hit(int(r), float(v)) for r, v in zip(rows_d[i], sc_d[i]) if r >= 0],
                    "sparse": [self._hit(int(r), float(v)) for r, v in zip(rows_s[i], sc_s[i]) if r >= 0]}
             out.append(self._results(merge_hybrid_results(rbm, top_k, weights, rrf_k)))
         return out
-
-    def _ids_truthy(self) -> bool:
-        if self._all_ids_truthy is None:
-            self._all_ids_truthy = all(bool(x) for x in self._ids)
-        return self._all_ids_truthy
 
     def query_batch(self, dense_queries: Optional[Sequence[Any]] = None, sparse_queries: Optional[Sequence[Any]] = None,
                     text_queries: Optional[Sequence[Optional[str]]] = None, top_k: int = 5, search_type: str = "hybrid",
@@ -824,7 +1116,8 @@ class GpuVectorStore(VectorStore):
         side branches (no vectors, a missing half in hybrid mode) are answered by `query` itself.  On a bf16 shard a
         batch of >= 3 dense queries runs on the matrix cores with every fp32 query carried as a (bf16, bf16 remainder)
         pair (16 significant bits; include/vrag_amd.h, vrag_dense_index_search): scores then agree with the single-query
-        fp32 path to fp32 summation noise; an f32 shard (the default) uses fp32 queries at every batch size."""
+        fp32 path to fp32 summation noise; an f32 shard (the default) uses fp32 queries at every batch size.
+        `top_k` (2 * top_k in hybrid mode) may not exceed `K_LIMIT` = 1024: ValueError otherwise."""
         n = max(len(x) for x in (dense_queries, sparse_queries, text_queries) if x is not None)
         dq = list(dense_queries) if dense_queries is not None else [None] * n
         sq = list(sparse_queries) if sparse_queries is not None else [None] * n
@@ -852,42 +1145,44 @@ class GpuVectorStore(VectorStore):
             if use_d and use_s:
                 return self._hybrid_batch(dq, sq, top_k, mask, weights, rrf_k)
             rows, scores = self._topk_rows("dense" if use_d else "sparse", dq if use_d else sq, top_k * 2, mask)
-            return [self._results_rows(rows[i, :top_k], scores[i, :top_k]) for i in range(n)]   # one method: its first top_k
+            return self._results_batch(rows[:, :top_k], scores[:, :top_k])   # one method: its first top_k
         if search_type == "dense" and all(is_set(q) for q in dq):
             mask = self._mask(filter)
-            rows, scores = self._topk_rows("dense", dq, top_k, mask)
-            return [self._results_rows(rows[i], scores[i]) for i in range(n)]
+            return self._results_batch(*self._topk_rows("dense", dq, top_k, mask))
         if search_type == "sparse" and all(is_set(q) for q in sq):
             mask = self._mask(filter)
-            rows, scores = self._topk_rows("sparse", sq, top_k, mask)
-            return [self._results_rows(rows[i], scores[i]) for i in range(n)]
+            return self._results_batch(*self._topk_rows("sparse", sq, top_k, mask))
         if search_type == "hybrid" and all(is_set(q) for q in dq) and all(is_set(q) for q in sq):
             mask = self._mask(filter)
             try:
                 return self._hybrid_batch(dq, sq, top_k, mask, {"dense": 0.5, "sparse": 0.5}, rrf_k)
             except Exception as e:
+                if self._world > 1:
+                    raise                                  # ranks must not diverge into different collectives
                 logger.warning("Batched hybrid search failed: %s, answering per query", e)
         return [single(i) for i in range(n)]
 
     def query(self, dense_query=None, sparse_query=None, text_query=None, top_k: int = 5, search_type: str = "hybrid",
               filter: Optional[str] = None, search_params: Optional[Dict[str, Any]] = None,
               hybrid_weights: Optional[Dict[str, float]] = None, rrf_k: int = 60) -> List[SearchResult]:
-        """milvus_base.py:189-313."""
+        """milvus_base.py:189-313.  `top_k` (2 * top_k in hybrid mode) may not exceed `K_LIMIT` = 1024."""
         if hybrid_weights is not None:
             return self._hybrid_search_with_weights(dense_query, sparse_query, text_query, top_k, filter, hybrid_weights, rrf_k)
-        if not dense_query and not sparse_query:
+        if not _is_given(dense_query) and not _is_given(sparse_query):
             return self._filter_only_query(filter, top_k)
         mask = self._mask(filter)
-        if search_type == "dense" and dense_query:
+        if search_type == "dense" and _is_given(dense_query):
             hits = self._search("dense", dense_query, top_k, mask)
-        elif search_type == "sparse" and sparse_query:
+        elif search_type == "sparse" and _is_given(sparse_query):
             hits = self._search("sparse", sparse_query, top_k, mask)
-        elif search_type == "hybrid" and dense_query and sparse_query:
+        elif search_type == "hybrid" and _is_given(dense_query) and _is_given(sparse_query):
             try:
                 rbm = {"dense": self._search("dense", dense_query, top_k * 2, mask),
                        "sparse": self._search("sparse", sparse_query, top_k * 2, mask)}
                 hits = merge_hybrid_results(rbm, top_k, {"dense": 0.5, "sparse": 0.5}, rrf_k=rrf_k)
             except Exception as e:  # milvus_base.py:296-306
+                if self._world > 1:
+                    raise
                 logger.warning("Hybrid search failed: %s, falling back to dense search", e)
                 hits = self._search("dense", dense_query, top_k, mask)
         else:
@@ -897,9 +1192,8 @@ class GpuVectorStore(VectorStore):
 
     def _filter_only_query(self, filter: Optional[str], limit: int) -> List[SearchResult]:
         mask = self._mask(filter)
-        rows = [i for i in range(len(self._ids)) if mask is None or mask[i]][:limit]
-        return [SearchResult(id=self._ids[i], score=1.0, metadata=dict(self._meta[i]), text=self._texts[i],
-                             enhanced_text=self._enh[i]) for i in rows]
+        rows = (np.arange(min(limit, len(self._ids))) if mask is None else np.nonzero(mask)[0][:limit]).astype(np.int64)
+        return self._results_batch(rows[None, :], np.ones((1, len(rows))))[0]
 
     def _hybrid_search_with_weights(self, dense_query, sparse_query, text_query, top_k, filter, hybrid_weights, rrf_k):
         """milvus_base.py:366-459."""
@@ -946,68 +1240,165 @@ class GpuVectorStore(VectorStore):
             return dict(row) if row is not None else None
 
     # -------------------------------------------------------------- persistence
+    FORMAT = 3
+
     def save(self, path: str) -> None:
-        """Writes the store to a directory: `rows.json` (ids, texts, enhanced texts, metadata; deleted rows are dropped)
-        and one `vectors.rank{r}.npz` per rank (that rank's packed unit dense rows and sparse CSR plus the row numbers
-        they belong to).  The reference persists through the Milvus-lite database file (milvus_local.py:39-56); this is
-        the GPU store's own on-disk format.  Sharded stores: every rank calls `save` with the same path."""
+        """Writes the store to a directory (deleted rows are dropped): `store.json` (geometry, document records) and
+        `ids.json` by rank 0; per rank `vectors.rank{r}.npz` (its packed unit dense rows, sparse CSR and the row numbers
+        they belong to) and `payload.rank{r}.json` (texts, enhanced texts, metadata of those rows).  Every file is
+        written beside its final name and renamed into place, and a sharded `save` ends in a barrier, so a `load` that
+        follows on any rank reads complete files.  The reference persists through the Milvus-lite database file
+        (milvus_local.py:39-56); this is the GPU store's own on-disk format.  Sharded stores: every rank calls `save`
+        with the same path."""
         import os
 
         os.makedirs(path, exist_ok=True)
-        alive = np.asarray(self._alive, dtype=bool)
-        keep = np.nonzero(alive)[0]
-        new_row = np.cumsum(alive) - 1                                   # row number after dropping the deleted rows
-        local = [j for j, g in enumerate(self._owned) if alive[g]]
-        arrays: Dict[str, np.ndarray] = {"owned": np.asarray([new_row[self._owned[j]] for j in local], dtype=np.int64)}
-        if self.enable_dense:
-            arrays["dense"] = (np.stack([self._dense_rows[j] for j in local]).astype(np.float32) if local
-                               else np.zeros((0, self.dense_dim or 0), np.float32))
-        if self.enable_sparse:
-            indptr, indices, values = dicts_to_csr([self._sparse_rows[j] for j in local])
-            arrays.update(sp_indptr=indptr, sp_indices=indices, sp_values=values)
-        np.savez(os.path.join(path, f"vectors.rank{self._rank}.npz"), **arrays)
-        if self._rank == 0:
-            with open(os.path.join(path, "rows.json"), "w", encoding="utf-8") as f:
-                json.dump({"format": 2, "world": self._world, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
-                           "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse,
-                           "dense_dtype": self.dense_dtype, "ids": [self._ids[i] for i in keep],
-                           "texts": [self._texts[i] for i in keep], "enhanced_texts": [self._enh[i] for i in keep],
-                           "metadatas": [self._meta[i] for i in keep], "documents": list(self._documents.values())},
-                          f, ensure_ascii=False)
+        with self._mu:
+            alive = self._alive.data.copy()
+            owned = self._owned.data
+            new_row = np.cumsum(alive) - 1                                   # row number after dropping the deleted rows
+            local = np.nonzero(alive[owned])[0] if len(owned) else np.zeros(0, np.int64)
+            arrays: Dict[str, np.ndarray] = {"owned": new_row[owned[local]].astype(np.int64)}
+            if self.enable_dense:
+                arrays["dense"] = np.ascontiguousarray(self._dense_rows.data[local], dtype=np.float32)
+            if self.enable_sparse:
+                indptr, indices, values = csr_take_rows(self._sp_ptr.data, self._sp_idx.data, self._sp_val.data, local)
+                arrays.update(sp_indptr=indptr, sp_indices=indices, sp_values=values)
+            # texts / metadata lists are indexed by local row, or by global row when a sharded store replicates them
+            slots = local if (self._payload_sharded or self._world == 1) else owned[local]
+            payload = {"texts": [self._texts[j] for j in slots], "enhanced_texts": [self._enh[j] for j in slots],
+                       "metadatas": [self._meta[j] for j in slots]}
+            ids = [self._ids[i] for i in np.nonzero(alive)[0]]
+            head = {"format": self.FORMAT, "world": self._world, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
+                    "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse, "dense_dtype": self.dense_dtype,
+                    "rows": len(ids), "documents": list(self._documents.values())}
 
-    @classmethod
-    def load(cls, path: str, device: int = 0, distributed: bool = False, group=None, comm=None) -> "GpuVectorStore":
-        """Reads a directory written by `save` (by a store of the same world size)."""
+        def put_json(name, obj):
+            tmp = os.path.join(path, f".{name}.tmp{os.getpid()}")
+            with open(tmp, "w", encoding="utf-8") as f:
+                json.dump(obj, f, ensure_ascii=False)
+            os.replace(tmp, os.path.join(path, name))
+
+        tmp = os.path.join(path, f".vectors.rank{self._rank}.tmp{os.getpid()}.npz")
+        np.savez(tmp, **arrays)
+        os.replace(tmp, os.path.join(path, f"vectors.rank{self._rank}.npz"))
+        put_json(f"payload.rank{self._rank}.json", payload)
+        if self._rank == 0:
+            put_json("ids.json", ids)
+            put_json("store.json", head)
+        if self._world > 1:
+            self._comm.barrier()
+
+    @staticmethod
+    def _read_saved(path: str):
+        """Any on-disk format -> (head, ids, [per saved rank: (owned rows, arrays, texts, enhanced, metadatas)]).
+        Format 3 = `save` above; format 2 = `rows.json` holding ids / texts / metadata for all rows beside
+        `vectors.rank{r}.npz`; format 1 = `rows.json` + one `vectors.npz` in row order (single GPU)."""
         import os
 
-        with open(os.path.join(path, "rows.json"), encoding="utf-8") as f:
-            rows = json.load(f)
-        if rows.get("format") != 2:
-            raise ValueError(f"{path}: unknown GpuVectorStore format {rows.get('format')!r}")
-        st = cls(dense_dim=rows["dense_dim"], sparse_vocab=rows["sparse_vocab"], enable_dense=rows["enable_dense"],
-                 enable_sparse=rows["enable_sparse"], dense_dtype=rows["dense_dtype"], device=device,
-                 distributed=distributed, group=group, comm=comm)
-        if rows.get("world", 1) != st._world:
-            raise ValueError(f"{path}: written by {rows.get('world', 1)} rank(s), opened by {st._world}")
-        z = np.load(os.path.join(path, f"vectors.rank{st._rank}.npz"))
-        n = len(rows["ids"])
-        st._ids, st._texts, st._enh = list(rows["ids"]), list(rows["texts"]), list(rows["enhanced_texts"])
-        st._meta = [dict(m) for m in rows["metadatas"]]
-        st._documents = {d.get("id", ""): dict(d) for d in rows.get("documents", [])}
-        st._alive = [True] * n
-        st._owned = [int(g) for g in z["owned"]]
-        m = len(st._owned)
-        if m and (min(st._owned) < 0 or max(st._owned) >= n):
-            raise ValueError(f"{path}: shard rows outside the {n} stored ids")
+        def get_json(name):
+            with open(os.path.join(path, name), encoding="utf-8") as f:
+                return json.load(f)
+
+        if os.path.exists(os.path.join(path, "store.json")):
+            head = get_json("store.json")
+            if head.get("format") != 3:
+                raise ValueError(f"{path}: unknown GpuVectorStore format {head.get('format')!r}")
+            ids = get_json("ids.json")
+            shards = []
+            for r in range(head.get("world", 1)):
+                z = np.load(os.path.join(path, f"vectors.rank{r}.npz"))
+                pay = get_json(f"payload.rank{r}.json")
+                shards.append((z["owned"], z, pay["texts"], pay["enhanced_texts"], pay["metadatas"]))
+            return head, ids, shards
+        rows = get_json("rows.json")
+        fmt = rows.get("format")
+        if fmt not in (1, 2):
+            raise ValueError(f"{path}: unknown GpuVectorStore format {fmt!r}")
+        ids = list(rows["ids"])
+        head = {k: rows.get(k) for k in ("dense_dim", "sparse_vocab", "enable_dense", "enable_sparse", "dense_dtype")}
+        head.update(world=rows.get("world", 1) if fmt == 2 else 1, rows=len(ids), documents=rows.get("documents", []))
+        shards = []
+        for r in range(head["world"]):
+            z = np.load(os.path.join(path, "vectors.npz" if fmt == 1 else f"vectors.rank{r}.npz"))
+            owned = np.arange(len(ids), dtype=np.int64) if fmt == 1 else z["owned"]
+            shards.append((owned, z, [rows["texts"][g] for g in owned], [rows["enhanced_texts"][g] for g in owned],
+                           [rows["metadatas"][g] for g in owned]))
+        return head, ids, shards
+
+    @classmethod
+    def load(cls, path: str, device: int = 0, distributed: bool = False, group=None, comm=None,
+             payload: str = "sharded") -> "GpuVectorStore":
+        """Reads a directory written by `save` -- by this or an earlier revision (formats 1 - 3), by any number of
+        ranks: when the world size differs from the writer's, the saved shards are put back in row order and cut
+        contiguously over the ranks that open the store."""
+        head, ids, shards = cls._read_saved(path)
+        st = cls(dense_dim=head["dense_dim"], sparse_vocab=head["sparse_vocab"], enable_dense=head["enable_dense"],
+                 enable_sparse=head["enable_sparse"], dense_dtype=head["dense_dtype"], device=device,
+                 distributed=distributed, group=group, comm=comm, payload=payload)
+        n = len(ids)
+        for owned, *_ in shards:
+            if len(owned) and (owned.min() < 0 or owned.max() >= n):
+                raise ValueError(f"{path}: shard rows outside the {n} stored ids")
+        if len(shards) == st._world:
+            owned, z, texts, enh, metas = shards[st._rank]
+            owned = np.asarray(owned, dtype=np.int64)
+            dense = z["dense"] if st.enable_dense else None
+            csr = (z["sp_indptr"], z["sp_indices"], z["sp_values"]) if st.enable_sparse else None
+        else:                                                     # re-shard: everything back in row order, my contiguous cut
+            from .distributed import shard_range
+
+            all_owned = np.concatenate([np.asarray(o, dtype=np.int64) for o, *_ in shards]) if shards else np.zeros(0, np.int64)
+            order = np.argsort(all_owned, kind="stable")
+            lo, hi = shard_range(n, st._rank, st._world)
+            pick = order[lo:hi]                                   # positions in the concatenation of the saved shards
+            owned = all_owned[pick]
+            texts_all = [t for _o, _z, tx, _e, _m in shards for t in tx]
+            enh_all = [t for _o, _z, _tx, e, _m in shards for t in e]
+            meta_all = [t for _o, _z, _tx, _e, m in shards for t in m]
+            texts, enh, metas = [texts_all[i] for i in pick], [enh_all[i] for i in pick], [meta_all[i] for i in pick]
+            dense = np.concatenate([z["dense"] for _o, z, *_ in shards])[pick] if st.enable_dense else None
+            csr = None
+            if st.enable_sparse:
+                ptrs, idxs, vals, off = [np.zeros(1, np.int64)], [], [], 0
+                for _o, z, *_ in shards:
+                    ptrs.append(z["sp_indptr"][1:].astype(np.int64) + off)
+                    idxs.append(z["sp_indices"])
+                    vals.append(z["sp_values"])
+                    off += int(z["sp_indptr"][-1])
+                csr = csr_take_rows(np.concatenate(ptrs), np.concatenate(idxs), np.concatenate(vals), pick)
+        m = len(owned)
+        covered = np.concatenate([np.asarray(o, dtype=np.int64) for o, *_ in shards]) if shards else np.zeros(0, np.int64)
+        if len(covered) != n or len(np.unique(covered)) != n:
+            raise ValueError(f"{path}: the saved shards do not cover the {n} stored ids exactly once")
+        st._ids = list(ids)
+        st._all_ids_truthy = all(bool(x) for x in st._ids)
+        st._documents = {d.get("id", ""): dict(d) for d in head.get("documents", [])}
+        st._alive.extend(np.ones(n, dtype=bool))
+        st._owned.extend(owned)
+        if st._payload_sharded or st._world == 1:
+            st._texts, st._enh, st._meta = list(texts), list(enh), [dict(x) for x in metas]
+        else:                                                     # replicated payload: every rank needs every row's
+            st._texts, st._enh, st._meta = [""] * n, [""] * n, [{} for _ in range(n)]
+            for o, _z, tx, e, mm in shards:
+                for g, t1, t2, t3 in zip(np.asarray(o).tolist(), tx, e, mm):
+                    st._texts[g], st._enh[g], st._meta[g] = t1, t2, dict(t3)
         if st.enable_dense:
-            d = z["dense"]
-            if d.shape[0] != m:
-                raise ValueError(f"{path}: {d.shape[0]} dense rows for {m} shard rows")
-            st._dense_rows = [d[i] for i in range(m)]
+            if dense.shape[0] != m:
+                raise ValueError(f"{path}: {dense.shape[0]} dense rows for {m} shard rows")
+            st._dense_rows.extend(np.asarray(dense, dtype=np.float32))
         if st.enable_sparse:
-            ip, ix, vv = z["sp_indptr"], z["sp_indices"], z["sp_values"]
+            ip, ix, vv = csr
             if len(ip) != m + 1:
                 raise ValueError(f"{path}: sparse indptr has {len(ip)} entries for {m} shard rows")
-            st._sparse_rows = [{int(k): float(v) for k, v in zip(ix[ip[i]:ip[i + 1]], vv[ip[i]:ip[i + 1]])} for i in range(m)]
+            st._sp_ptr.extend(np.asarray(ip[1:], dtype=np.int64))
+            st._sp_idx.extend(np.asarray(ix, dtype=np.int32))
+            st._sp_val.extend(np.asarray(vv, dtype=np.float32))
         st._dirty = n > 0
         return st
+
+
+def _is_given(q) -> bool:
+    """Truthiness of a query vector the way the reference tests it (`if dense_query`, milvus_base.py:232-254), for
+    lists, dicts and numpy rows alike."""
+    return q is not None and len(q) > 0

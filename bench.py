@@ -205,30 +205,36 @@ def topk_recall_check(seed: int = 1234):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def sharded_retrieval_leg(rank: int, world: int, device: int, rows_per_rank: int = 200_000, dim: int = 768, nq: int = 64,
+def _grid_rows(n: int, dim: int, seed: int) -> np.ndarray:
+    """`[n, dim]` fp32 rows on the dyadic grid k / 64 (dot products exact in fp32 in any order), filled slab by slab."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, dim), np.float32)
+    for a in range(0, n, 65536):
+        b = min(n, a + 65536)
+        np.multiply(rng.integers(-64, 65, size=(b - a, dim), dtype=np.int8), np.float32(1.0 / 64.0), out=out[a:b])
+    return out
+
+
+def sharded_retrieval_leg(rank: int, world: int, device: int, rows_per_rank: int = 1_250_000, dim: int = 768, nq: int = 64,
                           k: int = 10, reps: int = 5):
-    """The exchange step of the path on N > 1 ranks (BASELINE configs[3] at reduced size; north_star: "RCCL all-gather
-    of per-shard top-k for the final merge"): every rank searches its own fp32 row shard on its GPU, ONE
-    all_gather_into_tensor carries the [Q, k] lists, `vrag_topk_merge` merges them on every GPU.  Outside the timed
-    region of the headline metric; returns a small report on rank 0 (never raises)."""
+    """The exchange step of the path on N > 1 ranks at BASELINE configs[3]'s per-GPU size (10^7 x 768 rows over 8 GPUs =
+    1.25 * 10^6 per rank; north_star: "RCCL all-gather of per-shard top-k for the final merge"): every rank searches its
+    own fp32 row shard on its GPU, the `[Q, k]` lists stay in HBM (`vrag_dense_index_search_device`), ONE
+    all_gather_into_tensor carries them, `vrag_topk_merge` merges them on every GPU.  Outside the timed region of the
+    headline metric; returns a small report on rank 0 (never raises)."""
     try:
         import torch.distributed as dist
 
         from verbatim_rag_amd.distributed import ShardedTopK, merge_topk
         from verbatim_rag_amd.vector_stores import DenseShard
 
-        rng = np.random.default_rng(77 + rank)
-        X = (rng.integers(-64, 65, size=(rows_per_rank, dim)) / 64.0).astype(np.float32)       # dyadic grid: exact sums
-        Q = (np.random.default_rng(5).integers(-64, 65, size=(nq, dim)) / 64.0).astype(np.float32)
+        rows_per_rank = int(os.environ.get("VRAG_BENCH_SHARD_ROWS", rows_per_rank))
+        X = _grid_rows(rows_per_rank, dim, 77 + rank)
+        Q = _grid_rows(nq, dim, 5)
         shard = DenseShard(dim, rows_per_rank, "f32", device)
         shard.add(X)
-        local = {}
-
-        def search(qs, kk):
-            local["lists"] = shard.search(qs, kk)
-            return local["lists"]
-
-        topk = ShardedTopK(search, shard_base=rank * rows_per_rank, device=device)
+        del X
+        topk = ShardedTopK(shard.search, shard_base=rank * rows_per_rank, device=device, shard=shard)
         s, i = topk.search(Q, k)                                                                 # warm-up + the checked result
         dist.barrier()
         t0 = time.perf_counter()
@@ -236,16 +242,17 @@ def sharded_retrieval_leg(rank: int, world: int, device: int, rows_per_rank: int
             topk.search(Q, k)
         dist.barrier()
         dt = (time.perf_counter() - t0) / reps
-        ls, li = local["lists"]
+        ls, li = shard.search(Q, k)                                                              # the host-side statement of the same lists
         gathered = [None] * world
         dist.all_gather_object(gathered, (ls, np.where(li >= 0, li + rank * rows_per_rank, -1)))
         shard.close()
         if rank != 0:
             return None
         hs, hi = merge_topk(np.stack([g[0] for g in gathered]), np.stack([g[1] for g in gathered]).astype(np.int64), k)
-        return {"rows_total": rows_per_rank * world, "dim": dim, "rows_dtype": "f32", "queries": nq, "k": k,
+        return {"rows_total": rows_per_rank * world, "rows_per_rank": rows_per_rank, "dim": dim, "rows_dtype": "f32", "queries": nq, "k": k,
                 "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
                 "collective": f"one all_gather_into_tensor of {nq * k * 12} B per rank ({dist.get_backend()}), merge on every GPU",
+                "lists_device_resident": bool(topk._comm is not None and topk._comm.on_gpu),
                 "merged_equals_host_merge_of_shard_lists": bool(np.array_equal(hi, i) and np.array_equal(hs, s))}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}

@@ -28,19 +28,22 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
     return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
 
 
-def dense_topk(rows: np.ndarray, queries: np.ndarray, k: int):
+def dense_topk(rows: np.ndarray, queries: np.ndarray, k: int, blocked: bool = False):
+    """`blocked=True`: the loop nest for full-size shards (16 queries per pass over a row, rows cut over the OpenMP
+    threads); the same fmaf chains, bit-identical results."""
     rows = np.ascontiguousarray(rows, dtype=np.float32)
     queries = np.ascontiguousarray(queries, dtype=np.float32)
     nq, dim = queries.shape
     scores = np.empty((nq, k), np.float32)
     ids = np.empty((nq, k), np.int64)
     fp, lp = C.POINTER(C.c_float), C.POINTER(C.c_int64)
-    _lib().dense_topk_ref(rows.ctypes.data_as(fp), C.c_int64(rows.shape[0]), C.c_int(dim), queries.ctypes.data_as(fp),
+    fn = _lib().dense_topk_ref_blocked if blocked else _lib().dense_topk_ref
+    fn(rows.ctypes.data_as(fp), C.c_int64(rows.shape[0]), C.c_int(dim), queries.ctypes.data_as(fp),
                           C.c_int(nq), C.c_int(k), scores.ctypes.data_as(fp), ids.ctypes.data_as(lp))
     return scores, ids
 
 
-def sparse_topk(indptr, indices, values, vocab: int, q_indptr, q_indices, q_values, k: int):
+def sparse_topk(indptr, indices, values, vocab: int, q_indptr, q_indices, q_values, k: int, blocked: bool = False):
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
     indices = np.ascontiguousarray(indices, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.float32)
@@ -51,7 +54,8 @@ def sparse_topk(indptr, indices, values, vocab: int, q_indptr, q_indices, q_valu
     scores = np.empty((nq, k), np.float32)
     ids = np.empty((nq, k), np.int64)
     fp, lp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
-    _lib().sparse_topk_ref(C.c_int64(len(indptr) - 1), indptr.ctypes.data_as(lp), indices.ctypes.data_as(ip),
+    fn = _lib().sparse_topk_ref_blocked if blocked else _lib().sparse_topk_ref
+    fn(C.c_int64(len(indptr) - 1), indptr.ctypes.data_as(lp), indices.ctypes.data_as(ip),
                            values.ctypes.data_as(fp), C.c_int(vocab), q_indptr.ctypes.data_as(lp),
                            q_indices.ctypes.data_as(ip), q_values.ctypes.data_as(fp), C.c_int(nq), C.c_int(k),
                            scores.ctypes.data_as(fp), ids.ctypes.data_as(lp))

@@ -156,3 +156,103 @@ def _store_worker(rank, world, port, q):
 
 def test_sharded_store_world2_gloo_equals_single_rank():
     assert _run_world(_store_worker) == [(0, True), (1, True)]
+
+
+def _reshard_worker(rank, world, port, q):
+    """Round 3: (a) `payload="replicated"` answers like the default sharded payload; (b) a directory saved by 2 ranks is
+    opened by 2 ranks and -- in the parent -- by 1, and one saved by 1 rank is opened by 2 (re-cut on load);
+    (c) a 10^7-row store: sharded ingest (5 * 10^6 rows per rank), save, load, same answers."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    try:
+        import time
+
+        import torch.distributed as dist
+
+        import verbatim_rag_amd  # noqa: F401
+        from tests.sharded_store_cases import build_and_query, cpu_stand_ins
+        from verbatim_rag_amd import vector_stores as vs
+        from verbatim_rag_amd.distributed import ShardComm, merge_topk
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [os.environ["VRAG_TEST_DIR"]]
+        ok = True
+        with cpu_stand_ins():
+            comm = ShardComm(merge=merge_topk)
+            rng = np.random.default_rng(3)
+            n, dim, vocab = 203, 64, 300
+            dense = np.where(rng.random((n, dim)) < 0.5, 0.5, -0.5).astype(np.float32)
+            sparse = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 7, replace=False), rng.integers(1, 64, 7) / 64)} for _ in range(n)]
+
+            def fill(**kw):
+                st = vs.GpuVectorStore(dense_dim=dim, sparse_vocab=vocab, **kw)
+                st.add_vectors([f"r{i}" for i in range(n)], dense, sparse, [f"t{i}" for i in range(n)], [f"e{i}" for i in range(n)],
+                               [{"document_id": f"d{i % 5}", "n": i} for i in range(n)])
+                st.delete(["r5", "r100"])
+                return st
+
+            def ask(st):
+                out = []
+                for kw in (dict(search_type="dense", top_k=6), dict(search_type="hybrid", top_k=5),
+                           dict(search_type="sparse", top_k=4, filter='metadata["document_id"] == "d3"')):
+                    res = st.query_batch(dense_queries=[dense[9].tolist(), dense[77].tolist()], sparse_queries=[sparse[9], sparse[77]], **kw)
+                    out.append([[(r.id, r.score, r.text, r.enhanced_text, sorted(r.metadata.items())) for r in rs] for rs in res])
+                out.append([(r.id, r.text) for r in st.query(top_k=4, filter='metadata["n"] in [7, 8, 9, 100]')])     # filter-only browse
+                return out
+
+            sharded, replicated = fill(comm=comm), fill(comm=comm, payload="replicated")
+            want = ask(sharded)
+            if ask(replicated) != want or len(sharded._texts) not in (101, 102) or len(replicated._texts) != n:
+                ok = "replicated payload answers differ from the sharded payload"
+            sharded.save(os.path.join(box[0], "by2"))                         # ends in a barrier
+            if ok is True and ask(vs.GpuVectorStore.load(os.path.join(box[0], "by2"), comm=comm)) != want:
+                ok = "2 ranks -> 2 ranks: answers changed"
+            if rank == 0:
+                single = vs.GpuVectorStore(dense_dim=dim, sparse_vocab=vocab)
+                single.add_vectors([f"r{i}" for i in range(n)], dense, sparse, [f"t{i}" for i in range(n)], [f"e{i}" for i in range(n)],
+                                   [{"document_id": f"d{i % 5}", "n": i} for i in range(n)])
+                single.delete(["r5", "r100"])
+                if ok is True and ask(single) != want:
+                    ok = "single-rank store answers differ"
+                single.save(os.path.join(box[0], "by1"))
+                if ok is True and ask(vs.GpuVectorStore.load(os.path.join(box[0], "by2"))) != want:
+                    ok = "2 ranks -> 1 rank: answers changed"
+            dist.barrier()
+            back = vs.GpuVectorStore.load(os.path.join(box[0], "by1"), comm=comm)
+            if ok is True and (ask(back) != want or len(back._owned) not in (100, 101)):
+                ok = "1 rank -> 2 ranks: answers changed"
+            # (c) 10^7 rows
+            big = int(os.environ.get("VRAG_TEST_BIG_ROWS", "10000000"))
+            t0 = time.perf_counter()
+            X = np.where(np.random.default_rng(11).random((big, 8)) < 0.5, 0.5, -0.5).astype(np.float32)
+            X[12345] = 0.0
+            X[12345, 0] = 1.0                                                 # the only one-hot row: its own best match
+            st = vs.GpuVectorStore(dense_dim=8, enable_sparse=False, sparse_vocab=None, comm=comm)
+            st.add_vectors([f"r{i}" for i in range(big)], X, None, [""] * big, [""] * big, [None] * big)
+            first = [(r.id, r.score) for r in st.query(dense_query=X[12345].tolist(), top_k=3, search_type="dense")]
+            st.delete([first[1][0]])
+            second = [(r.id, r.score) for r in st.query(dense_query=X[12345].tolist(), top_k=3, search_type="dense")]
+            st.save(os.path.join(box[0], "big"))
+            st2 = vs.GpuVectorStore.load(os.path.join(box[0], "big"), comm=comm)
+            third = [(r.id, r.score) for r in st2.query(dense_query=X[12345].tolist(), top_k=3, search_type="dense")]
+            took = time.perf_counter() - t0
+            if ok is True and not (first[0][0] == "r12345" and second[0] == first[0] and first[1] not in second and third == second
+                                   and len(st2) == big - 1 and len(st2._owned) in (big // 2 - 1, big // 2)):
+                ok = f"10^7-row round trip: {first} {second} {third} {len(st2)}"
+            if rank == 0:
+                print(f"[gloo] {big}-row ingest + 3 queries + save + load on 2 ranks: {took:.1f} s", file=sys.stderr)
+        q.put((rank, ok))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
+
+
+def test_sharded_store_payload_modes_resharding_and_ten_million_rows(tmp_path):
+    os.environ["VRAG_TEST_DIR"] = str(tmp_path)
+    try:
+        assert _run_world(_reshard_worker, timeout=1500) == [(0, True), (1, True)]
+    finally:
+        os.environ.pop("VRAG_TEST_DIR", None)

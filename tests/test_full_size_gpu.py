@@ -1,0 +1,281 @@
+"""Retrieval parity at the single-GPU sizes BASELINE.json names, checked against the exact CPU oracle
+(oracle/topk_ref.c, blocked OpenMP form -- the same fmaf chains as the scalar form, tests/test_oracle_golden.py):
+
+  * configs[2]: a 10^6-document / ~1.28 * 10^8-nnz SELL-64 shard, 1 000 queries, k = 5 -- the 8-queries-per-pass kernel
+    and the single-query kernel, ids AND scores equal to the oracle;
+  * configs[3] (one GPU's slice of the 10^7-row index): 1.25 * 10^6 x 768 rows, fp32 (bit-exact on arbitrary data) and
+    bf16 (bit-exact on bf16-representable grid data), 1 / 32 / 256 queries;
+  * both through the PUBLIC ingest path -- `GpuVectorStore.add_vectors` (milvus_base.py:90-127) -> `query_batch` /
+    `query` (milvus_base.py:189-313) on a 10^6-chunk hybrid store: dense, sparse, hybrid (RRF), filtered, after a
+    delete and after an append (dense append + sparse tail segment);
+  * configs[4] slice: `StaticVerbatimPipeline.query_batch` over a hybrid store with the ModernBERT-large extractor at
+    full depth -- spans, highlights and citation offsets equal to the same pipeline with the extractor's logits
+    replaced by the fp32 oracle's (oracle/modernbert_np.py).
+"""
+import gc
+import json
+import os
+import time
+import types
+
+import numpy as np
+import pytest
+
+from oracle import topk_ref as T
+from tests import synth_corpus as S
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+VOCAB = 30522
+SCALE = float(os.environ.get("VRAG_TEST_SCALE", "1"))            # < 1: host-logic dry runs on CPU stand-ins
+N_SPARSE = int(1_000_000 * SCALE)
+N_DENSE = int(1_250_000 * SCALE)
+DIM = 768
+
+
+def _note(key, value):
+    """Timings for DESIGN.md: merged into gpurun_out/full_size_timings.json when that scratch directory exists."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if not os.path.isdir(root):
+        return
+    path = os.path.join(root, "full_size_timings.json")
+    try:
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = value
+        json.dump(data, open(path, "w"), indent=1)
+    except Exception:
+        pass
+
+
+@pytest.fixture(scope="module")
+def sparse_rows():
+    return S.sparse_corpus(N_SPARSE, VOCAB, seed=21)
+
+
+def test_configs2_sparse_shard_1m_docs_1000_queries(sparse_rows):
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    ip, ix, vv = sparse_rows
+    t0 = time.perf_counter()
+    sh = SparseShard(VOCAB, ip, ix, vv)
+    _note("sparse_shard_build_s", time.perf_counter() - t0)
+    st = sh.stats()
+    assert st["n_docs"] == N_SPARSE and st["nnz"] == len(ix) > 120 * N_SPARSE and st["padded_nnz"] < 1.02 * st["nnz"]
+    _dq, (qp, qi, qv) = S.sparse_queries(1000, VOCAB, seed=22)
+    k = 5
+    t0 = time.perf_counter()
+    s, i = sh.search_csr(qp, qi, qv, k)                        # 8 queries per pass
+    _note("sparse_1000_queries_search_s", time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    rs, ri = T.sparse_topk(ip, ix, vv, VOCAB, qp, qi, qv, k, blocked=True)
+    _note("sparse_1000_queries_oracle_s", time.perf_counter() - t0)
+    assert (ri >= 0).all()
+    assert np.array_equal(i, ri)
+    assert np.array_equal(s, rs)
+    for q in range(0, 1000, 37):                               # the single-query kernel on a sample
+        a, b = int(qp[q]), int(qp[q + 1])
+        s1, i1 = sh.search_csr(np.asarray([0, b - a], np.int64), qi[a:b], qv[a:b], k)
+        assert np.array_equal(i1[0], ri[q]) and np.array_equal(s1[0], rs[q]), q
+    s64, i64 = sh.search_csr(qp[:5], qi[: qp[4]], qv[: qp[4]], 64)     # a full device page per query
+    rs64, ri64 = T.sparse_topk(ip, ix, vv, VOCAB, qp[:5], qi[: qp[4]], qv[: qp[4]], 64, blocked=True)
+    assert np.array_equal(i64, ri64) and np.array_equal(s64, rs64)
+    sh.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_configs3_dense_shard_1_25m_rows(dtype):
+    """fp32 rows: arbitrary values, the kernel's per-row fmaf chain equals the oracle's bit for bit.  bf16 rows: values on
+    a bf16-exact grid (every product and sum exact), so the matrix-core path must agree exactly too, ties included."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    gen = S.dense_rows if dtype == "f32" else S.dense_grid
+    X = gen(N_DENSE, DIM, seed=31)
+    Q = gen(256, DIM, seed=32)
+    sh = DenseShard(DIM, N_DENSE, dtype)
+    t0 = time.perf_counter()
+    sh.add(X)
+    _note(f"dense_{dtype}_upload_s", time.perf_counter() - t0)
+    k = 10
+    t0 = time.perf_counter()
+    rs, ri = T.dense_topk(X, Q, k, blocked=True)
+    _note(f"dense_{dtype}_256_queries_oracle_s", time.perf_counter() - t0)
+    try:
+        for nq in (1, 32, 256):
+            t0 = time.perf_counter()
+            s, i = sh.search(Q[:nq], k)
+            _note(f"dense_{dtype}_{nq}_queries_search_s", time.perf_counter() - t0)
+            assert np.array_equal(i, ri[:nq]), (dtype, nq)
+            assert np.array_equal(s, rs[:nq]), (dtype, nq)
+    finally:
+        sh.close()
+        del X
+        gc.collect()
+
+
+def _rrf_expect(rows_d, rows_s, top_k, rrf_k=60):
+    from verbatim_rag_amd.vector_stores import rrf_merge_rows
+
+    return rrf_merge_rows({"dense": rows_d, "sparse": rows_s}, top_k, {"dense": 0.5, "sparse": 0.5}, rrf_k)
+
+
+def test_store_ingests_1m_chunks_and_answers_like_the_oracle(sparse_rows):
+    from verbatim_rag_amd.vector_stores import GpuVectorStore
+
+    ip, ix, vv = sparse_rows
+    n = N_SPARSE
+    X = S.dense_rows(n, DIM, seed=41)
+    ids = [f"c{i}" for i in range(n)]
+    texts = [f"chunk {i}" for i in range(n)]
+    metas = [{"document_id": f"d{i >> 6}", "n": i} for i in range(n)]
+    st = GpuVectorStore(dense_dim=DIM, sparse_vocab=VOCAB)
+    t0 = time.perf_counter()
+    st.add_vectors(ids, X, (ip, ix, vv), texts, texts, metas)
+    t_ingest = time.perf_counter() - t0
+    _note("store_add_vectors_1m_s", t_ingest)
+    assert t_ingest < 60, f"add_vectors took {t_ingest:.1f} s for 10^6 chunks"
+    del X
+    gc.collect()
+    nq, k = 256, 5
+    Q = S.dense_rows(nq, DIM, seed=42)
+    dq, (qp, qi, qv) = S.sparse_queries(nq, VOCAB, seed=43)
+    t0 = time.perf_counter()
+    got_d = st.query_batch(dense_queries=Q, search_type="dense", top_k=k)            # includes the flush (upload, SELL build)
+    _note("store_first_query_batch_with_flush_s", time.perf_counter() - t0)
+    rows = st._dense_rows.data                                                       # the unit rows the index holds
+    uq = st._unit_queries(Q)
+    rs_d, ri_d = T.dense_topk(rows, uq, 2 * k, blocked=True)
+    rs_s, ri_s = T.sparse_topk(ip, ix, vv, VOCAB, qp, qi, qv, 2 * k, blocked=True)
+
+    def check(got, want_rows, want_scores, exact_scores=True):
+        assert len(got) == len(want_rows)
+        for q, rs in enumerate(got):
+            want = [int(r) for r in want_rows[q] if r >= 0]
+            assert [r.id for r in rs] == [f"c{r}" for r in want], q
+            assert [r.text for r in rs] == [f"chunk {r}" for r in want]
+            assert [r.metadata for r in rs] == [{"document_id": f"d{r >> 6}", "n": r} for r in want]
+            if exact_scores:
+                assert [r.score for r in rs] == [float(v) for v, r in zip(want_scores[q], want_rows[q]) if r >= 0], q
+
+    check(got_d, ri_d[:, :k], rs_d[:, :k])
+    check(st.query_batch(sparse_queries=dq, search_type="sparse", top_k=k), ri_s[:, :k], rs_s[:, :k])
+    hyb_rows, hyb_dist = _rrf_expect(ri_d, ri_s, k)
+    check(st.query_batch(dense_queries=Q, sparse_queries=dq, search_type="hybrid", top_k=k), hyb_rows, hyb_dist)
+    for q in (0, 100, 255):                                                          # the per-query entry point
+        one = st.query(dense_query=Q[q].tolist(), sparse_query=dq[q], top_k=k, search_type="hybrid")
+        check([one], hyb_rows[q:q + 1], hyb_dist[q:q + 1])
+    # a per-document filter: 64 of 10^6 rows pass -> the masked subset shard answers
+    flt = 'metadata["document_id"] == "d77"'
+    lo = 77 * 64
+    sub_s, sub_i = T.dense_topk(rows[lo:lo + 64], uq[:8], k)
+    check(st.query_batch(dense_queries=Q[:8], search_type="dense", top_k=k, filter=flt), sub_i + lo, sub_s)
+    # deletes act before the search
+    gone = [f"c{int(r)}" for r in ri_d[:4, 0]]
+    st.delete(gone)
+    after = st.query_batch(dense_queries=Q[:4], search_type="dense", top_k=k)
+    for q in range(4):
+        want = [int(r) for r in ri_d[q] if f"c{int(r)}" not in gone][:k]
+        assert [r.id for r in after[q]] == [f"c{r}" for r in want]
+    # an append: dense rows join the resident shard, sparse rows form a tail segment beside the main SELL image
+    m = 1000
+    X2 = S.dense_rows(m, DIM, seed=44)
+    ip2, ix2, vv2 = S.sparse_corpus(m, VOCAB, seed=45)
+    X2[:nq] = Q * np.float32(3.0)                                                   # row n + q is query q's best dense hit
+    st.add_vectors([f"c{n + i}" for i in range(m)], X2, (ip2, ix2, vv2), [f"chunk {n + i}" for i in range(m)],
+                   [f"chunk {n + i}" for i in range(m)], [{"document_id": f"d{(n + i) >> 6}", "n": n + i} for i in range(m)])
+    top = st.query_batch(dense_queries=Q, search_type="dense", top_k=1)
+    assert [r[0].id for r in top] == [f"c{n + q}" for q in range(nq)]
+    assert len(st._sparse_parts) == 2 and st._sparse_parts[1][1:] == (n, m)
+    all_ip = np.concatenate([ip, ip2[1:] + ip[-1]])
+    rs_s2, ri_s2 = T.sparse_topk(all_ip, np.concatenate([ix, ix2]), np.concatenate([vv, vv2]), VOCAB, qp[:17], qi[: qp[16]], qv[: qp[16]],
+                                 k + len(gone), blocked=True)
+    alive = st._alive.data
+    order = np.argsort(~alive[ri_s2], axis=1, kind="stable")[:, :k]                   # deleted rows out, ranking kept
+    check(st.query_batch(sparse_queries=dq[:16], search_type="sparse", top_k=k), np.take_along_axis(ri_s2, order, axis=1),
+          np.take_along_axis(rs_s2, order, axis=1))
+    for shard, _b, _n in st._sparse_parts:
+        shard.close()
+    st._dense.close()
+
+
+def test_configs4_slice_pipeline_with_the_large_extractor_equals_the_oracle_pipeline():
+    """BASELINE configs[4] on one GPU, small corpus: hybrid (SPLADE + dense) retrieval -> top-5 -> ModernBERT-large
+    sentence classifier (28 layers at full width) -> static template -> citations.  The reference pipeline's arithmetic
+    is `QAModel.forward` in fp32 (extractor_models/model.py:59-117); the second run replaces the extractor's logits
+    with the fp32 oracle's (oracle/modernbert_np.py) behind the same host code: spans, highlights and citation offsets
+    must be identical."""
+    from tokenizers import Tokenizer
+
+    from oracle import modernbert_np as O
+    from verbatim_rag_amd.embedding_providers import GpuDenseProvider, GpuSpladeProvider
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor, SpanExtractor, select_sentences
+    from verbatim_rag_amd.index import HotPathIndex
+    from verbatim_rag_amd.pipeline import StaticVerbatimPipeline
+    from verbatim_rag_amd.vector_stores import GpuVectorStore
+    from verbatim_rag_amd.weights import random_init, random_qa_head
+
+    tok = Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+    with open(os.path.join(G, "host_fixtures.json")) as f:
+        fx = json.load(f)
+    # corpus: sentences of the captured config-1 documents re-dealt into 400 chunks of 3 - 7 sentences
+    sents = [s for d in fx["config1"]["docs"] for s in d.replace("?", ".").split(". ") if len(s) > 12]
+    rng = np.random.default_rng(9)
+    chunks = []
+    for i in range(400):
+        pick = rng.choice(len(sents), size=int(rng.integers(3, 8)), replace=False)
+        chunks.append(" ".join(sents[j].rstrip(".") + (" number %d." % i if n == 0 else ".") for n, j in enumerate(pick)))
+    tiny = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
+                pad_token_id=0, cls_token_id=1, sep_token_id=2)
+    z = np.load(os.path.join(G, "encoder_tiny.npz"))
+    emb = EncoderEngine(ModernBertShape(**tiny), O.random_weights(O.EncoderConfig(**tiny), seed=7), max_tokens=16384, max_seqs=256,
+                        max_seq_len=512, max_ranges=256)
+    emb.set_mlm_head(z["mlm_head.dense.weight"], z["mlm_head.norm.weight"], z["mlm_decoder.bias"])
+    store = GpuVectorStore(dense_dim=128, sparse_vocab=512)
+    index = HotPathIndex(store, dense_provider=GpuDenseProvider(emb, tok, pooling="mean"), sparse_provider=GpuSpladeProvider(emb, tok))
+    index.add_chunks([f"k{i}" for i in range(len(chunks))], chunks,
+                     metadatas=[{"title": f"Doc {i}", "source": f"s{i}.md", "document_id": f"d{i}"} for i in range(len(chunks))])
+    base = ModernBertShape.large()
+    shape = ModernBertShape(**{**base.__dict__, "vocab_size": 512, "pad_token_id": 0, "cls_token_id": 1, "sep_token_id": 2})
+    w = random_init(shape, seed=404)
+    qa_w, qa_b = random_qa_head(shape)
+    eng = EncoderEngine(shape, w, max_tokens=16384, max_seqs=64, max_seq_len=512, max_ranges=1024)
+    eng.set_qa_head(qa_w, qa_b)
+    gpu_ext = GpuModelSpanExtractor(engine=eng, tokenizer=tok, threshold=0.5)
+    cfg = O.EncoderConfig(vocab_size=512, hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
+                          num_attention_heads=shape.num_attention_heads, intermediate_size=shape.intermediate_size,
+                          global_attn_every_n_layers=shape.global_attn_every_n_layers, local_attention=shape.local_attention,
+                          global_rope_theta=shape.global_rope_theta, local_rope_theta=shape.local_rope_theta,
+                          norm_eps=shape.norm_eps, pad_token_id=0, cls_token_id=1, sep_token_id=2)
+    margins = []
+
+    class OracleExtractor(SpanExtractor):
+        """The extractor's host code (split, packing, threshold select) around the fp32 CPU arithmetic."""
+
+        def extract_spans(self, question, search_results):
+            out = {}
+            texts = [getattr(r, "text", "") for r in search_results]
+            all_sents, samples = gpu_ext.pack_qa(question, texts)
+            for text, raw, smp in zip(texts, all_sents, samples):
+                if smp is None:
+                    out[text] = []
+                    continue
+                hid = O.encoder_forward(cfg, w, np.asarray(smp.input_ids, np.int32))
+                logits = O.qa_sentence_logits(hid, smp.sentence_boundaries, qa_w, qa_b)
+                margins.extend(np.abs(O.softmax_rows(logits)[:, 1] - gpu_ext.threshold).tolist())
+                out[text] = select_sentences(logits, raw, gpu_ext.threshold)
+            return out
+
+    questions = ["Where is the tower?", "Who built the old bridge?", "When was the museum opened?"]
+    got = StaticVerbatimPipeline(index, gpu_ext, k=5).query_batch(questions)
+    want = [StaticVerbatimPipeline(index, OracleExtractor(), k=5).query(q) for q in questions]
+    eng.close()
+    emb.close()
+    assert min(margins) > 2e-3, "a sentence probability sits on the threshold: pick another seed"
+    n_cited = 0
+    for g, wnt in zip(got, want):
+        g, wnt = g.model_dump(), wnt.model_dump()
+        assert [d["highlights"] for d in g["documents"]] == [d["highlights"] for d in wnt["documents"]]    # citation offsets
+        assert g["structured_answer"]["citations"] == wnt["structured_answer"]["citations"]
+        assert g["answer"] == wnt["answer"]
+        n_cited += len(g["structured_answer"]["citations"])
+    assert n_cited > 0

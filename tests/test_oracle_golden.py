@@ -74,3 +74,34 @@ def test_base_config_logits_vs_transformers():
     assert np.abs(hid[:4] - z["hidden_rows_1"]).max() < 2e-4
     lg = O.qa_sentence_logits(hid, bounds, qa_w, qa_b)
     assert np.abs(lg - z["logits_1"]).max() < 5e-5
+
+
+def test_blocked_topk_oracle_equals_the_scalar_statement():
+    """oracle/topk_ref.c: the loop nest used at full size (16 queries per pass over a row, rows cut over the OpenMP
+    threads, thread-private lists merged at the end) returns the scalar statement's bits -- arbitrary data, frequent
+    exact ties (grid data), fewer hits than k, empty rows."""
+    import numpy as np
+
+    from oracle import topk_ref as T
+
+    rng = np.random.default_rng(8)
+    for n, dim, nq, k in [(5000, 96, 37, 10), (70, 8, 3, 64), (20000, 768, 17, 5)]:
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        a, b = T.dense_topk(X, Q, k), T.dense_topk(X, Q, k, blocked=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        G = (rng.integers(-2, 3, (n, dim)) / 2).astype(np.float32)          # many exact ties: id order decides
+        a, b = T.dense_topk(G, G[:nq], k), T.dense_topk(G, G[:nq], k, blocked=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    V, n = 500, 6000
+    lens = rng.integers(0, 20, n)
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ix = np.concatenate([np.sort(rng.choice(V, int(m), replace=False)) for m in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    vv = rng.random(len(ix)).astype(np.float32)
+    qlens = rng.integers(0, 9, 41)
+    qp = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    qi = np.concatenate([np.sort(rng.choice(V, int(m), replace=False)) for m in qlens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    qv = rng.random(len(qi)).astype(np.float32)
+    for k in (3, 64, 500):
+        a, b = T.sparse_topk(ip, ix, vv, V, qp, qi, qv, k), T.sparse_topk(ip, ix, vv, V, qp, qi, qv, k, blocked=True)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])

@@ -52,8 +52,8 @@ def test_store_query_batch_equals_per_query(n, dim, dtype):
     finally:
         if st._dense is not None:
             st._dense.close()
-        if st._sparse is not None:
-            st._sparse.close()
+        for shard, _base, _n in st._sparse_parts:
+            shard.close()
 
 
 def test_store_query_batch_side_branches():
@@ -69,4 +69,5 @@ def test_store_query_batch_side_branches():
             st.query(dense_query=None, sparse_query=sparse[1], top_k=2, hybrid_weights={"dense": 1.0, "sparse": 1.0})]
     assert _dump(mixed) == _dump(want)
     st._dense.close()
-    st._sparse.close()
+    for shard, _base, _n in st._sparse_parts:
+        shard.close()

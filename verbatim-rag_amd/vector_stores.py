@@ -351,6 +351,7 @@ class SparseShard:
 
 
 _JSON_PLAIN = (str, int, float, bool, type(None))
+_NO_METADATA: Dict[str, Any] = {}
 
 
 def json_serialize_safe(obj: Any) -> Any:
@@ -381,7 +382,7 @@ def _metadata_rows(metadatas: Sequence[Optional[dict]]) -> List[Dict[str, Any]]:
     out = []
     for md in metadatas:
         if not md:
-            out.append({})
+            out.append(_NO_METADATA)         # stored metadata is never modified in place (results hand out copies)
         elif all(type(k) is str and type(v) in plain for k, v in md.items()):
             out.append(dict(md))
         else:
@@ -407,8 +408,12 @@ class _Column:
     def data(self) -> np.ndarray:
         return self._buf[: self._n]
 
-    def extend(self, rows: np.ndarray) -> None:
+    def extend(self, rows: np.ndarray, adopt: bool = False) -> None:
+        """`adopt=True`: `rows` is a fresh array nobody else holds -- an empty column takes it as its buffer (no copy)."""
         m = len(rows)
+        if adopt and self._n == 0 and rows.dtype == self._buf.dtype and rows.flags.c_contiguous and rows.flags.owndata:
+            self._buf, self._n = rows, m
+            return
         if self._n + m > len(self._buf):
             cap = max(self._n + m, int(len(self._buf) * 1.5) + 16)
             grown = np.empty((cap,) + self._buf.shape[1:], self._buf.dtype)
@@ -448,15 +453,14 @@ def _as_csr(sparse_vectors, n_expected: int, vocab: int):
             raise ValueError(f"add_vectors: sparse vector {bad} has a term outside [0, {vocab})")
         indices = np.ascontiguousarray(indices, dtype=np.int32)
         if len(indices) > 1:
-            step = np.diff(indices.astype(np.int64))
-            inner = np.ones(len(indices) - 1, dtype=bool)
-            inner[indptr[1:-1][(indptr[1:-1] > 0) & (indptr[1:-1] < len(indices))] - 1] = False   # row boundaries
-            if (inner & (step <= 0)).any():
+            # terms must ascend strictly inside a row: look only at the places where they do not (row starts, mostly)
+            drops = np.nonzero(indices[1:] <= indices[:-1])[0] + 1
+            if len(drops) and not np.isin(drops, indptr).all():
                 row_of = np.repeat(np.arange(n_expected, dtype=np.int64), np.diff(indptr))
                 order = np.lexsort((indices, row_of))
                 indices, values = indices[order], values[order]
-                step = np.diff(indices.astype(np.int64))
-                if (inner & (step == 0)).any():
+                drops = np.nonzero(indices[1:] <= indices[:-1])[0] + 1
+                if not np.isin(drops, indptr).all():
                     raise ValueError("add_vectors: a sparse vector repeats a term")
         return indptr, indices, values
     if len(sparse_vectors) != n_expected:
@@ -605,6 +609,55 @@ def parse_filter(expr: str):
     return pred
 
 
+def _replace_into(path: str, name: str, writer) -> None:
+    """Writes beside the final name and renames into place: a reader never sees half a file."""
+    import os
+
+    tmp = os.path.join(path, f".{name}.tmp{os.getpid()}")
+    writer(tmp)
+    os.replace(tmp, os.path.join(path, name))
+
+
+def _write_text(file: str, text: str) -> None:
+    with open(file, "w", encoding="utf-8", newline="") as f:
+        f.write(text)
+
+
+def _put_strings(path: str, stem: str, col: Sequence[str]) -> None:
+    """A column of strings as `{stem}.txt`: the rows joined by NUL (one C-level join / split for 10^7 rows); a column
+    holding a NUL itself or a non-string goes to `{stem}.json` instead."""
+    import os
+
+    blob = None
+    try:
+        blob = "\x00".join(col)
+        if blob.count("\x00") != max(0, len(col) - 1):
+            blob = None
+    except TypeError:
+        blob = None
+    for stale in (f"{stem}.txt", f"{stem}.json"):
+        if os.path.exists(os.path.join(path, stale)):
+            os.remove(os.path.join(path, stale))
+    if blob is not None:
+        _replace_into(path, f"{stem}.txt", lambda tmp: _write_text(tmp, blob))
+    else:
+        _replace_into(path, f"{stem}.json", lambda tmp: _write_text(tmp, json.dumps(list(col), ensure_ascii=False)))
+
+
+def _get_strings(path: str, stem: str, n: int) -> List[str]:
+    import os
+
+    if os.path.exists(os.path.join(path, f"{stem}.txt")):
+        with open(os.path.join(path, f"{stem}.txt"), encoding="utf-8", newline="") as f:
+            col = f.read().split("\x00") if n else []
+    else:
+        with open(os.path.join(path, f"{stem}.json"), encoding="utf-8") as f:
+            col = json.load(f)
+    if len(col) != n:
+        raise ValueError(f"{path}: {stem} holds {len(col)} rows, expected {n}")
+    return col
+
+
 # ---------------------------------------------------------------------------- the store
 class GpuVectorStore(VectorStore):
     """Exact GPU search store with BaseMilvusStore's behaviour (milvus_base.py:90-127,189-459).
@@ -733,9 +786,14 @@ class GpuVectorStore(VectorStore):
                     if shape != (self.dense_dim,):
                         raise ValueError(f"add_vectors: dense vector {i} has shape {shape}, the store holds {self.dense_dim}-d rows")
                 raise ValueError(f"add_vectors: dense_vectors must be [n, {self.dense_dim}]")
-            mine = block[lo:hi]
-            norms = np.sqrt((mine * mine).sum(axis=1, dtype=np.float32))
-            new_dense = mine / np.where(norms > 0, norms, np.float32(1.0))[:, None]   # COSINE == IP on unit rows
+            new_dense = np.empty((hi - lo, self.dense_dim), np.float32)
+            slab = 16384                                     # a cache-sized slab at a time into one reused scratch: no
+            sq = np.empty((min(slab, max(1, hi - lo)), self.dense_dim), np.float32)   # [n, dim] temporaries at 10^6 rows
+            for a in range(lo, hi, slab):
+                mine = block[a:min(hi, a + slab)]
+                np.multiply(mine, mine, out=sq[: len(mine)])
+                norms = np.sqrt(sq[: len(mine)].sum(axis=1, dtype=np.float32))
+                np.divide(mine, np.where(norms > 0, norms, np.float32(1.0))[:, None], out=new_dense[a - lo:a - lo + len(mine)])   # COSINE == IP on unit rows
         new_csr = None
         if self.enable_sparse:
             indptr, indices, values = _as_csr(sparse_vectors, n, self.sparse_vocab)
@@ -757,7 +815,7 @@ class GpuVectorStore(VectorStore):
             self._alive.extend(np.ones(n, dtype=bool))
             self._owned.extend(np.arange(base + lo, base + hi, dtype=np.int64))
             if new_dense is not None:
-                self._dense_rows.extend(new_dense)
+                self._dense_rows.extend(new_dense, adopt=True)
             if new_csr is not None:
                 self._sp_ptr.extend(new_csr[0][1:] + self._sp_ptr.data[-1])
                 self._sp_idx.extend(new_csr[1])
@@ -1243,11 +1301,11 @@ class GpuVectorStore(VectorStore):
     FORMAT = 3
 
     def save(self, path: str) -> None:
-        """Writes the store to a directory (deleted rows are dropped): `store.json` (geometry, document records) and
-        `ids.json` by rank 0; per rank `vectors.rank{r}.npz` (its packed unit dense rows, sparse CSR and the row numbers
-        they belong to) and `payload.rank{r}.json` (texts, enhanced texts, metadata of those rows).  Every file is
-        written beside its final name and renamed into place, and a sharded `save` ends in a barrier, so a `load` that
-        follows on any rank reads complete files.  The reference persists through the Milvus-lite database file
+        """Writes the store to a directory (deleted rows are dropped): `store.json` (geometry, document records) and the
+        id column by rank 0; per rank `vectors.rank{r}.npz` (its packed unit dense rows, sparse CSR and the row numbers
+        they belong to) and the text / enhanced-text / metadata columns of those rows (string columns as NUL-joined text,
+        `_put_strings`; metadata as one JSON array).  Every file is written beside its final name and renamed into
+        place, and a sharded `save` ends in a barrier, so a `load` that follows on any rank reads complete files.  The reference persists through the Milvus-lite database file
         (milvus_local.py:39-56); this is the GPU store's own on-disk format.  Sharded stores: every rank calls `save`
         with the same path."""
         import os
@@ -1266,26 +1324,34 @@ class GpuVectorStore(VectorStore):
                 arrays.update(sp_indptr=indptr, sp_indices=indices, sp_values=values)
             # texts / metadata lists are indexed by local row, or by global row when a sharded store replicates them
             slots = local if (self._payload_sharded or self._world == 1) else owned[local]
-            payload = {"texts": [self._texts[j] for j in slots], "enhanced_texts": [self._enh[j] for j in slots],
-                       "metadatas": [self._meta[j] for j in slots]}
-            ids = [self._ids[i] for i in np.nonzero(alive)[0]]
+            whole = len(slots) == len(self._texts) and (len(slots) == 0 or (slots[0] == 0 and slots[-1] == len(slots) - 1))
+
+            def take(col, at):        # col[at] for 10^7 rows: one object-array gather instead of a Python loop
+                box = np.empty(len(col), dtype=object)
+                box[:] = col
+                return box[at].tolist()
+
+            pick = (lambda col: col) if whole else (lambda col: take(col, slots))
+            texts, enh, metas = pick(self._texts), pick(self._enh), pick(self._meta)
+            ids = self._ids if alive.all() else take(self._ids, np.nonzero(alive)[0])
+            if not any(metas):
+                metas = {"empty_rows": len(metas)}                             # nothing to store per row
             head = {"format": self.FORMAT, "world": self._world, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
                     "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse, "dense_dtype": self.dense_dtype,
                     "rows": len(ids), "documents": list(self._documents.values())}
+            r = self._rank
 
-        def put_json(name, obj):
-            tmp = os.path.join(path, f".{name}.tmp{os.getpid()}")
-            with open(tmp, "w", encoding="utf-8") as f:
-                json.dump(obj, f, ensure_ascii=False)
-            os.replace(tmp, os.path.join(path, name))
+            def put_arrays(tmp):
+                with open(tmp, "wb") as f:
+                    np.savez(f, **arrays)
 
-        tmp = os.path.join(path, f".vectors.rank{self._rank}.tmp{os.getpid()}.npz")
-        np.savez(tmp, **arrays)
-        os.replace(tmp, os.path.join(path, f"vectors.rank{self._rank}.npz"))
-        put_json(f"payload.rank{self._rank}.json", payload)
-        if self._rank == 0:
-            put_json("ids.json", ids)
-            put_json("store.json", head)
+            _replace_into(path, f"vectors.rank{r}.npz", put_arrays)
+            _put_strings(path, f"texts.rank{r}", texts)
+            _put_strings(path, f"enhanced.rank{r}", enh)
+            _replace_into(path, f"metadatas.rank{r}.json", lambda tmp: _write_text(tmp, json.dumps(metas, ensure_ascii=False)))
+            if r == 0:
+                _put_strings(path, "ids", ids)
+                _replace_into(path, "store.json", lambda tmp: _write_text(tmp, json.dumps(head, ensure_ascii=False)))
         if self._world > 1:
             self._comm.barrier()
 
@@ -1304,12 +1370,17 @@ class GpuVectorStore(VectorStore):
             head = get_json("store.json")
             if head.get("format") != 3:
                 raise ValueError(f"{path}: unknown GpuVectorStore format {head.get('format')!r}")
-            ids = get_json("ids.json")
+            ids = _get_strings(path, "ids", head["rows"])
             shards = []
             for r in range(head.get("world", 1)):
                 z = np.load(os.path.join(path, f"vectors.rank{r}.npz"))
-                pay = get_json(f"payload.rank{r}.json")
-                shards.append((z["owned"], z, pay["texts"], pay["enhanced_texts"], pay["metadatas"]))
+                m = len(z["owned"])
+                metas = get_json(f"metadatas.rank{r}.json")
+                if isinstance(metas, dict):
+                    metas = [_NO_METADATA] * int(metas["empty_rows"])
+                if len(metas) != m:
+                    raise ValueError(f"{path}: metadatas.rank{r} holds {len(metas)} rows, expected {m}")
+                shards.append((z["owned"], z, _get_strings(path, f"texts.rank{r}", m), _get_strings(path, f"enhanced.rank{r}", m), metas))
             return head, ids, shards
         rows = get_json("rows.json")
         fmt = rows.get("format")
@@ -1377,7 +1448,7 @@ class GpuVectorStore(VectorStore):
         st._alive.extend(np.ones(n, dtype=bool))
         st._owned.extend(owned)
         if st._payload_sharded or st._world == 1:
-            st._texts, st._enh, st._meta = list(texts), list(enh), [dict(x) for x in metas]
+            st._texts, st._enh, st._meta = list(texts), list(enh), list(metas)
         else:                                                     # replicated payload: every rank needs every row's
             st._texts, st._enh, st._meta = [""] * n, [""] * n, [{} for _ in range(n)]
             for o, _z, tx, e, mm in shards:

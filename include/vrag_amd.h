@@ -240,6 +240,10 @@ int vrag_debug_set_gemm_small_m(int32_t rows);
 /* Diagnostics (kernel tuning): average ms of one GEMM instantiation (epilogue id as in
  * csrc/gemm_bf16.h, 7 = no epilogue) on synthetic [-1,1) operands. */
 int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t device, float* ms_out);
+/* Same for one attention launch: n_seqs sequences of S tokens (S a multiple of 8), hidden H = 64 * heads, local != 0 =
+ * the banded kernel with |i - j| <= window. */
+int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t device,
+                       float* ms_out);
 int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/,
                               int64_t* launches /*[VRAG_PROF_COUNT]*/, int32_t reset);
 

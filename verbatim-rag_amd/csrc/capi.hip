@@ -1763,6 +1763,91 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
   return VRAG_OK;
 }
 
+int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t device,
+                       float* ms_out) {
+  ARG_CHECK(ms_out && n_seqs > 0 && S > 0 && S % kSeqAlign == 0 && H % 64 == 0 && iters > 0, "bad arguments");
+  if (vrag_device_count() <= device) {
+    set_error("no HIP device %d visible", device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  const size_t T = (size_t)n_seqs * S, Tp = (size_t)align_up((int)T, kRowPad);
+  const int qb = attention_q_block(local != 0);
+  std::vector<int> bs, bl, bq;
+  for (int s = 0; s < n_seqs; ++s)
+    for (int q0 = 0; q0 < S; q0 += qb) {
+      bs.push_back(s * S);
+      bl.push_back(S);
+      bq.push_back(q0);
+    }
+  void *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
+  int *d_bs = nullptr, *d_bl = nullptr, *d_bq = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {q, k, vt, o, (void*)d_bs, (void*)d_bl, (void*)d_bq})
+      if (p) (void)hipFree(p);
+  };
+  hipError_t e = hipMalloc(&q, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&k, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&vt, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&o, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bs, bs.size() * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bl, bs.size() * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bq, bs.size() * 4);
+  if (e != hipSuccess) {
+    cleanup();
+    set_error("debug attention allocation failed: %s", hipGetErrorString(e));
+    return VRAG_ERR_HIP;
+  }
+  {
+    std::vector<unsigned short> h(Tp * H);
+    unsigned x = 777u;
+    for (auto& v : h) {   // pseudo-random bf16 in about [-1, 1), as vrag_debug_gemm_ms
+      x = x * 1664525u + 1013904223u;
+      v = (unsigned short)(((x >> 31) << 15) | (0x3e80u + (((x >> 20) & 1) << 7)) | ((x >> 9) & 0x7f));
+    }
+    (void)hipMemcpy(q, h.data(), Tp * H * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(k, h.data(), Tp * H * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(vt, h.data(), Tp * H * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_bs, bs.data(), bs.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_bl, bl.data(), bs.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_bq, bq.data(), bs.size() * 4, hipMemcpyHostToDevice);
+  }
+  AttnParams ap{};
+  ap.q = (const bf16_t*)q;
+  ap.k = (const bf16_t*)k;
+  ap.vt = (const bf16_t*)vt;
+  ap.o = (bf16_t*)o;
+  ap.blk_seq_start = d_bs;
+  ap.blk_seq_len = d_bl;
+  ap.blk_q0 = d_bq;
+  ap.n_blocks = (int)bs.size();
+  ap.H = H;
+  ap.nh = H / 64;
+  ap.Tp = (int)Tp;
+  ap.window = window;
+  ap.op_dtype = getenv("VRAG_DEBUG_GEMM_F16") ? kOpF16 : kOpBf16;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  hipError_t le = hipSuccess;
+  for (int i = 0; i < 3 && le == hipSuccess; ++i) le = launch_attention(ap, local != 0, 0);
+  (void)hipEventRecord(a, 0);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_attention(ap, local != 0, 0);
+  (void)hipEventRecord(b, 0);
+  hipError_t se = hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  cleanup();
+  if (le != hipSuccess || se != hipSuccess) {
+    set_error("debug attention failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+    return VRAG_ERR_HIP;
+  }
+  *ms_out = ms / iters;
+  return VRAG_OK;
+}
+
 int vrag_encoder_set_concurrency(vrag_encoder* e, int32_t n_streams) {
   ARG_CHECK(e && n_streams >= 1 && n_streams <= 4, "n_streams must be in [1, 4]");
   std::lock_guard<std::recursive_mutex> lk(e->mu);

@@ -217,6 +217,13 @@ int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t
                             const int32_t* rng_seq, const int32_t* rng_start, const int32_t* rng_end,
                             int32_t n_ranges, float* logits);
 
+/* fp16 operands (VRAG_OPERAND_F16) saturate at +-65504 instead of overflowing.  *saturated = 1 if any fp32 -> fp16
+ * operand conversion on this device (weights at load time, LayerNorm-fold copies, q / k / v, GeGLU outputs, attention
+ * outputs) has had to clamp since the last reset: the logits computed meanwhile are not to be trusted -- re-run with
+ * VRAG_OPERAND_BF16 (checkpoints with activation outliers beyond fp16's range; the flag is per process and device, not
+ * per handle).  Synchronises the device. */
+int vrag_encoder_f16_saturated(vrag_encoder* enc, int32_t reset, int32_t* saturated);
+
 /* Per-kernel-class timing with HIP events recorded on the launch stream.
  * classes: see VRAG_PROF_* ; ms[i] = summed event time, launches[i] = launch count since reset. */
 #define VRAG_PROF_EMBED 0

@@ -200,3 +200,76 @@ def test_highlighter_cross_query_batching_equals_per_query_calls(setup):
     want = [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
     assert got == want and list(got[1]) == [ctxs[2], ""] and got[1][""] == []
     assert any(len(v) > 0 for d in got for v in d.values())
+
+
+def test_fp16_operands_report_saturation_instead_of_returning_clamped_logits(tmp_path, caplog):
+    """fp16 conversions clamp at +-65504.  A checkpoint with outlier channels (here: three GeGLU channels of
+    layer 1 scaled x3000, so gelu(x1) * x2 leaves fp16's range) must be REPORTED, not answered with plausible, wrong
+    logits: `vrag_encoder_f16_saturated` is set, a healthy checkpoint leaves it clear, bf16 operands (fp32's exponent
+    range) never touch it, and an extractor built from a model directory switches itself to bf16 and answers like an
+    extractor that was constructed with bf16 operands."""
+    import json
+    import logging
+    import shutil
+    import types
+
+    from safetensors.numpy import save_file
+
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=7)
+    z = np.load(os.path.join(G, "encoder_tiny.npz"))
+    hot = {k: v.copy() for k, v in w.items()}
+    wi = hot["layers.1.mlp.Wi.weight"]                         # [2I, H]: rows 0..I-1 = x1 (gelu input), I..2I-1 = x2
+    I = cfg.intermediate_size
+    for c in (3, 77, 150):
+        wi[c] *= 3000.0
+        wi[I + c] *= 3000.0
+    seqs = [z["ids_200"], z["ids_64"]]
+
+    def run(weights, dtype):
+        eng = EncoderEngine(ModernBertShape(**TINY), weights, max_tokens=8192, max_seqs=64, max_seq_len=2048, max_ranges=256,
+                            operand_dtype=dtype)
+        eng.set_token_head(z["tk_head.dense.weight"], z["tk_head.norm.weight"], z["tk_classifier.weight"], z["tk_classifier.bias"])
+        eng.f16_saturated(reset=True)
+        eng.load_batch(seqs)
+        eng.run()
+        eng.run_token_head()
+        lg = eng.read_token_logits()
+        flag = eng.f16_saturated(reset=True)
+        again = eng.f16_saturated(reset=True)
+        eng.close()
+        return lg, flag, again
+
+    lg, flag, again = run(w, "f16")
+    assert not flag and np.isfinite(lg).all()
+    lg_hot16, flag, again = run(hot, "f16")
+    assert flag and not again                                  # reported once, cleared by the reset
+    lg_hot, flag, _ = run(hot, "bf16")
+    assert not flag and np.isfinite(lg_hot).all()
+    assert np.abs(lg_hot16 - lg_hot).max() > 1e-2              # the clamped run really was wrong, not just flagged
+    # the extractor built from a directory: v2 layout (model.* + head.* + classifier.*, auto_map naming a Highlighter)
+    d = str(tmp_path)
+    sd = {"model." + k: np.ascontiguousarray(v) for k, v in hot.items()}
+    sd.update({"head.dense.weight": z["tk_head.dense.weight"], "head.norm.weight": z["tk_head.norm.weight"],
+               "classifier.weight": z["tk_classifier.weight"], "classifier.bias": z["tk_classifier.bias"]})
+    save_file(sd, os.path.join(d, "model.safetensors"))
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump({**TINY, "model_type": "modernbert", "max_position_embeddings": 8192, "global_attn_every_n_layers": 3,
+                   "local_attention": 128, "global_rope_theta": 160000.0, "local_rope_theta": 10000.0, "norm_eps": 1e-5,
+                   "auto_map": {"AutoModel": "modeling_highlighter.VerbatimHighlighterModel"}}, f)
+    shutil.copy(os.path.join(G, "tokenizer.json"), os.path.join(d, "tokenizer.json"))
+    kw = dict(threshold=0.5, max_length=256, doc_stride=32, min_span_chars=5, merge_gap_chars=3)
+    ext16 = GpuModelSpanExtractor(model_path=d, **kw)
+    ext_bf = GpuModelSpanExtractor(model_path=d, operand_dtype="bf16", **kw)
+    assert ext16.engine.operand_dtype == "f16" and ext_bf.engine.operand_dtype == "bf16"
+    ctx = " ".join(["The tall iron tower in paris was built for the world fair."] * 12)
+    results = [types.SimpleNamespace(text=ctx), types.SimpleNamespace(text="A stone bridge crosses the river at night.")]
+    with caplog.at_level(logging.WARNING):
+        got = ext16.extract_spans("Where is the tower?", results)
+    assert ext16.engine.operand_dtype == "bf16" and any("saturated" in r.message for r in caplog.records)
+    assert got == ext_bf.extract_spans("Where is the tower?", results)
+    for e in ext16.engines + ext_bf.engines:
+        e.close()

@@ -25,13 +25,9 @@ POWER_RE = re.compile(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)
 
 
 def _hwmon():
-    for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
-        try:
-            if int(open(p).read().strip()) > 0:
-                return p
-        except Exception:
-            pass
-    return None
+    """The hwmon power file is not usable on this part (it sat at its idle value through every loop, r3a session): the
+    package power comes from `rocm-smi --showpower` like tools/energy_probe.py, unless VRAG_POWER_HWMON names a file."""
+    return os.environ.get("VRAG_POWER_HWMON") or None
 
 
 def read_power(hw):
@@ -96,7 +92,7 @@ def main():
     for name, kind, a, flop in classes:
         ms = run(kind, a, 50)                                        # calibrate the launch count
         iters = max(200, int(args.seconds / (ms * 1e-3)))
-        smp = Sampler(hw, 0.05 if hw else 0.3)
+        smp = Sampler(hw, 0.05 if hw else 0.05)          # rocm-smi itself takes a few hundred ms per reading
         t0 = time.perf_counter()
         smp.start()
         ms = run(kind, a, iters)

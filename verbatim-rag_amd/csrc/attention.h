@@ -23,4 +23,7 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream);
 int attention_q_block(bool local);  // query rows per work item (256 global / 128 banded)
 
+// 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
+unsigned attention_f16_saturated(bool reset);
+
 }  // namespace vrag

@@ -299,4 +299,6 @@ hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream)
   return hipGetLastError();
 }
 
+unsigned attention_f16_saturated(bool reset) { return f16_sat_take(reset); }
+
 }  // namespace vrag

@@ -1848,6 +1848,19 @@ int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int3
   return VRAG_OK;
 }
 
+int vrag_encoder_f16_saturated(vrag_encoder* e, int32_t reset, int32_t* saturated) {
+  ARG_CHECK(e && saturated, "null argument");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned any = f16_sat_take(reset != 0);                 // conversions in this file (weight packing)
+  any |= gemm_f16_saturated(reset != 0);
+  any |= attention_f16_saturated(reset != 0);
+  any |= norm_heads_f16_saturated(reset != 0);
+  *saturated = any ? 1 : 0;
+  return VRAG_OK;
+}
+
 int vrag_encoder_set_concurrency(vrag_encoder* e, int32_t n_streams) {
   ARG_CHECK(e && n_streams >= 1 && n_streams <= 4, "n_streams must be in [1, 4]");
   std::lock_guard<std::recursive_mutex> lk(e->mu);

@@ -21,6 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // kernels, templated on the operand type, reinterpret them.  fp16 conversions saturate at +-65504 instead of
 // producing inf.
 constexpr int kOpBf16 = 0, kOpF16 = 1;
+// Set by any fp32 -> fp16 operand conversion that had to clamp (one copy per translation unit: no relocatable device
+// code in this build; f16_sat_take() below reads and clears the copy of the file that includes it).
+static __device__ unsigned vrag_f16_sat_flag;
 template <typename T> struct Op;
 template <> struct Op<bf16_t> {
   typedef bf16x4 v4;
@@ -36,7 +39,12 @@ template <> struct Op<bf16_t> {
 template <> struct Op<f16_t> {
   typedef f16x4 v4;
   typedef f16x8 v8;
-  static __device__ __forceinline__ f16_t to(float v) { return (f16_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+  static __device__ __forceinline__ f16_t to(float v) {
+    // a value outside fp16's range is stored as +-65504 AND reported: silently clamped activations would come back as
+    // plausible, wrong logits (vrag_encoder_f16_saturated; the branch is never taken on healthy checkpoints)
+    if (__builtin_fabsf(v) > 65504.f) vrag_f16_sat_flag = 1u;
+    return (f16_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  }
   static __device__ __forceinline__ f32x16 mfma32(const v8& a, const v8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
@@ -127,6 +135,18 @@ __device__ __forceinline__ void store8_nt(void* dst, const V4& v) {
 }
 __device__ __forceinline__ f32x4 load16_nt(const void* src) {
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+}
+
+// Host side of vrag_f16_sat_flag for THIS translation unit: 1 if a conversion clamped since the last reset (synchronises
+// the device: callers use it on the read-back path, never between launches).
+static inline unsigned f16_sat_take(bool reset) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(vrag_f16_sat_flag), sizeof(v)) != hipSuccess) return 0;
+  if (reset && v) {
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vrag_f16_sat_flag), &zero, sizeof(zero));
+  }
+  return v;
 }
 
 // 16-byte global -> LDS DMA. LDS destination = wave-uniform `lds` + lane*16.

@@ -66,4 +66,7 @@ const char* gemm_kernel_name(GemmEpi epi);
 // set_to >= 0 changes the threshold (0 disables the configuration); returns the current value.
 int gemm_small_m_threshold(int set_to);
 
+// 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
+unsigned gemm_f16_saturated(bool reset);
+
 }  // namespace vrag

@@ -727,4 +727,6 @@ const char* gemm_kernel_name(GemmEpi epi) {
   return epi >= 0 && epi < EPI_COUNT ? names[epi] : "?";
 }
 
+unsigned gemm_f16_saturated(bool reset) { return f16_sat_take(reset); }
+
 }  // namespace vrag

@@ -42,4 +42,7 @@ hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row,
                                     const float* bp, const float* Wc, const float* bc, int num_labels, float* logits,
                                     hipStream_t stream);
 
+// 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
+unsigned norm_heads_f16_saturated(bool reset);
+
 }  // namespace vrag

@@ -337,4 +337,6 @@ hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row,
   return hipGetLastError();
 }
 
+unsigned norm_heads_f16_saturated(bool reset) { return f16_sat_take(reset); }
+
 }  // namespace vrag

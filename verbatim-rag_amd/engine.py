@@ -180,6 +180,14 @@ class EncoderEngine:
         except Exception:
             pass
 
+    def f16_saturated(self, reset: bool = True) -> bool:
+        """True when an fp32 -> fp16 operand conversion on this device had to clamp to +-65504 since the last reset
+        (`vrag_encoder_f16_saturated`): the logits computed meanwhile are not to be trusted -- use bf16 operands for
+        that checkpoint.  Always False for bf16 handles' own work (they never convert to fp16).  Synchronises."""
+        v = C.c_int32(0)
+        _lib.check("vrag_encoder_f16_saturated", self._lib.vrag_encoder_f16_saturated(self._h, 1 if reset else 0, C.byref(v)))
+        return bool(v.value)
+
     # ------------------------------------------------------------------ heads
     def set_qa_head(self, weight, bias) -> None:
         w, b = _f32(weight), _f32(bias)

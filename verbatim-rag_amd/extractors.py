@@ -224,6 +224,28 @@ class GpuModelSpanExtractor(SpanExtractor):
                                tensors["classifier.weight"], tensors["classifier.bias"])
         return eng
 
+    def _f16_clamped(self, engine) -> bool:
+        """fp16 operands saturate at 65504 instead of overflowing; a checkpoint with activation outliers beyond that
+        would come back with plausible, wrong logits.  The library reports every clamp (`vrag_encoder_f16_saturated`):
+        on the first report the engines this extractor built are rebuilt with bf16 operands (fp32's exponent range)
+        and True is returned -- the caller runs its batch again; an extractor that was handed its engine cannot rebuild
+        it and raises (its per-chunk error handling logs the failure and returns no spans: never silently wrong)."""
+        if getattr(engine, "operand_dtype", "bf16") != "f16" or not hasattr(engine, "f16_saturated") or not engine.f16_saturated(reset=True):
+            return False
+        if self.model_path is None or not os.path.isdir(self.model_path):
+            raise RuntimeError("fp16 MFMA operands saturated on this checkpoint (activations beyond 65504): "
+                               "build the engine with operand_dtype='bf16'")
+        with self._cache_lock:
+            if self.operand_dtype != "bf16":               # the first thread to notice rebuilds; the others just retry
+                logger.warning("fp16 MFMA operands saturated on %s (activations beyond 65504): switching this extractor to "
+                               "bf16 operands (construct it with operand_dtype='bf16' to skip the probe)", self.model_path)
+                dev = int(self.device.replace("cuda:", ""))
+                self.operand_dtype = "bf16"
+                # swapped in as a whole; a call still running on an old handle keeps it alive and finishes on it
+                self.engines = [self._build_engine(self.model_path, dev) for _ in self.engines]
+                self.engine = self.engines[0]
+        return True
+
     @staticmethod
     def _load_tokenizer(model_path: str):
         tj = os.path.join(model_path, "tokenizer.json")
@@ -403,6 +425,8 @@ class GpuModelSpanExtractor(SpanExtractor):
                 else:   # engines without the flat entry point
                     flat = np.concatenate(engine.qa_logits(
                         [b[3] for b in batch], [list(zip(b[4].tolist(), b[5].tolist())) for b in batch]))
+                if self._f16_clamped(engine):
+                    return self._run_sub_batch(batch, out, which)          # once more, on the bf16 engines
                 keep = softmax_rows(flat)[:, 1] > self.threshold
                 o = 0
                 for (qi, text, sents, _ids, _st, _en), c in zip(batch, counts.tolist()):
@@ -483,6 +507,8 @@ class GpuModelSpanExtractor(SpanExtractor):
                     self.engine.run()
                     self.engine.run_token_head()
                     logits = self.engine.read_token_logits()
+                    if self._f16_clamped(self.engine):
+                        continue                                # the engines run on bf16 operands now: this batch again
                     p1 = softmax_rows(logits)[:, 1]
                     o = 0
                     for ji, (ids, (a, b), q_len) in flat[start:end]:

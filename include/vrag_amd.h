@@ -278,7 +278,8 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
  * out_ids[q][j] = row_map[row] when `row_map` (device int64[n_map], the caller's local row -> global row table) is
  * given -- rows at or beyond n_map become -1 -- else id_base + row; missing hits -1 / -inf.  Queries are host memory
  * (the call returns once they have been uploaded); the kernels are only enqueued on `stream`: no synchronisation and no
- * device->host copy. */
+ * device->host copy.  `stream` = NULL means the legacy default stream here (not the handle's own stream): whatever
+ * consumes the lists next -- the all-gather -- is ordered against the stream the caller named. */
 int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries /*[nq,dim] host*/, int32_t nq, int32_t k,
                                    const int64_t* row_map /*device or NULL*/, int64_t n_map, int64_t id_base,
                                    float* out_scores /*[nq,k] device*/, int64_t* out_ids /*[nq,k] device*/, void* stream);

@@ -1487,6 +1487,7 @@ struct vrag_dense_index {
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
+  hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
 };
 
 struct vrag_sparse_index {
@@ -1511,6 +1512,7 @@ struct vrag_sparse_index {
   int pass_qb = 8;                    // queries per pass the resident tables were built for (8 or 16)
   bool last_multi = false;   // which kernel family the resident queries were prepared for
   hipEvent_t upload_done = nullptr;   // recorded behind the query-table uploads
+  hipEvent_t lists_done = nullptr;    // as in vrag_dense_index
 };
 
 namespace {
@@ -1580,6 +1582,7 @@ int paged_search(int nq, int k, u64** d_bound, size_t* d_bound_elems, const u64*
 int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st) {
   const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
   int rc;
+  if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));   // a device-resident search may still be reading the scratch
   if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
   if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
   if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;   // + per-query entry thresholds
@@ -1663,6 +1666,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
+  if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -1703,6 +1707,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));
   if (k > KMAX) {   // pages of KMAX on the scalar kernels (fp32 queries; the matrix-core paths stop at k = 16)
     const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, KMAX, ix->size);
     int rc;
@@ -1742,7 +1747,9 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
   ARG_CHECK(!row_map || n_map >= 0, "negative row map length");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
-  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  // NULL = the legacy default stream, NOT the handle's own stream: the caller's next operation (the all-gather) is
+  // ordered against the stream it named, and torch's default stream IS the null stream
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
   const long long n = (long long)nq * k;
@@ -1750,6 +1757,8 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
                      reinterpret_cast<const long long*>(row_map), (long long)n_map, (long long)id_base, out_scores,
                      reinterpret_cast<long long*>(out_ids));
   HIP_TRY(hipGetLastError());
+  if (!ix->lists_done) HIP_TRY(hipEventCreateWithFlags(&ix->lists_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ix->lists_done, st));
   return VRAG_OK;
 }
 
@@ -1862,6 +1871,7 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->d_docid) (void)hipFree(ix->d_docid);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
+  if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -1943,6 +1953,7 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   int rc;
   if (!ix->upload_done) HIP_TRY(hipEventCreateWithFlags(&ix->upload_done, hipEventDisableTiming));
+  if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));
   if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
   if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k))) return rc;
   // Batched path: two or more queries; per pass of SQB queries the union of their terms gets ids 1 .. SUW-1, the
@@ -2023,6 +2034,7 @@ int vrag_sparse_index_search(vrag_sparse_index* ix, const int64_t* q_indptr, con
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   int rc;
@@ -2059,7 +2071,7 @@ int vrag_sparse_index_search_device(vrag_sparse_index* ix, const int64_t* q_indp
   ARG_CHECK(!row_map || n_map >= 0, "negative row map length");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
-  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);   // NULL = the legacy default stream (see the dense form)
   int rc;
   if ((rc = sparse_search_enqueue(ix, q_indptr, q_indices, q_values, nq, k, st))) return rc;
   const long long n = (long long)nq * k;
@@ -2067,6 +2079,8 @@ int vrag_sparse_index_search_device(vrag_sparse_index* ix, const int64_t* q_indp
                      reinterpret_cast<const long long*>(row_map), (long long)n_map, (long long)id_base, out_scores,
                      reinterpret_cast<long long*>(out_ids));
   HIP_TRY(hipGetLastError());
+  if (!ix->lists_done) HIP_TRY(hipEventCreateWithFlags(&ix->lists_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ix->lists_done, st));
   return VRAG_OK;
 }
 

@@ -1133,6 +1133,7 @@ class GpuVectorStore(VectorStore):
             sub_parts, shard_rows, sub_dev = self._subset(kind, mask)
             which = np.nonzero(short)[0]
             scores, rows = self._device_topk(kind, sub_parts, shard_rows, [queries[i] for i in which], want, sub_dev)
+            rows = np.where((rows >= 0) & (rows < n), rows, -1)
             rows_out[which, :want] = rows
             score_out[which, :want] = np.where(rows >= 0, scores, np.float32(0.0))
         return rows_out, score_out

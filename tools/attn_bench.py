@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Attention kernels alone (vrag_debug_attn_ms): us per launch at ModernBERT-base shapes, one 65 536-token micro-batch.
-VRAG_ATTN_V1=1 selects the first-generation kernel (A/B inside one session: run the script twice)."""
+VRAG_ATTN_V2=1 selects the second-generation kernel (A/B inside one session: run the script twice)."""
 import ctypes as C
 import os
 import sys
@@ -10,7 +10,7 @@ import verbatim_rag_amd  # noqa
 from verbatim_rag_amd import _lib
 
 lib = _lib.load()
-tag = "v1" if os.environ.get("VRAG_ATTN_V1") else "v2"
+tag = "v2" if os.environ.get("VRAG_ATTN_V2") else "v1"
 for name, local, n_seqs, S in [("global S=512", 0, 128, 512), ("banded S=512", 1, 128, 512), ("global S=8192", 0, 8, 8192),
                                ("banded S=8192", 1, 8, 8192), ("global S=200", 0, 320, 200), ("banded S=200", 1, 320, 200)]:
     ms = C.c_float()

@@ -55,6 +55,14 @@ def main(pmc_path, bench_path):
             "note": "FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes; L2-fabric side, "
                     "Infinity-Cache hits included; kernel<3> = mean over the Wo and mlp-Wo launches",
         }
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("gemm_bf16.hip", "gemm_bf16.h", "common.h"):      # bench.py refuses the summary once these change
+        with open(os.path.join(root, "verbatim-rag_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    res["_gemm_source_sha16"] = h.hexdigest()[:16]
     print(json.dumps(res, indent=1))
 
 

@@ -511,21 +511,28 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         // The fold's per-row shift is the row's previous mean; the very first sub-layer has none, so layer 0's
         // mlp_norm runs as a stand-alone (two-pass) LayerNorm that also records the exact row means.
         const bool fold_here = fold && l > 0;
+        bool fused_stats = false;   // the GEMM finishes the row statistics itself (row walk): no finalize launch
         if (fold_here) {
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
           g.ln_shift = e->ln_shift + r0;
+          g.fin_mu = e->ln_mu + r0;
+          g.fin_rstd = e->ln_rstd + r0;
+          g.fin_eps = c.norm_eps;
+          fused_stats = gemm_residual_finalizes(g);
         }
-        ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
-        HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
-      }
-      if (fold && l == 0) {   // a = bf16(normalised h) without the gain (folded into Wi), ln_shift = mean(h)
-        ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, nullptr, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr,
-                                 e->ln_shift + r0, e->op_dtype));
-      } else {
-        int rc = fold ? finalize_stats(false) : layer_norm(L.mlp_norm);
-        if (rc) return rc;
+        {
+          ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
+          HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+        }
+        if (fold && l == 0) {   // a = bf16(normalised h) without the gain (folded into Wi), ln_shift = mean(h)
+          ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
+          HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, nullptr, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr,
+                                   e->ln_shift + r0, e->op_dtype));
+        } else if (!fused_stats) {
+          int rc = fold ? finalize_stats(false) : layer_norm(L.mlp_norm);
+          if (rc) return rc;
+        }
       }
       {
         GemmParams g{};
@@ -553,17 +560,24 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.N = H;
         g.K = I;
         g.out_f32 = e->h + (size_t)r0 * H;
+        bool fused_stats = false;
         if (fold && l + 1 < c.num_layers) {  // the next layer's attn_norm is folded into its QKV GEMM
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
           g.ln_shift = e->ln_shift + r0;
+          g.fin_mu = e->ln_mu + r0;
+          g.fin_rstd = e->ln_rstd + r0;
+          g.fin_eps = c.norm_eps;
+          fused_stats = gemm_residual_finalizes(g);
         }
-        ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
-        HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
-      }
-      if (fold && l + 1 < c.num_layers) {
-        int rc = finalize_stats(false);
-        if (rc) return rc;
+        {
+          ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
+          HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+        }
+        if (fold && l + 1 < c.num_layers && !fused_stats) {
+          int rc = finalize_stats(false);
+          if (rc) return rc;
+        }
       }
     }
   }

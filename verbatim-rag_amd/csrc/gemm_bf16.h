@@ -53,6 +53,15 @@ struct GemmParams {
   const float* ln_shift;  // [Mpad] or null: per-row shift c subtracted before the bf16 copy / the statistics (see the epilogue)
   bf16_t* resid_bf16;     // [Mpad, N] or null  = bf16(updated residual - c)
   float* stats_part;      // [Mpad, N/64, 2] or null
+  // Row-walk form of EPI_RESIDUAL (launcher's choice, gemm_residual_finalizes()): a workgroup computes ALL column tiles of
+  // its 256-row block one after the other, keeps the row statistics in LDS and finishes them itself -- what
+  // ln_stats_finalize_kernel did in a launch of its own (capi.hip): fin_mu[r] = d = mean(h - c), fin_rstd[r] =
+  // 1/sqrt(E[(h-c)^2] - d^2 + eps), ln_shift[r] <- c + d, same operands in the same order (bit-identical).
+  float* fin_mu;          // [Mpad] or null
+  float* fin_rstd;        // [Mpad]
+  float fin_eps;
+  int row_walk;           // filled by the launcher
+  int col_groups;         // filled by the launcher: > 1 = every XCD walks its row blocks once per group of column tiles (see the kernel)
   int op_dtype;           // kOpBf16 (0) or kOpF16 (1): what A, W and every 16-bit output hold (pointers stay typed bf16_t*)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias
@@ -65,6 +74,10 @@ const char* gemm_kernel_name(GemmEpi epi);
 // GEMMs with M <= threshold rows use the small-batch configuration (128x128 tiles, four LDS stages).
 // set_to >= 0 changes the threshold (0 disables the configuration); returns the current value.
 int gemm_small_m_threshold(int set_to);
+
+// True when launch_gemm(EPI_RESIDUAL, p) will finish the LayerNorm statistics inside the GEMM (p.fin_mu set and the tile
+// geometry suits the row walk): the caller then skips its stand-alone finalize launch.
+bool gemm_residual_finalizes(const GemmParams& p);
 
 // 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
 unsigned gemm_f16_saturated(bool reset);

@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(uns
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
 template <int EPI, int RT, int WROWS, typename T>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* smem, int wave, int lane,
-                                              int mw, int nw, bool v_block) {
+                                              int mw, int nw, bool v_block, int m0 = 0, char* stats_lds = nullptr) {
   typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
   // The lane index is re-read through an opaque asm: every per-lane address of the epilogue then depends on a value
   // defined inside the tile loop, so none of them is hoisted out of it to sit in (spilled) registers across the K loop.
@@ -152,9 +152,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             s1 = row16_sum(s1);
             s2 = row16_sum(s2);
             if (c16 == 0) {
-              float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
-              sp[0] = s1;
-              sp[1] = s2;
+              if (p.row_walk) {   // the workgroup owns the whole row block: partials stay in LDS (behind the operand ring)
+                float* sp = reinterpret_cast<float*>(stats_lds) + ((mw - m0 + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
+                sp[0] = s1;
+                sp[1] = s2;
+              } else {
+                float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
+                sp[0] = s1;
+                sp[1] = s2;
+              }
             }
           }
         }
@@ -508,14 +514,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   // Staying resident lets a tile's epilogue stores drain while the next tile's operands stream in.
   const int nbn = p.N / BN;
   const int K = p.K;
-  const int n_tiles = p.n_tiles;
+  const int n_tiles = (EPI == EPI_RESIDUAL && p.row_walk) ? p.n_tiles / nbn : p.n_tiles;   // units dealt to the workgroups
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int per_xcd_wgs = (gridDim.x + 7 - xcd) >> 3;  // workgroups of this grid that sit on my XCD
   const int tq = n_tiles >> 3, tr = n_tiles & 7;
   const int range_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const int range_len = xcd < tr ? tq + 1 : tq;
+  // Row walk (EPI_RESIDUAL with the LayerNorm statistics finished in-kernel): the unit dealt to a workgroup is a whole row
+  // block -- its nbn column tiles run back to back on this CU (the A panel is re-read from L2, the statistics meet in LDS).
+  const int sub = (EPI == EPI_RESIDUAL && p.row_walk) ? nbn : 1;
+  char* stats_lds = smem + NS * STAGE_BYTES;
   for (int tix = slot; tix < range_len; tix += per_xcd_wgs) {
-  const int b = range_lo + tix;
+  for (int nt = 0; nt < sub; ++nt) {
+  int b = (range_lo + tix) * sub + nt;
+  if (p.col_groups > 1) {
+    // Column groups (wide GEMMs, N = 9 tiles): with n fastest the 32 workgroups of an XCD touch all nbn weight tiles at once
+    // (3.5 MB at N = 2304) next to 3-4 streaming A panels -- more than the XCD's 4 MiB L2 holds, so the weight tiles are
+    // re-fetched from the Infinity Cache every round (1.9x the algorithmic bytes, profiles/r02_pmc_traffic.json).  Here the
+    // XCD owns whole row blocks and walks them once per group of column tiles: a group's weight tiles stay in L2 and the A
+    // panels are read once per group instead.
+    const int rows = range_len / nbn;               // row blocks of this XCD (the launcher guarantees whole row blocks)
+    int t = tix, c_lo = 0;
+    for (int gi = 0; gi < p.col_groups; ++gi) {
+      const int gw = (nbn - c_lo + (p.col_groups - gi) - 1) / (p.col_groups - gi);   // columns of this group
+      if (t < rows * gw) {
+        b = (range_lo / nbn + t / gw) * nbn + c_lo + t % gw;
+        break;
+      }
+      t -= rows * gw;
+      c_lo += gw;
+    }
+  }
   const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
@@ -647,15 +676,48 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<EPI, RT, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block);
+  gemm_epilogue<EPI, RT, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block, m0, stats_lds);
   __syncthreads();  // staging area is reused as operand slots by the next tile
-  }  // tile loop
+  if constexpr (EPI == EPI_RESIDUAL) {
+    if (p.row_walk && nt == sub - 1) {
+      // every column tile of rows m0 .. m0 + BM has passed: one thread per row finishes the statistics -- the arithmetic of
+      // ln_stats_finalize_kernel (capi.hip), partials summed in the same fixed order
+      if (tid < BM) {
+        const int np = p.N >> 6;
+        const float* part = reinterpret_cast<const float*>(stats_lds) + tid * np * 2;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < np; ++i) {
+          s1 += part[2 * i];
+          s2 += part[2 * i + 1];
+        }
+        const float d = s1 / (float)p.N;
+        const float var = fmaxf(s2 / (float)p.N - d * d, 0.f);
+        const float c = p.ln_shift ? p.ln_shift[m0 + tid] : 0.f;
+        p.fin_mu[m0 + tid] = d;
+        p.fin_rstd[m0 + tid] = 1.0f / sqrtf(var + p.fin_eps);
+        const_cast<float*>(p.ln_shift)[m0 + tid] = c + d;
+      }
+      __syncthreads();   // the next row block's epilogues reuse the statistics area
+    }
+  }
+  }  // column tiles of the unit
+  }  // unit loop
 }
 
 int gemm_small_m_threshold(int set_to) {
   static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 8192};
   if (set_to >= 0) thr.store(set_to);
   return thr.load();
+}
+
+// Row walk for the residual GEMMs (256 x 256 tiles): worth it when dealing whole row blocks fills the grid as well as
+// dealing single tiles does (M = 65 536: 256 row blocks on 256 workgroups), and the statistics fit behind the operand ring.
+static bool residual_row_walk(const GemmParams& p, int grid_cap) {
+  static const bool off = getenv("VRAG_GEMM_NO_ROWWALK") != nullptr;   // A/B knob
+  if (off || !p.fin_mu || !p.fin_rstd || !p.ln_shift || !p.resid_bf16 || p.N % 256 != 0 || p.N > 1024) return false;
+  const int nbm = (p.M + 255) / 256, nbn = p.N / 256;
+  auto fill = [&](int units) { return (double)units / (double)(((units + grid_cap - 1) / grid_cap) * grid_cap); };
+  return fill(nbm) >= fill(nbm * nbn) - 0.02;
 }
 
 // One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
@@ -671,6 +733,25 @@ static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   p.n_tiles = nbm * nbn;
+  p.row_walk = 0;
+  static const int col_groups = getenv("VRAG_GEMM_COLGROUPS") ? atoi(getenv("VRAG_GEMM_COLGROUPS")) : 0;   // tuning knob
+  p.col_groups = (col_groups > 1 && BM == 256 && nbn >= 2 * col_groups && nbm % 8 == 0 && grid_cap % 8 == 0) ? col_groups : 0;
+  if constexpr (EPI == EPI_RESIDUAL && BM == 256 && BN == 256 && NS == 2) {
+    if (residual_row_walk(p, grid_cap)) {
+      constexpr int SMEM_RW = SMEM + 256 * 4 * 4 * 2 * (int)sizeof(float);   // + [256 rows][<= 16 segments][2] statistics
+      static bool attr_rw = false;
+      if (!attr_rw) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_RW);
+        if (e != hipSuccess) return e;
+        attr_rw = true;
+      }
+      p.row_walk = 1;
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>), dim3(std::min(nbm, grid_cap)), dim3(WM * WN * 64),
+                         SMEM + nbn * 256 * 4 * 2 * (int)sizeof(float), stream, p);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
                      stream, p);
   return hipGetLastError();
@@ -717,6 +798,13 @@ hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
   if (p.M <= 0) return hipSuccess;
   if (p.N % 128 != 0 || p.K % BK != 0) return hipErrorInvalidValue;
   return p.op_dtype == kOpF16 ? launch_typed<f16_t>(epi, p, stream) : launch_typed<bf16_t>(epi, p, stream);
+}
+
+bool gemm_residual_finalizes(const GemmParams& p) {
+  static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr, res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;
+  static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;
+  if (p.M <= gemm_small_m_threshold(-1) || force128 || res128 || p.N % 256 != 0 || p.M < 256) return false;   // launch_t's choice of the 256 x 256 configuration
+  return residual_row_walk(p, pgrid);
 }
 
 const char* gemm_kernel_name(GemmEpi epi) {

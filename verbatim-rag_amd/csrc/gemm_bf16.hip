@@ -713,8 +713,13 @@ int gemm_small_m_threshold(int set_to) {
 // Row walk for the residual GEMMs (256 x 256 tiles): worth it when dealing whole row blocks fills the grid as well as
 // dealing single tiles does (M = 65 536: 256 row blocks on 256 workgroups), and the statistics fit behind the operand ring.
 static bool residual_row_walk(const GemmParams& p, int grid_cap) {
-  static const bool off = getenv("VRAG_GEMM_NO_ROWWALK") != nullptr;   // A/B knob
-  if (off || !p.fin_mu || !p.fin_rstd || !p.ln_shift || !p.resid_bf16 || p.N % 256 != 0 || p.N > 1024) return false;
+  // Opt-in (VRAG_GEMM_ROWWALK=1).  Measured on the headline step (r3d session, three alternating repetitions): 6 362 / 6 356 /
+  // 6 341 chunks/s with the row walk against 6 429 / 6 401 / 6 346 with the tile walk + 84 stand-alone finalize launches --
+  // the launches were never on the critical path of the two-stream schedule, and three column tiles back to back on one CU
+  // re-read their A panel from L2 a little slower than three CUs sharing it do.  Kept for single-stream / graph-captured
+  // schedules, where a launch is a launch.
+  static const bool on = getenv("VRAG_GEMM_ROWWALK") != nullptr;
+  if (!on || !p.fin_mu || !p.fin_rstd || !p.ln_shift || !p.resid_bf16 || p.N % 256 != 0 || p.N > 1024) return false;
   const int nbm = (p.M + 255) / 256, nbn = p.N / 256;
   auto fill = [&](int units) { return (double)units / (double)(((units + grid_cap - 1) / grid_cap) * grid_cap); };
   return fill(nbm) >= fill(nbm * nbn) - 0.02;

@@ -217,6 +217,13 @@ int vrag_encoder_extract_qa(vrag_encoder* enc, const int32_t* ids, const int32_t
                             const int32_t* rng_seq, const int32_t* rng_start, const int32_t* rng_end,
                             int32_t n_ranges, float* logits);
 
+/* Launch-bound batches (at most 8 192 packed rows in one micro-batch -- a query's handful of chunks, the reference's call
+ * shape verbatim_rag/core.py:238-255 with k = 5): the layer schedule of a (rows, attention blocks, layers) geometry is
+ * captured into a HIP graph the second time it is seen and replayed afterwards; results are bit-identical to the eager
+ * launches (same kernels, same arguments).  enable: 0 = eager only, > 0 = row limit for graph replay, < 0 = leave as is;
+ * *replays = graph launches so far, *cached = instantiated graphs (either may be NULL).  VRAG_GRAPHS=0 disables at create. */
+int vrag_encoder_graph_stats(vrag_encoder* enc, int32_t enable, int64_t* replays, int32_t* cached);
+
 /* fp16 operands (VRAG_OPERAND_F16) saturate at +-65504 instead of overflowing.  *saturated = 1 if any fp32 -> fp16
  * operand conversion on this device (weights at load time, LayerNorm-fold copies, q / k / v, GeGLU outputs, attention
  * outputs) has had to clamp since the last reset: the logits computed meanwhile are not to be trusted -- re-run with

@@ -229,3 +229,47 @@ def test_layernorm_fold_with_row_mean_offsets_and_outlier_channels(monkeypatch):
     for a, b in zip(e_fold, e_plain):
         assert a < max(3e-2, 1.5 * b), f"fold {e_fold} vs stand-alone LayerNorm {e_plain}"
     assert f_fold < max(3e-2, 1.5 * f_plain), (f_fold, f_plain)
+
+
+def test_graph_replay_is_bit_identical_to_the_eager_launches():
+    """Launch-bound batches (the reference's call shape: one question x k = 5 chunks, verbatim_rag/core.py:238-255) replay a
+    captured HIP graph from the third call of a geometry on: same kernels, same arguments -> the same bits as eager launches,
+    for new contents of the same geometry, across geometry changes and back."""
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=7)
+    rng = np.random.default_rng(5)
+    qa_w, qa_b = rng.standard_normal((2, 128)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
+
+    def engine(graphs):
+        e = EncoderEngine(ModernBertShape(**TINY), w, max_tokens=8192, max_seqs=64, max_seq_len=512, max_ranges=1024)
+        e.set_qa_head(qa_w, qa_b)
+        e.graph_stats(enable=8192 if graphs else 0)
+        return e
+
+    eager, graphed = engine(False), engine(True)
+
+    def batch(lens, seed):
+        r = np.random.default_rng(seed)
+        seqs = [r.integers(3, 512, size=n).astype(np.int32) for n in lens]
+        bounds = [[(1, n // 2), (n // 2 + 1, n - 1)] for n in lens]
+        return seqs, bounds
+
+    geoms = [(190, 201, 187, 170, 199), (60, 70), (300, 301, 280, 290, 310)]
+    try:
+        for rep in range(4):
+            for gi, lens in enumerate(geoms):
+                seqs, bounds = batch(lens, 100 * rep + gi)
+                a = eager.qa_logits(seqs, bounds)
+                b = graphed.qa_logits(seqs, bounds)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, gi)
+                assert np.array_equal(eager.read_hidden(final_norm=True), graphed.read_hidden(final_norm=True)), (rep, gi)
+        replays, cached = graphed.graph_stats()
+        assert cached == len(geoms) and replays == len(geoms) * 3        # call 1 eager, call 2 capture + launch, calls 3, 4 replay
+        assert eager.graph_stats() == (0, 0)
+        ref = O.qa_sentence_logits(O.encoder_forward(cfg, w, seqs[0]), bounds[0], qa_w, qa_b)
+        assert np.abs(b[0] - ref).max() < 1e-3
+    finally:
+        eager.close()
+        graphed.close()

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vrag_encoder_read_splade_sparse": (C.c_int, [_H, C.c_float, C.c_int32, _IP, _IP, _FP, C.c_void_p]),
     "vrag_encoder_read_hidden": (C.c_int, [_H, C.c_int32, _FP, C.c_void_p]),
     "vrag_encoder_extract_qa": (C.c_int, [_H, _IP, _IP, C.c_int32, _IP, _IP, _IP, C.c_int32, _FP]),
+    "vrag_encoder_graph_stats": (C.c_int, [_H, C.c_int32, _LP, _IP]),
     "vrag_encoder_f16_saturated": (C.c_int, [_H, C.c_int32, _IP]),
     "vrag_encoder_set_concurrency": (C.c_int, [_H, C.c_int32]),
     "vrag_encoder_set_profiling": (C.c_int, [_H, C.c_int32]),

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "attention.h"
+
+#include <array>
+#include <map>
 #include "common.h"
 #include "gemm_bf16.h"
 #include "norm_heads.h"
@@ -255,6 +258,21 @@ struct vrag_encoder {
   std::vector<int> seq_start, seq_len;
   std::vector<MicroBatch> mbs;
   bool ran = false;
+
+  // Launch-bound batches (one query's handful of chunks: ~180 launches of a few microseconds each): the layer schedule of a
+  // (rows, q-blocks, layers) geometry is captured into a HIP graph the second time the geometry is seen and replayed from
+  // then on -- every per-batch quantity the kernels read (ids, positions, block descriptors) lives in device arrays that
+  // load_batch refreshes, every pointer is a fixed workspace address, so only the geometry is baked into the graph.
+  struct GraphEntry {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    int seen = 0;
+    uint64_t last_use = 0;
+  };
+  std::map<std::array<int, 5>, GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  int graph_rows_max = 8192;   // 0 disables (VRAG_GRAPHS=0); batches above it are throughput-bound, not launch-bound
+  int64_t graph_replays = 0;
 
   // profiling
   bool prof_on = false;
@@ -775,6 +793,7 @@ int init_streams(vrag_encoder* e) {
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->n_streams = 2;  // micro-batches alternate between two internal streams (VRAG_STREAMS=1 disables)
   if (const char* ns = getenv("VRAG_STREAMS")) e->n_streams = std::min(4, std::max(1, atoi(ns)));
+  if (const char* gr = getenv("VRAG_GRAPHS")) e->graph_rows_max = std::max(0, atoi(gr)) == 1 ? 8192 : std::max(0, atoi(gr));   // 0 = eager only
   for (int i = 0; i < 4; ++i) HIP_TRY(hipStreamCreateWithFlags(&e->aux_streams[i], hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
@@ -1126,6 +1145,10 @@ void vrag_encoder_destroy(vrag_encoder* e) {
     (void)hipEventDestroy(r.b);
   }
   for (auto ev : e->prof_free) (void)hipEventDestroy(ev);
+  for (auto& kv : e->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
   for (void* p : e->dev_allocs) (void)hipFree(p);
   for (void* p : e->host_allocs) (void)hipHostFree(p);
   for (int i = 0; i < 4; ++i) {
@@ -1407,14 +1430,83 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   return VRAG_OK;
 }
 
+// Eager or graph-replayed layer schedule (see vrag_encoder::graphs).  First sight of a geometry: eager (this also runs every
+// first-use hipFuncSetAttribute of the instantiations involved, which must not happen inside a capture); second: capture,
+// instantiate, launch; afterwards: one hipGraphLaunch.
+static int run_layers_maybe_graphed(vrag_encoder* e, int n_layers, hipStream_t st) {
+  auto eager = [&]() { return e->arch == 1 ? run_layers_bert_locked(e, n_layers, st) : run_layers_locked(e, n_layers, st); };
+  const bool eligible = e->graph_rows_max > 0 && e->mbs.size() == 1 && e->rows <= e->graph_rows_max && !e->prof_on &&
+                        st != nullptr && n_layers > 0;
+  if (!eligible) return eager();
+  const MicroBatch& mb = e->mbs[0];
+  const std::array<int, 5> key = {e->rows, mb.blk1 - mb.blk0, mb.lblk1 - mb.lblk0, n_layers, e->types_loaded ? 1 : 0};
+  auto& g = e->graphs[key];
+  g.last_use = ++e->graph_clock;
+  if (g.exec) {
+    HIP_TRY(hipGraphLaunch(g.exec, st));
+    ++e->graph_replays;
+    e->ran = true;
+    return VRAG_OK;
+  }
+  if (g.seen++ == 0) return eager();
+  if (e->graphs.size() > 32) {   // bound the cache: drop the least recently used instantiated graph
+    auto victim = e->graphs.end();
+    for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
+      if (it->second.exec && it->first != key && (victim == e->graphs.end() || it->second.last_use < victim->second.last_use)) victim = it;
+    if (victim != e->graphs.end()) {
+      (void)hipGraphExecDestroy(victim->second.exec);
+      (void)hipGraphDestroy(victim->second.graph);
+      e->graphs.erase(victim);
+    }
+  }
+  auto& slot = e->graphs[key];
+  hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (ce != hipSuccess) return eager();                    // a stream that cannot be captured: stay eager
+  const int rc = eager();
+  hipGraph_t graph = nullptr;
+  ce = hipStreamEndCapture(st, &graph);
+  if (rc != VRAG_OK || ce != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    slot.seen = -1000000;                                   // never try this geometry again
+    return rc != VRAG_OK ? rc : eager();
+  }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    slot.seen = -1000000;
+    return eager();
+  }
+  slot.graph = graph;
+  slot.exec = exec;
+  HIP_TRY(hipGraphLaunch(exec, st));
+  ++e->graph_replays;
+  e->ran = true;
+  return VRAG_OK;
+}
+
 int vrag_encoder_run_layers(vrag_encoder* e, int32_t n_layers, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   ARG_CHECK(n_layers >= 0 && n_layers <= e->cfg.num_layers, "n_layers out of range");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
-  return e->arch == 1 ? run_layers_bert_locked(e, n_layers, pick_stream(e, stream))
-                      : run_layers_locked(e, n_layers, pick_stream(e, stream));
+  return run_layers_maybe_graphed(e, n_layers, pick_stream(e, stream));
+}
+
+int vrag_encoder_graph_stats(vrag_encoder* e, int32_t enable, int64_t* replays, int32_t* cached) {
+  ARG_CHECK(e, "null encoder handle");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  if (enable == 0) e->graph_rows_max = 0;
+  else if (enable > 0) e->graph_rows_max = enable;
+  if (replays) *replays = e->graph_replays;
+  if (cached) {
+    int n = 0;
+    for (auto& kv : e->graphs) n += kv.second.exec != nullptr;
+    *cached = n;
+  }
+  return VRAG_OK;
 }
 
 int vrag_encoder_run(vrag_encoder* e, void* stream) {

@@ -180,6 +180,13 @@ class EncoderEngine:
         except Exception:
             pass
 
+    def graph_stats(self, enable: int = -1) -> Tuple[int, int]:
+        """(graph replays so far, instantiated graphs) of the launch-bound path (`vrag_encoder_graph_stats`); `enable`:
+        0 = eager launches only, > 0 = packed-row limit below which the layer schedule is captured and replayed."""
+        n, c = C.c_int64(0), C.c_int32(0)
+        _lib.check("vrag_encoder_graph_stats", self._lib.vrag_encoder_graph_stats(self._h, enable, C.byref(n), C.byref(c)))
+        return int(n.value), int(c.value)
+
     def f16_saturated(self, reset: bool = True) -> bool:
         """True when an fp32 -> fp16 operand conversion on this device had to clamp to +-65504 since the last reset
         (`vrag_encoder_f16_saturated`): the logits computed meanwhile are not to be trusted -- use bf16 operands for

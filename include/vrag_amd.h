@@ -319,6 +319,16 @@ int vrag_topk_merge(const float* scores, const int64_t* ids, int32_t n_lists, in
                     int64_t score_list_stride, int64_t id_list_stride, float* out_scores, int64_t* out_ids,
                     int32_t on_device, int32_t device, void* stream);
 
+/* Sentence boundaries of a batch of chunk texts (the GPU-side sentence split): for every document the parts of
+ *   re.split(r"(?<=[.!?])\s+", text), each stripped of surrounding white space, empty parts dropped
+ * (packages/core/verbatim_core/extractors.py:190-195), as [start, end) BYTE offsets into the document's UTF-8 text.
+ * `text` holds the documents back to back, document d is bytes doc_off[d] .. doc_off[d+1] (doc_off[0] = 0).  counts[d] is
+ * the exact number of sentences; only the first `cap` of a document are stored at starts/ends[d * cap ...] -- the caller
+ * re-splits a document with counts[d] > cap itself.  White space = Python's str.isspace set.  Host pointers; synchronous. */
+int vrag_split_sentences(const uint8_t* text, const int64_t* doc_off /*[n_docs+1]*/, int32_t n_docs, int32_t cap,
+                         int32_t* counts /*[n_docs]*/, int32_t* starts /*[n_docs, cap]*/, int32_t* ends /*[n_docs, cap]*/,
+                         int32_t device);
+
 /* -inf / -1 lists in device memory: the contribution of a rank that holds none of the rows. */
 int vrag_topk_fill_empty(float* scores /*[n] device*/, int64_t* ids /*[n] device*/, int64_t n, int32_t device, void* stream);
 

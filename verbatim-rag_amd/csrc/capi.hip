@@ -106,6 +106,28 @@ __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np,
   shift_out[r] = c + d;
 }
 
+// Packing metadata on the device: the host hands over the batch as it received it -- ids back to back plus
+// (first row, first id, length) per sequence -- and this kernel lays the padding-free row image out: ids / position inside
+// the sequence / sequence index for every row of the packed buffer, pad tokens in the alignment gaps, between micro-batches
+// and over the stale rows of a longer previous batch.  One lane per row, sequence found by bisection.
+__global__ void pack_layout_kernel(const int* __restrict__ packed, const int* __restrict__ seq_row, const int* __restrict__ seq_src,
+                                   const int* __restrict__ seq_len, int n_seqs, int rows, int pad_id, int* __restrict__ ids,
+                                   int* __restrict__ pos, int* __restrict__ tok_seq) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int lo = 0, hi = n_seqs;            // last sequence whose first row is <= r
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seq_row[mid] <= r) lo = mid;
+    else hi = mid;
+  }
+  const int i = r - seq_row[lo];
+  const bool in = i >= 0 && i < seq_len[lo];
+  ids[r] = in ? packed[seq_src[lo] + i] : pad_id;
+  pos[r] = in ? i : 0;
+  tok_seq[r] = in ? lo : -1;
+}
+
 // One workgroup per sequence: stable compaction of a SPLADE row (weights are >= 0) into (index, value) pairs.
 __global__ __launch_bounds__(256) void splade_compact_kernel(const float* __restrict__ rows, int V, int ld, float thr, int cap,
                                                              int* __restrict__ counts, int* __restrict__ idx,
@@ -229,6 +251,8 @@ struct vrag_encoder {
   // workspace
   int cap_rows = 0;
   int *d_ids = nullptr, *d_pos = nullptr, *d_tokseq = nullptr;
+  int *d_packed = nullptr, *d_seq_meta = nullptr;   // the batch as handed over: ids back to back; [3][max_seqs] first row / first id / length
+  int* h_seq_meta = nullptr;
   float* h = nullptr;
   bf16_t *a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr, *act = nullptr;
   float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
@@ -246,7 +270,7 @@ struct vrag_encoder {
   int sp_cap = 0;
 
   // pinned staging
-  int *h_ids = nullptr, *h_pos = nullptr, *h_tokseq = nullptr;
+  int* h_ids = nullptr;   // the batch's ids back to back (the row image is laid out on the device, pack_layout_kernel)
   int *h_blk_start = nullptr, *h_blk_len = nullptr, *h_blk_q0 = nullptr;
   int *h_lblk_start = nullptr, *h_lblk_len = nullptr, *h_lblk_q0 = nullptr;
   int *h_rng_start = nullptr, *h_rng_end = nullptr;
@@ -834,24 +858,26 @@ int init_workspace(vrag_encoder* e) {
   TRY(dev_alloc(e, &e->ln_mu, R));
   TRY(dev_alloc(e, &e->ln_rstd, R));
   TRY(dev_alloc(e, &e->ln_shift, R));
-  TRY(dev_alloc(e, &e->d_blk_start, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_blk_len, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_blk_q0, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_lblk_start, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_lblk_len, e->cap_blocks));
-  TRY(dev_alloc(e, &e->d_lblk_q0, e->cap_blocks));
+  // the six q-block descriptor arrays are slices of ONE buffer (host and device alike): one upload per batch
+  TRY(dev_alloc(e, &e->d_blk_start, (size_t)6 * e->cap_blocks));
+  e->d_blk_len = e->d_blk_start + e->cap_blocks;
+  e->d_blk_q0 = e->d_blk_start + 2 * e->cap_blocks;
+  e->d_lblk_start = e->d_blk_start + 3 * e->cap_blocks;
+  e->d_lblk_len = e->d_blk_start + 4 * e->cap_blocks;
+  e->d_lblk_q0 = e->d_blk_start + 5 * e->cap_blocks;
+  TRY(dev_alloc(e, &e->d_packed, (size_t)cfg->max_tokens));
+  TRY(dev_alloc(e, &e->d_seq_meta, (size_t)3 * cfg->max_seqs));
   TRY(dev_alloc(e, &e->d_rng_start, cfg->max_ranges));
   TRY(dev_alloc(e, &e->d_rng_end, cfg->max_ranges));
   TRY(dev_alloc(e, &e->d_rng_out, (size_t)cfg->max_ranges * H));
   TRY(host_alloc(e, &e->h_ids, R));
-  TRY(host_alloc(e, &e->h_pos, R));
-  TRY(host_alloc(e, &e->h_tokseq, R));
-  TRY(host_alloc(e, &e->h_blk_start, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_blk_len, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_blk_q0, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_lblk_start, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_lblk_len, e->cap_blocks));
-  TRY(host_alloc(e, &e->h_lblk_q0, e->cap_blocks));
+  TRY(host_alloc(e, &e->h_blk_start, (size_t)6 * e->cap_blocks));
+  e->h_blk_len = e->h_blk_start + e->cap_blocks;
+  e->h_blk_q0 = e->h_blk_start + 2 * e->cap_blocks;
+  e->h_lblk_start = e->h_blk_start + 3 * e->cap_blocks;
+  e->h_lblk_len = e->h_blk_start + 4 * e->cap_blocks;
+  e->h_lblk_q0 = e->h_blk_start + 5 * e->cap_blocks;
+  TRY(host_alloc(e, &e->h_seq_meta, (size_t)3 * cfg->max_seqs));
   TRY(host_alloc(e, &e->h_rng_start, cfg->max_ranges));
   TRY(host_alloc(e, &e->h_rng_end, cfg->max_ranges));
   // pad ids everywhere so never-loaded rows embed a valid token
@@ -1347,50 +1373,44 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     set_error("batch has %lld tokens, handle capacity is %d", (long long)total, c.max_tokens);
     return VRAG_ERR_CAPACITY;
   }
+  // Host side: O(sequences) geometry only -- first row of every sequence (multiples of kSeqAlign; a micro-batch starts on a
+  // multiple of kRowPad), micro-batch cuts, q-block descriptors -- plus ONE pass over the ids that copies them into the
+  // pinned staging and range-checks them.  The per-row image (ids in their rows, positions, sequence index, pad rows) is
+  // laid out on the device by pack_layout_kernel.
   int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_lblk0 = 0, nlblk = 0, mb_tokens = 0;
   size_t src = 0;
-  int prev_rows = e->rows;
+  const int prev_rows = e->rows;
+  int *seq_row = e->h_seq_meta, *seq_src = e->h_seq_meta + c.max_seqs, *seq_ln = e->h_seq_meta + 2 * c.max_seqs;
   for (int s = 0; s < n_seqs; ++s) {
     const int Ls = seq_lens[s];
     t = (int)align_up(t, kSeqAlign);
     if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
       const int row1 = (int)align_up(t, kRowPad);
       e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk});
-      for (int r = t; r < row1; ++r) {
-        e->h_ids[r] = c.pad_token_id;
-        e->h_pos[r] = 0;
-        e->h_tokseq[r] = -1;
-      }
       t = row1;
       mb_row0 = row1;
       mb_blk0 = nblk;
       mb_lblk0 = nlblk;
       mb_tokens = 0;
     }
-    // alignment gap before this sequence
-    for (int r = (s == 0 ? 0 : e->seq_start[s - 1] + seq_lens[s - 1]); r < t; ++r) {
-      e->h_ids[r] = c.pad_token_id;
-      e->h_pos[r] = 0;
-      e->h_tokseq[r] = -1;
-    }
     e->seq_start[s] = t;
-    for (int i = 0; i < Ls; ++i) {
-      const int id = ids[src + i];
-      ARG_CHECK(id >= 0 && id < c.vocab_size, "token id %d outside the vocabulary (sequence %d)", id, s);
-      e->h_ids[t + i] = id;
-      e->h_pos[t + i] = i;
-      e->h_tokseq[t + i] = s;
-    }
+    seq_row[s] = t;
+    seq_src[s] = (int)src;
+    seq_ln[s] = Ls;
     for (int q0 = 0; q0 < Ls; q0 += attention_q_block(false)) {
-      e->h_blk_start[nblk] = t;
-      e->h_blk_len[nblk] = Ls;
-      e->h_blk_q0[nblk] = q0;
+      if (nblk < e->cap_blocks) {
+        e->h_blk_start[nblk] = t;
+        e->h_blk_len[nblk] = Ls;
+        e->h_blk_q0[nblk] = q0;
+      }
       ++nblk;
     }
     for (int q0 = 0; q0 < Ls; q0 += attention_q_block(true)) {
-      e->h_lblk_start[nlblk] = t;
-      e->h_lblk_len[nlblk] = Ls;
-      e->h_lblk_q0[nlblk] = q0;
+      if (nlblk < e->cap_blocks) {
+        e->h_lblk_start[nlblk] = t;
+        e->h_lblk_len[nlblk] = Ls;
+        e->h_lblk_q0[nlblk] = q0;
+      }
       ++nlblk;
     }
     src += Ls;
@@ -1403,13 +1423,23 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
               e->cap_rows, e->cap_blocks);
     return VRAG_ERR_CAPACITY;
   }
+  {
+    unsigned bad = 0;
+    const unsigned V = (unsigned)c.vocab_size;
+    for (int64_t i = 0; i < total; ++i) {   // one vectorisable pass: copy + range check
+      const int id = ids[i];
+      bad |= (unsigned)((unsigned)id >= V);
+      e->h_ids[i] = id;
+    }
+    if (bad) {
+      size_t o = 0;
+      for (int s = 0; s < n_seqs; o += seq_lens[s], ++s)
+        for (int i = 0; i < seq_lens[s]; ++i)
+          ARG_CHECK(ids[o + i] >= 0 && ids[o + i] < c.vocab_size, "token id %d outside the vocabulary (sequence %d)", ids[o + i], s);
+    }
+  }
   // rows up to max(rows, previous rows) get pad ids so stale tokens of an older batch vanish
   const int fill_to = std::min(e->cap_rows, std::max(rows, prev_rows));
-  for (int r = t; r < fill_to; ++r) {
-    e->h_ids[r] = c.pad_token_id;
-    e->h_pos[r] = 0;
-    e->h_tokseq[r] = -1;
-  }
   e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk});
   e->n_seqs = n_seqs;
   e->n_tokens = (int)total;
@@ -1418,15 +1448,14 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   e->n_ranges = 0;
   e->ran = false;
   e->types_loaded = false;   // segment ids belong to one batch
-  HIP_TRY(hipMemcpyAsync(e->d_ids, e->h_ids, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_pos, e->h_pos, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_tokseq, e->h_tokseq, (size_t)fill_to * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_blk_start, e->h_blk_start, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_blk_len, e->h_blk_len, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_blk_q0, e->h_blk_q0, (size_t)nblk * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_lblk_start, e->h_lblk_start, (size_t)nlblk * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_lblk_len, e->h_lblk_len, (size_t)nlblk * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->d_lblk_q0, e->h_lblk_q0, (size_t)nlblk * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_packed, e->h_ids, (size_t)total * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_seq_meta, e->h_seq_meta, (size_t)3 * c.max_seqs * sizeof(int), hipMemcpyHostToDevice, st));
+  // one upload for the six descriptor arrays: from the first used entry of the first to the last used entry of the last
+  HIP_TRY(hipMemcpyAsync(e->d_blk_start, e->h_blk_start, ((size_t)5 * e->cap_blocks + nlblk) * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(pack_layout_kernel, dim3((fill_to + 255) / 256), dim3(256), 0, st, e->d_packed, e->d_seq_meta,
+                     e->d_seq_meta + c.max_seqs, e->d_seq_meta + 2 * c.max_seqs, n_seqs, fill_to, c.pad_token_id, e->d_ids, e->d_pos,
+                     e->d_tokseq);
+  HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }
 

@@ -29,6 +29,7 @@ from .packing import (
     TokenizerAdapter,
     encode_question_and_sentences,
     split_into_sentences,
+    split_into_sentences_batch,
     valid_boundaries,
 )
 
@@ -117,6 +118,7 @@ class GpuModelSpanExtractor(SpanExtractor):
     """
 
     DEFAULT_MODEL = "KRLabsOrg/verbatim-rag-modern-bert-v2"
+    GPU_SPLIT_MIN = 256   # unseen chunks in one call from which the sentence split runs on the GPU (prepare_chunks at ingest)
     _FORMAT_HIGHLIGHTER = "highlighter"
     _FORMAT_QA_MODEL = "qa_model"
 
@@ -294,7 +296,9 @@ class GpuModelSpanExtractor(SpanExtractor):
         with self._cache_lock:
             missing = [t for t in dict.fromkeys(texts) if t not in self._chunk_cache]
             if missing:
-                split = [split_into_sentences(t) for t in missing]
+                # ingest-sized batches of unseen chunks: boundaries on the GPU (one lane per chunk); a query's few: the regex
+                split = split_into_sentences_batch(missing, int(self.device.replace("cuda:", ""))) if len(missing) >= self.GPU_SPLIT_MIN \
+                    else [split_into_sentences(t) for t in missing]
                 flat = [s for sents in split for s in sents]
                 flat_ids = self._tok.ids_batch(flat, max_length=self.qa_max_length - 2)
                 if len(self._chunk_cache) + len(missing) > self._chunk_cache_size:

@@ -26,6 +26,45 @@ def split_into_sentences(text: str) -> List[str]:
     return [s.strip() for s in _SENT_SPLIT.split(text) if s.strip()]
 
 
+def split_into_sentences_batch(texts: Sequence[str], device: int = 0, cap: int = 64) -> List[List[str]]:
+    """`[split_into_sentences(t) for t in texts]` for a batch of chunk texts with the boundaries found on the GPU
+    (`vrag_split_sentences`, csrc/text.hip: one lane scans one document's UTF-8 bytes) -- the ingest-time form of the
+    reference's per-chunk, per-query regex split.  A document with more than `cap` sentences is re-split by
+    the regex here; the result is identical either way (tests/test_text_gpu.py)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+
+    texts = list(texts)
+    if not texts:
+        return []
+    lib = _lib.load()
+    _lib.require_gpu()
+    raw = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(raw) + 1, np.int64)
+    np.cumsum([len(b) for b in raw], out=off[1:])
+    blob = b"".join(raw) or b"\x00"
+    counts = np.empty(len(raw), np.int32)
+    starts = np.empty((len(raw), cap), np.int32)
+    ends = np.empty((len(raw), cap), np.int32)
+    buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+    _lib.check("vrag_split_sentences", lib.vrag_split_sentences(
+        C.cast(buf, C.c_void_p), off.ctypes.data_as(C.POINTER(C.c_int64)), len(raw), cap, counts.ctypes.data_as(C.POINTER(C.c_int32)),
+        starts.ctypes.data_as(C.POINTER(C.c_int32)), ends.ctypes.data_as(C.POINTER(C.c_int32)), device))
+    out: List[List[str]] = []
+    for d, (t, b) in enumerate(zip(texts, raw)):
+        n = int(counts[d])
+        if n > cap:
+            out.append(split_into_sentences(t))
+        elif len(b) == len(t):           # pure ASCII: byte offsets are character offsets
+            out.append([t[a:z] for a, z in zip(starts[d, :n].tolist(), ends[d, :n].tolist())])
+        else:
+            out.append([b[a:z].decode("utf-8") for a, z in zip(starts[d, :n].tolist(), ends[d, :n].tolist())])
+    return out
+
+
 class TokenizerAdapter:
     """Uniform `ids(text, add_special_tokens, max_length)` over a HF fast tokenizer
     (transformers) or a raw `tokenizers.Tokenizer`; truncation like the reference's

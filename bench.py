@@ -217,6 +217,24 @@ def topk_recall_check(seed: int = 1234):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def power_limited_rate(shape, rows: int, device: int, value: float):
+    """What the matrix pipe sustains on THIS part under its package power cap: the bare main loop of the widest GEMM
+    (EPI_NONE: no epilogue, nothing stored) on random operands, looped alone.  Every kernel class of the step runs at the cap
+    (profiles/r03_energy_by_class.json), so this -- not the nominal 2.5 PFLOP/s -- is the rate the main loops are bound by;
+    reported beside the nominal fraction, never instead of it.  Never raises."""
+    try:
+        import ctypes as C
+
+        from verbatim_rag_amd import _lib as L
+
+        ms = C.c_float()
+        L.check("gemm", L.load().vrag_debug_gemm_ms(7, rows, 3 * shape.hidden_size, shape.hidden_size, 60, device, C.byref(ms)))
+        plateau = 2.0 * rows * 3 * shape.hidden_size * shape.hidden_size / (ms.value * 1e-3) / 1e12
+        return {"power_limited_mainloop_tflops": plateau, "model_frac_of_power_limited_rate": value * chunk_flops(shape) / 1e12 / plateau}
+    except Exception as exc:
+        return {"power_limited_mainloop_tflops": f"{type(exc).__name__}: {exc}"}
+
+
 def api_leg(eng, shape, n_chunks: int, steps: int):
     """What a caller of the plug point gets (reference call site verbatim_rag/core.py:255):
     `GpuModelSpanExtractor.extract_spans_batch` for ONE question over `n_chunks` real-text chunks of ~512 tokens -- tokenise
@@ -535,24 +553,9 @@ def main() -> None:
                                     "avg_launch_ms": v["avg_launch_ms"]} for c, v in iso_cls.items()},
                     "breakdown_ms_per_step": {k: v[0] / 2 for k, v in iso.items() if v[1] > 0}}
         cpu, parity, recall, api, tok16 = None, None, None, None, None
-        if world == 1 and args.cpu_budget > 0 and roof is not None:
-            # What the matrix pipe sustains on THIS part under its package power cap: the bare main loop of the widest GEMM
-            # (EPI_NONE: no epilogue, nothing stored) on random operands, looped alone.  Every kernel class of the step runs at
-            # the cap (profiles/r03_energy_by_class.json), so this -- not the nominal 2.5 PFLOP/s -- is the rate the main
-            # loops are bound by; reported beside the nominal fraction, never instead of it.
-            try:
-                import ctypes as C
-
-                from verbatim_rag_amd import _lib as L
-
-                ms = C.c_float()
-                Mb = min(args.micro_batch_tokens or n_chunks * SEQ, n_chunks * SEQ)
-                L.check("gemm", L.load().vrag_debug_gemm_ms(7, Mb, 3 * shape.hidden_size, shape.hidden_size, 60, local_rank, C.byref(ms)))
-                plateau = 2.0 * Mb * 3 * shape.hidden_size * shape.hidden_size / (ms.value * 1e-3) / 1e12
-                roof["power_limited_mainloop_tflops"] = plateau
-                roof["model_frac_of_power_limited_rate"] = value * chunk_flops(shape) / 1e12 / plateau
-            except Exception as exc:
-                roof["power_limited_mainloop_tflops"] = f"{type(exc).__name__}: {exc}"
+        if world == 1 and args.cpu_budget > 0:
+            if roof is not None:
+                roof.update(power_limited_rate(shape, min(args.micro_batch_tokens or n_chunks * SEQ, n_chunks * SEQ), local_rank, value))
             api = api_leg(eng, shape, n_chunks, steps=max(3, args.steps))
             if api and "api_chunks_per_s" in api:
                 api["fraction_of_resident_rate"] = api["api_chunks_per_s"] / value

@@ -767,7 +767,16 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr;  // tuning knob
   // Small batches (a query's handful of chunks): few tiles, so the K loop's chain of memory round trips is the
   // whole kernel -- 128x128 tiles (4x the workgroups) with four LDS stages (three K-steps in flight), 1 workgroup per CU.
-  if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) return launch_cfg<EPI, 128, 128, 2, 2, 0, 4, T>(p, 256, stream);
+  if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) {
+    if constexpr (EPI == EPI_RESIDUAL) {
+      // N = 768 at ~1 000 rows is 48 tiles of 128 x 128 on 256 CUs, and a K-step there is bound by what ONE CU's LDS-DMA
+      // brings in (32 KiB per step: 1.2 us measured, profiles/r03_latency_kernel_stats.txt), not by its 0.25 us of MFMAs:
+      // 64 x 64 tiles (one wave each, 16 KiB per step) spread the same bytes over four times the CUs.
+      static const int small_res = getenv("VRAG_GEMM_SMALL_RES64") ? atoi(getenv("VRAG_GEMM_SMALL_RES64")) : 0;
+      if (small_res && (int64_t)((p.M + 127) / 128) * (p.N / 128) <= 128) return launch_cfg<EPI, 64, 64, 1, 1, 0, 4, T>(p, 1024, stream);
+    }
+    return launch_cfg<EPI, 128, 128, 2, 2, 0, 4, T>(p, 256, stream);
+  }
   static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
   if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
     static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   constexpr int A_INSTR = BM / RPI / (WM * WN); // LDS-DMA instructions per wave per stage
   constexpr int W_INSTR = BN / RPI / (WM * WN);
   static_assert(A_INSTR * RPI * WM * WN == BM && W_INSTR * RPI * WM * WN == BN, "tile rows must split over the waves");
-  static_assert(NS * STAGE_BYTES >= WM * WN * 16384, "the epilogues stage 16 KiB per wave through the operand ring");
+  static_assert(NS * STAGE_BYTES >= WM * WN * 16384 || EPI == EPI_NONE, "the epilogues stage 16 KiB per wave through the operand ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -781,6 +781,12 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
   if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
     static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
+    if constexpr (EPI == EPI_NONE) {
+      // probe (round 3): the 128 x 256 tile a software-pipelined epilogue would need (64 accumulator registers per wave, so a
+      // second set fits) -- what does the smaller tile cost the main loop?
+      static const bool t128x256 = getenv("VRAG_GEMM_TILE_128x256") != nullptr;
+      if (t128x256) return launch_cfg<EPI, 128, 256, 2, 4, 0, 2, T>(p, pgrid, stream);
+    }
     if constexpr (EPI == EPI_NONE) {
       static const int env_debug = getenv("VRAG_GEMM_DEBUG") ? atoi(getenv("VRAG_GEMM_DEBUG")) : 0;
       if (env_debug) {   // main-loop decomposition probe: results are garbage by design

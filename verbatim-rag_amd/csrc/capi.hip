@@ -490,13 +490,22 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         if (rc) return rc;
       }
       // `first`: no previous mean to shift by (c = 0)
+      // launch-bound batches: the consumer GEMM (small-row configuration) finishes the statistics itself
+      const bool consumer_stats = fold && gemm_consumer_finalizes(M);
       auto finalize_stats = [&](bool first) -> int {
+        if (consumer_stats) return VRAG_OK;
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st,
                            e->st_part + (size_t)r0 * (H / 64) * 2, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
                            e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0);
         HIP_TRY(hipGetLastError());
         return VRAG_OK;
+      };
+      auto stats_for_consumer = [&](GemmParams& g) {
+        if (!consumer_stats) return;
+        g.stats_in = e->st_part + (size_t)r0 * (H / 64) * 2;
+        g.ln_shift = e->ln_shift + r0;
+        g.fin_eps = c.norm_eps;
       };
       {
         GemmParams g{};
@@ -507,6 +516,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           g.ln_mu = e->ln_mu + r0;
           g.ln_rstd = e->ln_rstd + r0;
           g.ln_s = L.s_qkv;
+          stats_for_consumer(g);
         }
         g.M = M;
         g.N = 3 * H;
@@ -585,6 +595,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           g.ln_mu = e->ln_mu + r0;
           g.ln_rstd = e->ln_rstd + r0;
           g.ln_s = L.s_wi;
+          stats_for_consumer(g);
         }
         g.M = M;
         g.N = 2 * I;

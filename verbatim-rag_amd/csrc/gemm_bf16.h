@@ -57,6 +57,11 @@ struct GemmParams {
   // its 256-row block one after the other, keeps the row statistics in LDS and finishes them itself -- what
   // ln_stats_finalize_kernel did in a launch of its own (capi.hip): fin_mu[r] = d = mean(h - c), fin_rstd[r] =
   // 1/sqrt(E[(h-c)^2] - d^2 + eps), ln_shift[r] <- c + d, same operands in the same order (bit-identical).
+  // Consumer side of the same fusion, small-row configuration only (gemm_consumer_finalizes()): the LayerNorm-folding GEMM
+  // (EPI_QKV_ROPE / EPI_GEGLU / EPI_BF16) finishes the producer's partial statistics itself -- every wave for its own 64 rows,
+  // before its epilogue reads them -- and the wave of column 0 advances ln_shift.  One launch fewer per sub-layer where a
+  // launch costs as much as the kernel (a query's handful of chunks).
+  const float* stats_in;  // [Mpad, K/64, 2] or null (then ln_mu / ln_rstd were written by ln_stats_finalize_kernel)
   float* fin_mu;          // [Mpad] or null
   float* fin_rstd;        // [Mpad]
   float fin_eps;
@@ -78,6 +83,10 @@ int gemm_small_m_threshold(int set_to);
 // True when launch_gemm(EPI_RESIDUAL, p) will finish the LayerNorm statistics inside the GEMM (p.fin_mu set and the tile
 // geometry suits the row walk): the caller then skips its stand-alone finalize launch.
 bool gemm_residual_finalizes(const GemmParams& p);
+
+// True when a LayerNorm-folding GEMM over `rows` token rows takes the small-row configuration and therefore finishes the row
+// statistics itself when given `stats_in` (the caller then skips ln_stats_finalize_kernel).
+bool gemm_consumer_finalizes(int rows);
 
 // 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
 unsigned gemm_f16_saturated(bool reset);

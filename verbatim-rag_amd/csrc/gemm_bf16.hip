@@ -42,7 +42,7 @@ __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(uns
 
 // Epilogue shared by the GEMM kernels. `acc[nj][rt]` are this wave's accumulators (swapped layout:
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
-template <int EPI, int RT, int WROWS, typename T>
+template <int EPI, int RT, int WROWS, typename T, bool SMALL = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* smem, int wave, int lane,
                                               int mw, int nw, bool v_block, int m0 = 0, char* stats_lds = nullptr) {
   typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
@@ -57,6 +57,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   // global store/RMW instruction covers whole 128/256-byte row segments (full cache lines)
   // instead of 16 scattered 16-byte pieces.
   char* stg = smem + wave * 16384;
+
+  if constexpr (SMALL && (EPI == EPI_QKV_ROPE || EPI == EPI_GEGLU || EPI == EPI_BF16)) {
+    // Small-row configuration: finish the producer's row statistics here instead of in a launch of their own
+    // (ln_stats_finalize_kernel's arithmetic, partials in the same fixed order -> the same bits).  Lane L takes row mw + L of
+    // the wave's 64; the values go through ln_mu / ln_rstd in global memory (every wave that covers these rows writes the
+    // same numbers) and are read back by this wave below: same CU, same L1, ordered by the vmcnt wait.
+    static_assert(WROWS == 64, "one row per lane");
+    if (p.stats_in) {
+      const int row = mw + lane, np = p.K >> 6;
+      const float* part = p.stats_in + (size_t)row * np * 2;
+      float s1 = 0.f, s2 = 0.f;
+      for (int i = 0; i < np; ++i) {
+        s1 += part[2 * i];
+        s2 += part[2 * i + 1];
+      }
+      const float d = s1 / (float)p.K;
+      const float var = fmaxf(s2 / (float)p.K - d * d, 0.f);
+      const_cast<float*>(p.ln_mu)[row] = d;
+      const_cast<float*>(p.ln_rstd)[row] = 1.0f / sqrtf(var + p.fin_eps);
+      if (nw == 0) const_cast<float*>(p.ln_shift)[row] = p.ln_shift[row] + d;   // exactly one wave per row sits on column 0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
 
   // 16-bit tile [R rows][C cols] (C = 64 or 32): lane writes 4 consecutive columns of its row.
   auto put_bf16 = [&](int row, int col, const V4& v, int row_bytes) {
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<EPI, RT, WROWS, T>(p, acc, smem, wave, lane, mw, nw, v_block, m0, stats_lds);
+  gemm_epilogue<EPI, RT, WROWS, T, (NS == 4 && BM == 128 && BN == 128)>(p, acc, smem, wave, lane, mw, nw, v_block, m0, stats_lds);
   __syncthreads();  // staging area is reused as operand slots by the next tile
   if constexpr (EPI == EPI_RESIDUAL) {
     if (p.row_walk && nt == sub - 1) {
@@ -819,6 +842,11 @@ hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
   if (p.M <= 0) return hipSuccess;
   if (p.N % 128 != 0 || p.K % BK != 0) return hipErrorInvalidValue;
   return p.op_dtype == kOpF16 ? launch_typed<f16_t>(epi, p, stream) : launch_typed<bf16_t>(epi, p, stream);
+}
+
+bool gemm_consumer_finalizes(int rows) {
+  static const bool off = getenv("VRAG_GEMM_NO_CONSUMER_STATS") != nullptr;   // A/B knob
+  return !off && rows > 0 && rows <= gemm_small_m_threshold(-1);               // launch_t's choice of the 128 x 128, NS = 4 configuration
 }
 
 bool gemm_residual_finalizes(const GemmParams& p) {

@@ -43,8 +43,23 @@ for tag, env in (("v1", {}), ("v2", {"VRAG_ATTN_V2": "1"})):
     path = f"/tmp/attn_{tag}.json"
     subprocess.run([sys.executable, os.path.abspath(__file__), "child", path], check=True, env={**os.environ, **env})
     res[tag] = {k: np.asarray(v, np.float32) for k, v in json.load(open(path)).items()}
+tiny = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
+            pad_token_id=0, cls_token_id=1, sep_token_id=2)
+ocfg = O.EncoderConfig(**tiny)
+ow = O.random_weights(ocfg, seed=7)
+oracle = {}
+for ci, lens in enumerate(CASES):
+    rng = np.random.default_rng(ci)
+    seqs = [rng.integers(3, 512, size=n).astype(np.int32) for n in lens]
+    per = [O.encoder_forward(ocfg, ow, s_, return_all=True)[1] for s_ in seqs]
+    for nl in (1, 2):
+        oracle[f"{ci}_{nl}"] = np.concatenate([hs[nl] for hs in per])
 for key in res["v1"]:
     a, b = res["v1"][key], res["v2"][key]
+    ref = oracle[key]
+    ea, eb = np.abs(a - ref).max(axis=1), np.abs(b - ref).max(axis=1)
+    print(f"   vs oracle: v1 max {ea.max():.3e} (row {int(ea.argmax())}), v2 max {eb.max():.3e} (row {int(eb.argmax())}); "
+          f"v2 rows over 3x v1's max: {np.nonzero(eb > 3 * ea.max())[0].tolist()[:24]}")
     d = np.abs(a - b).max(axis=1)
     worst = np.argsort(-d)[:8]
     print(f"case {key} lens={CASES[int(key.split('_')[0])]} layers={key.split('_')[1]}: max |v1 - v2| = {d.max():.3e} at rows {worst.tolist()} "

@@ -39,8 +39,11 @@ import numpy as np  # noqa: E402
 from oracle import modernbert_np as O  # noqa: E402
 
 res = {}
-for tag, env in (("v1", {}), ("v2", {"VRAG_ATTN_V2": "1"})):
-    path = f"/tmp/attn_{tag}.json"
+VARIANTS = {"v2": {"VRAG_ATTN_V2": "1"}, "v2 lazy=0": {"VRAG_ATTN_V2": "1", "VRAG_ATTN_V2_LAZY": "0"},
+            "v2 no seed": {"VRAG_ATTN_V2": "1", "VRAG_ATTN_V2_NOSEED": "1"},
+            "v2 lazy=0 no seed": {"VRAG_ATTN_V2": "1", "VRAG_ATTN_V2_LAZY": "0", "VRAG_ATTN_V2_NOSEED": "1"}}
+for tag, env in (("v1", {}), *VARIANTS.items()):
+    path = f"/tmp/attn_{tag.replace(' ', '_').replace('=', '')}.json"
     subprocess.run([sys.executable, os.path.abspath(__file__), "child", path], check=True, env={**os.environ, **env})
     res[tag] = {k: np.asarray(v, np.float32) for k, v in json.load(open(path)).items()}
 tiny = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
@@ -64,3 +67,8 @@ for key in res["v1"]:
     worst = np.argsort(-d)[:8]
     print(f"case {key} lens={CASES[int(key.split('_')[0])]} layers={key.split('_')[1]}: max |v1 - v2| = {d.max():.3e} at rows {worst.tolist()} "
           f"({(d > 0.1 * d.max()).sum()} rows above a tenth of it); |hidden| ~ {np.abs(a).mean():.3f}")
+
+for tag in VARIANTS:
+    worst = {key: float(np.abs(res[tag][key] - oracle[key]).max()) for key in res[tag] if key.endswith("_2")}
+    print(f"{tag:20s} two layers, max |hidden - oracle| per case: " + " ".join(f"{v:.2e}" for v in worst.values()))
+print(f"{'v1':20s} two layers, max |hidden - oracle| per case: " + " ".join(f"{float(np.abs(res['v1'][k] - oracle[k]).max()):.2e}" for k in res["v1"] if k.endswith("_2")))

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnParams p) {
       f32x4 st[2][4];
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
-        const float seed = -m_run[2 * u + cc];
+        const float seed = p.v2_noseed ? 0.f : -m_run[2 * u + cc];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) st[cc][kt] = f32x4{seed, seed, seed, seed};
       }
@@ -451,6 +451,14 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnParams p) {
           st[cc][kt] = Op<T>::mfma16(k0, qf[2 * u + cc][0], st[cc][kt]);
           st[cc][kt] = Op<T>::mfma16(k1, qf[2 * u + cc][1], st[cc][kt]);
         }
+      }
+      if (p.v2_noseed) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[cc][kt][r] -= m_run[2 * u + cc];
       }
       // masks and in-lane maxima (scores are relative to m_run already)
       float mx[2];
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnParams p) {
       // move the reference?  (wave-uniform; steady state: no)
       bool move = false;
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) move = move || mx[cc] > ATT_LAZY || (!seen[2 * u + cc] && mx[cc] > -INFINITY);
+      for (int cc = 0; cc < 2; ++cc) move = move || mx[cc] > p.v2_lazy || (!seen[2 * u + cc] && mx[cc] > -INFINITY);
       if (__any(move)) {
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -591,6 +599,12 @@ hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream)
   // sit 3.5e-3 from the oracle where the first kernel's sit 3e-4 (cause not found yet): work in progress, NEXT.md.
   static const bool v2 = getenv("VRAG_ATTN_V2") != nullptr;
   if (v2) {
+    static const float lazy = getenv("VRAG_ATTN_V2_LAZY") ? (float)atof(getenv("VRAG_ATTN_V2_LAZY")) : ATT_LAZY;
+    static const int noseed = getenv("VRAG_ATTN_V2_NOSEED") ? 1 : 0;
+    AttnParams pv = p;
+    pv.v2_lazy = lazy;
+    pv.v2_noseed = noseed;
+    const AttnParams& p = pv;
     if (p.op_dtype == kOpF16) {
       if (local) hipLaunchKernelGGL((attn2_fwd_kernel<true, f16_t>), grid, dim3(256), 0, stream, p);
       else hipLaunchKernelGGL((attn2_fwd_kernel<false, f16_t>), grid, dim3(256), 0, stream, p);

@@ -258,6 +258,10 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
  * the banded kernel with |i - j| <= window. */
 int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t device,
                        float* ms_out);
+/* Unit-test hook of the attention kernels alone: host operands in the kernels' layouts (q, k: [T, H] bf16 / fp16 bits, q
+ * pre-scaled by head_dim^-1/2 * log2 e; vt: [H, Tp], Tp = T rounded up to 256), o [T, H] out; T = n_seqs * S. */
+int vrag_debug_attn_run(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t f16, const uint16_t* q,
+                        const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t device);
 int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/,
                               int64_t* launches /*[VRAG_PROF_COUNT]*/, int32_t reset);
 

@@ -109,6 +109,8 @@ SIGNATURES = {
     "vrag_encoder_read_profile": (C.c_int, [_H, _FP, _LP, C.c_int32]),
     "vrag_debug_set_gemm_small_m": (C.c_int, [C.c_int32]),
     "vrag_debug_gemm_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "vrag_debug_attn_run": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int32]),
     "vrag_debug_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
     "vrag_dense_index_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_H)]),
     "vrag_dense_index_destroy": (None, [_H]),

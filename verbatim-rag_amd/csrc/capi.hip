@@ -2007,6 +2007,75 @@ int vrag_encoder_f16_saturated(vrag_encoder* e, int32_t reset, int32_t* saturate
   return VRAG_OK;
 }
 
+// Diagnostics / unit tests of the attention kernels alone: n_seqs sequences of S tokens, host operands in the kernels' own
+// layouts (q, k: [T, H] operand-type bits; vt: [H, Tp] with Tp = T rounded up to 256), output o [T, H] operand-type bits.
+int vrag_debug_attn_run(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t f16, const uint16_t* q,
+                        const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t device) {
+  ARG_CHECK(q && k && vt && o && n_seqs > 0 && S > 0 && S % kSeqAlign == 0 && H % 64 == 0, "bad arguments");
+  if (vrag_device_count() <= device) {
+    set_error("no HIP device %d visible", device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  const size_t T = (size_t)n_seqs * S, Tp = (size_t)align_up((int)T, kRowPad);
+  const int qb = attention_q_block(local != 0);
+  std::vector<int> bs, bl, bq;
+  for (int s = 0; s < n_seqs; ++s)
+    for (int q0 = 0; q0 < S; q0 += qb) {
+      bs.push_back(s * S);
+      bl.push_back(S);
+      bq.push_back(q0);
+    }
+  void *dq = nullptr, *dk = nullptr, *dv = nullptr, *dout = nullptr;
+  int *d_bs = nullptr, *d_bl = nullptr, *d_bq = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {dq, dk, dv, dout, (void*)d_bs, (void*)d_bl, (void*)d_bq})
+      if (p) (void)hipFree(p);
+  };
+  hipError_t e = hipMalloc(&dq, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&dk, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&dv, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&dout, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bs, bs.size() * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bl, bs.size() * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_bq, bs.size() * 4);
+  if (e == hipSuccess) e = hipMemset(dq, 0, Tp * H * 2);
+  if (e == hipSuccess) e = hipMemset(dk, 0, Tp * H * 2);
+  if (e == hipSuccess) e = hipMemset(dout, 0, Tp * H * 2);
+  if (e == hipSuccess) e = hipMemcpy(dq, q, T * H * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dk, k, T * H * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv, vt, (size_t)H * Tp * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_bs, bs.data(), bs.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_bl, bl.data(), bs.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_bq, bq.data(), bs.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) {
+    AttnParams ap{};
+    ap.q = (const bf16_t*)dq;
+    ap.k = (const bf16_t*)dk;
+    ap.vt = (const bf16_t*)dv;
+    ap.o = (bf16_t*)dout;
+    ap.blk_seq_start = d_bs;
+    ap.blk_seq_len = d_bl;
+    ap.blk_q0 = d_bq;
+    ap.n_blocks = (int)bs.size();
+    ap.H = H;
+    ap.nh = H / 64;
+    ap.Tp = (int)Tp;
+    ap.window = window;
+    ap.op_dtype = f16 ? kOpF16 : kOpBf16;
+    e = launch_attention(ap, local != 0, 0);
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(o, dout, T * H * 2, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) {
+    set_error("debug attention run failed: %s", hipGetErrorString(e));
+    return VRAG_ERR_HIP;
+  }
+  return VRAG_OK;
+}
+
 int vrag_encoder_set_concurrency(vrag_encoder* e, int32_t n_streams) {
   ARG_CHECK(e && n_streams >= 1 && n_streams <= 4, "n_streams must be in [1, 4]");
   std::lock_guard<std::recursive_mutex> lk(e->mu);

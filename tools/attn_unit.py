@@ -53,13 +53,14 @@ def run(local, n_seqs, S, H=128, W=64, seed=0, sharp=1.0):
     return err
 
 
-tag = "v2" if os.environ.get("VRAG_ATTN_V2") else "v1"
-for local in (0, 1):
-    for S in (64, 200, 512, 1000):
-        for sharp in (1.0, 6.0):
-            err = run(local, 2, S, seed=S + local, sharp=sharp)
-            line = f"{tag} {'banded' if local else 'global'} S={S:4d} sharp={sharp}: max {err.max():.2e} mean {err.mean():.2e}"
-            if local:
-                per = np.asarray([err[i::32].mean() for i in range(32)])
-                line += "  mean by row%32: " + " ".join(f"{x * 1e3:.1f}" for x in per) + " (x1e-3)"
-            print(line, flush=True)
+if __name__ == "__main__":
+    tag = "v2" if os.environ.get("VRAG_ATTN_V2") else "v1"
+    for local in (0, 1):
+        for S in (64, 200, 512, 1000):
+            for sharp in (1.0, 6.0):
+                err = run(local, 2, S, seed=S + local, sharp=sharp)
+                line = f"{tag} {'banded' if local else 'global'} S={S:4d} sharp={sharp}: max {err.max():.2e} mean {err.mean():.2e}"
+                if local:
+                    per = np.asarray([err[i::32].mean() for i in range(32)])
+                    line += "  mean by row%32: " + " ".join(f"{x * 1e3:.1f}" for x in per) + " (x1e-3)"
+                print(line, flush=True)

@@ -297,22 +297,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnParams p
 //   * the running maximum is LAZY: the S^T accumulators are seeded with -m_run (the MFMA's C operand), so scores arrive
 //     relative to the reference already and p = exp2(s) needs no subtraction; the reference is only moved when some
 //     score exceeds it by more than 2^8 (or a row meets its first visible key) -- a wave-uniform, rare branch that pays
-//     the cross-lane exchange (v_permlane16/32_swap, no LDS trip), the subtraction and the O rescale.  Softmax is
+//     the cross-lane exchange, the subtraction and the O rescale.  Softmax is
 //     invariant to the reference; p <= 256 is exact enough in bf16 / far inside fp16's range;
 //   * row sums come from the matrix pipe: one extra MFMA per 32 keys with an all-ones A operand accumulates
 //     l[q] = sum_k bf16(p) -- the very operands the P.V product sums, so numerator and denominator stay consistent;
 //   * the in-lane maximum uses v_max3.
 // -> per score: 1/2 (max3) + 1 (exp2, ~2 slots) + 1/2 (packed convert) issue slots instead of ~5.5.
-__device__ __forceinline__ float xor16_max(float v) {
-  const unsigned a = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);   // each lane ends up with its own and its lane^16 partner's value
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-__device__ __forceinline__ float xor32_max(float v) {
-  const unsigned a = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
+// Cross-lane maxima over the four lane groups of a query (lanes l, l^16, l^32, l^48).  They run only when the reference moves
+// (rare), so they take the plain LDS-crossbar shuffle: the v_permlane16/32_swap forms tried first returned the even row's /
+// lower half's value instead of the maximum here (tools/probes/permlane_probe.hip) and broke the banded layers whenever a lane
+// group had no visible key in a row's first tile.
+__device__ __forceinline__ float xor16_max(float v) { return fmaxf(v, __shfl_xor(v, 16, 64)); }
+__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // one v_max3_f32
 
 constexpr float ATT_LAZY = 8.0f;   // log2 units: the reference moves when a score exceeds it by more than 2^8
@@ -593,10 +589,10 @@ int attention_q_block(bool local) { return local ? ATT_QB_LOCAL : ATT_QB_GLOBAL;
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream) {
   if (p.n_blocks <= 0) return hipSuccess;
   dim3 grid(p.n_blocks, p.nh);
-  // The second-generation kernel is opt-in (VRAG_ATTN_V2=1): measured slower than the first one in its first form
-  // (r3c session: global 202 vs 177 us, banded 124 vs 115 us per 65 536-token launch -- 45 % fewer VALU slots per score
-  // but 12 % more MFMA issue and 1.5x the LDS fragment reads; the kernel is stall-bound, not VALU-bound) and its logits
-  // sit 3.5e-3 from the oracle where the first kernel's sit 3e-4 (cause not found yet): work in progress, NEXT.md.
+  // The second-generation kernel is opt-in (VRAG_ATTN_V2=1): measured slower than the first one (global 191-202 vs 177 us,
+  // banded 118-124 vs 115 us per 65 536-token launch -- 45 % fewer VALU slots per score but 12 % more MFMA issue and 1.5x
+  // the LDS fragment reads; the kernel is stall-bound, not VALU-bound).  Its accuracy equals the first kernel's since the
+  // cross-lane maxima use the plain shuffle (tests/test_attention_unit_gpu.py checks both kernels against a float64 softmax).
   static const bool v2 = getenv("VRAG_ATTN_V2") != nullptr;
   if (v2) {
     static const float lazy = getenv("VRAG_ATTN_V2_LAZY") ? (float)atof(getenv("VRAG_ATTN_V2_LAZY")) : ATT_LAZY;

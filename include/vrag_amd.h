@@ -258,6 +258,10 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
  * the banded kernel with |i - j| <= window. */
 int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t device,
                        float* ms_out);
+/* Same for the fused Wqkv + RoPE + attention kernel (csrc/qkv_attn.hip; S <= 512).  flags: 1 = no attention phase, 2 = no
+ * main-loop MFMAs, 4 = no operand DMA (phase decomposition of the kernel's time). */
+int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t flags,
+                           int32_t device, float* ms_out);
 /* Unit-test hook of the attention kernels alone: host operands in the kernels' layouts (q, k: [T, H] bf16 / fp16 bits, q
  * pre-scaled by head_dim^-1/2 * log2 e; vt: [H, Tp], Tp = T rounded up to 256), o [T, H] out; T = n_seqs * S. */
 int vrag_debug_attn_run(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t f16, const uint16_t* q,

@@ -112,6 +112,7 @@ SIGNATURES = {
     "vrag_debug_attn_run": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32]),
     "vrag_debug_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "vrag_debug_qkv_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
     "vrag_dense_index_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_H)]),
     "vrag_dense_index_destroy": (None, [_H]),
     "vrag_dense_index_size": (C.c_int64, [_H]),

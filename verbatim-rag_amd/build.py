@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libvrag_amd.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "norm_heads.hip", "topk.hip", "text.hip", "capi.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "qkv_attn.hip", "norm_heads.hip", "topk.hip", "text.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 FLAGS += os.environ.get("VRAG_HIPCC_FLAGS", "").split()  # tuning experiments only
 

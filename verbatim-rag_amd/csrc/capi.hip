@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "qkv_attn.h"
 
 #include <array>
 #include <map>
@@ -174,6 +175,9 @@ struct Layer {
   // LayerNorm gains are folded into wqkv (attn_norm, layers > 0) and wi (mlp_norm); s_* = row sums
   float* s_qkv = nullptr;
   float* s_wi = nullptr;
+  // the same Wqkv rows grouped per head, q(64) k(64) v(64), for the fused QKV + attention kernel (qkv_attn.hip)
+  bf16_t* wqkv_h = nullptr;
+  float* s_qkv_h = nullptr;
 };
 
 // BERT-family layer (post-LN, biased linears, GELU MLP): TF:models/bert/modeling_bert.py:282-286,340-344,
@@ -191,6 +195,8 @@ struct MicroBatch {
   int row0, row1;  // multiples of kRowPad (256): GEMM tiles never straddle micro-batches
   int blk0, blk1;    // global-layer q-block range
   int lblk0, lblk1;  // banded-layer q-block range
+  int seq0 = 0, seq1 = 0;   // sequences of the micro-batch
+  int max_len = 0;          // longest of them
 };
 
 struct ProfRec {
@@ -210,6 +216,7 @@ struct vrag_encoder {
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   int n_streams = 1;
   bool ln_fold = true;   // LayerNorm folded into the producer/consumer GEMM epilogues (VRAG_LN_FOLD=0: separate LN kernels)
+  int fused_qkv_attn = 0;   // Wqkv GEMM + RoPE + attention in one kernel per (sequence, head) when every sequence of the micro-batch has <= 512 tokens (VRAG_FUSED_QKV_ATTN)
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
 
@@ -293,7 +300,7 @@ struct vrag_encoder {
     int seen = 0;
     uint64_t last_use = 0;
   };
-  std::map<std::array<int, 5>, GraphEntry> graphs;
+  std::map<std::array<int, 6>, GraphEntry> graphs;
   uint64_t graph_clock = 0;
   int graph_rows_max = 8192;   // 0 disables (VRAG_GRAPHS=0); batches above it are throughput-bound, not launch-bound
   int64_t graph_replays = 0;
@@ -492,8 +499,11 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       // `first`: no previous mean to shift by (c = 0)
       // launch-bound batches: the consumer GEMM (small-row configuration) finishes the statistics itself
       const bool consumer_stats = fold && gemm_consumer_finalizes(M);
-      auto finalize_stats = [&](bool first) -> int {
-        if (consumer_stats) return VRAG_OK;
+      // sequences of <= 512 tokens, throughput-sized micro-batch: one kernel per (sequence, head) instead of the QKV GEMM and the
+      // attention launch -- Q, K and V^T never leave the CU (qkv_attn.hip)
+      const bool fused_attn = e->fused_qkv_attn && L.wqkv_h && mb.max_len <= kFusedMaxSeq && (!consumer_stats || e->fused_qkv_attn == 2);
+      auto finalize_stats = [&](bool first, bool for_qkv = false) -> int {
+        if (consumer_stats && !(for_qkv && fused_attn)) return VRAG_OK;
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st,
                            e->st_part + (size_t)r0 * (H / 64) * 2, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
@@ -507,6 +517,32 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.ln_shift = e->ln_shift + r0;
         g.fin_eps = c.norm_eps;
       };
+      if (fused_attn) {
+        QkvAttnParams f{};
+        f.op_dtype = e->op_dtype;
+        f.x = e->a;
+        f.w = L.wqkv_h;
+        if (fold && l > 0) {
+          f.ln_mu = e->ln_mu;
+          f.ln_rstd = e->ln_rstd;
+          f.ln_s = L.s_qkv_h;
+        }
+        f.rope_cos = global ? e->cos_g : e->cos_l;
+        f.rope_sin = global ? e->sin_g : e->sin_l;
+        f.o = e->o;
+        f.seq_row = e->d_seq_meta + mb.seq0;
+        f.seq_len = e->d_seq_meta + 2 * c.max_seqs + mb.seq0;
+        f.n_seqs = mb.seq1 - mb.seq0;
+        f.H = H;
+        f.nh = c.num_heads;
+        f.Tp = Tp;
+        f.window = c.sliding_window;
+        f.q_scale = 0.125f * 1.4426950408889634f;
+        static const int fused_dbg = getenv("VRAG_FUSED_DEBUG") ? atoi(getenv("VRAG_FUSED_DEBUG")) : 0;
+        f.debug_flags = fused_dbg;
+        ProfScope ps(e, VRAG_PROF_GEMM_QKV, st);
+        HIP_TRY(launch_qkv_attention(f, !global, st));
+      } else {
       {
         GemmParams g{};
         g.op_dtype = e->op_dtype;
@@ -550,6 +586,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         ap.window = c.sliding_window;
         ProfScope ps(e, global ? VRAG_PROF_ATTN_GLOBAL : VRAG_PROF_ATTN_LOCAL, st);
         HIP_TRY(launch_attention(ap, !global, st));
+      }
       }
       {
         GemmParams g{};
@@ -628,7 +665,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
         }
         if (fold && l + 1 < c.num_layers && !fused_stats) {
-          int rc = finalize_stats(false);
+          int rc = finalize_stats(false, true);
           if (rc) return rc;
         }
       }
@@ -977,6 +1014,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   TRY(init_streams(e));
 
   if (const char* lf = getenv("VRAG_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
+  if (const char* fq = getenv("VRAG_FUSED_QKV_ATTN")) e->fused_qkv_attn = cfg->hidden_size == cfg->num_heads * 64 ? atoi(fq) : 0;   // 2: launch-bound batches too
 
   // ---- weights
   const int Ip = (int)align_up(I, 128);
@@ -997,6 +1035,11 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
     const bool fold = e->ln_fold;
     TRY(upload_bf16(e, &ly.wqkv, w->wqkv[l], 3 * H, H, 3 * H, 0, stage, stage_elems,
                     fold && l > 0 ? ly.attn_norm : nullptr, fold && l > 0 ? &ly.s_qkv : nullptr));
+    if (e->fused_qkv_attn) {
+      TRY(dev_alloc(e, &ly.wqkv_h, (size_t)3 * H * H, false));
+      if (ly.s_qkv) TRY(dev_alloc(e, &ly.s_qkv_h, (size_t)3 * H, false));
+      HIP_TRY(permute_qkv_heads(ly.wqkv, ly.s_qkv, H, cfg->num_heads, ly.wqkv_h, ly.s_qkv_h, nullptr));
+    }
     TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
     TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * Ip, I, stage, stage_elems, fold ? ly.mlp_norm : nullptr,
                     fold ? &ly.s_wi : nullptr));
@@ -1388,7 +1431,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   // multiple of kRowPad), micro-batch cuts, q-block descriptors -- plus ONE pass over the ids that copies them into the
   // pinned staging and range-checks them.  The per-row image (ids in their rows, positions, sequence index, pad rows) is
   // laid out on the device by pack_layout_kernel.
-  int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_lblk0 = 0, nlblk = 0, mb_tokens = 0;
+  int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_lblk0 = 0, nlblk = 0, mb_tokens = 0, mb_seq0 = 0, mb_max_len = 0;
   size_t src = 0;
   const int prev_rows = e->rows;
   int *seq_row = e->h_seq_meta, *seq_src = e->h_seq_meta + c.max_seqs, *seq_ln = e->h_seq_meta + 2 * c.max_seqs;
@@ -1397,7 +1440,9 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     t = (int)align_up(t, kSeqAlign);
     if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
       const int row1 = (int)align_up(t, kRowPad);
-      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk});
+      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, s, mb_max_len});
+      mb_seq0 = s;
+      mb_max_len = 0;
       t = row1;
       mb_row0 = row1;
       mb_blk0 = nblk;
@@ -1427,6 +1472,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     src += Ls;
     t += Ls;
     mb_tokens += Ls;
+    mb_max_len = std::max(mb_max_len, Ls);
   }
   const int rows = (int)align_up(t, kRowPad);
   if (rows > e->cap_rows || nblk > e->cap_blocks || nlblk > e->cap_blocks) {
@@ -1451,7 +1497,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   }
   // rows up to max(rows, previous rows) get pad ids so stale tokens of an older batch vanish
   const int fill_to = std::min(e->cap_rows, std::max(rows, prev_rows));
-  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk});
+  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, n_seqs, mb_max_len});
   e->n_seqs = n_seqs;
   e->n_tokens = (int)total;
   e->rows = rows;
@@ -1479,7 +1525,7 @@ static int run_layers_maybe_graphed(vrag_encoder* e, int n_layers, hipStream_t s
                         st != nullptr && n_layers > 0;
   if (!eligible) return eager();
   const MicroBatch& mb = e->mbs[0];
-  const std::array<int, 5> key = {e->rows, mb.blk1 - mb.blk0, mb.lblk1 - mb.lblk0, n_layers, e->types_loaded ? 1 : 0};
+  const std::array<int, 6> key = {e->rows, mb.blk1 - mb.blk0, mb.lblk1 - mb.lblk0, n_layers, e->types_loaded ? 1 : 0, mb.seq1 - mb.seq0};
   auto& g = e->graphs[key];
   g.last_use = ++e->graph_clock;
   if (g.exec) {
@@ -1994,6 +2040,98 @@ int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int3
   return VRAG_OK;
 }
 
+int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t flags,
+                           int32_t device, float* ms_out) {
+  ARG_CHECK(ms_out && n_seqs > 0 && S > 0 && S <= kFusedMaxSeq && S % kSeqAlign == 0 && H % 64 == 0 && iters > 0, "bad arguments");
+  if (vrag_device_count() <= device) {
+    set_error("no HIP device %d visible", device);
+    return VRAG_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  const size_t T = (size_t)n_seqs * S, Tp = (size_t)align_up((int)T, kRowPad);
+  const int nh = H / 64;
+  std::vector<int> row(n_seqs), len(n_seqs, S);
+  for (int s = 0; s < n_seqs; ++s) row[s] = s * S;
+  void *x = nullptr, *w = nullptr, *o = nullptr;
+  float *mu = nullptr, *rstd = nullptr, *lns = nullptr, *cs = nullptr;
+  int *d_row = nullptr, *d_len = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {x, w, o, (void*)mu, (void*)rstd, (void*)lns, (void*)cs, (void*)d_row, (void*)d_len})
+      if (p) (void)hipFree(p);
+  };
+  hipError_t e = hipMalloc(&x, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&w, (size_t)3 * H * H * 2);
+  if (e == hipSuccess) e = hipMalloc(&o, Tp * H * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&mu, Tp * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&rstd, Tp * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&lns, (size_t)3 * H * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&cs, (size_t)kFusedMaxSeq * 32 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_row, n_seqs * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_len, n_seqs * 4);
+  if (e != hipSuccess) {
+    cleanup();
+    set_error("debug allocation failed: %s", hipGetErrorString(e));
+    return VRAG_ERR_HIP;
+  }
+  {
+    std::vector<unsigned short> h(std::max(Tp * H, (size_t)3 * H * H));
+    unsigned xs = 777u;
+    for (auto& v : h) {   // pseudo-random bf16 in about [-1, 1), as vrag_debug_gemm_ms
+      xs = xs * 1664525u + 1013904223u;
+      v = (unsigned short)(((xs >> 31) << 15) | (0x3e80u + (((xs >> 20) & 1) << 7)) | ((xs >> 9) & 0x7f));
+    }
+    (void)hipMemcpy(x, h.data(), Tp * H * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(w, h.data(), (size_t)3 * H * H * 2, hipMemcpyHostToDevice);
+    std::vector<float> f(std::max(Tp, (size_t)kFusedMaxSeq * 32), 0.05f);
+    (void)hipMemcpy(mu, f.data(), Tp * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(rstd, f.data(), Tp * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(lns, f.data(), (size_t)3 * H * 4, hipMemcpyHostToDevice);
+    std::fill(f.begin(), f.end(), 0.7071f);
+    (void)hipMemcpy(cs, f.data(), (size_t)kFusedMaxSeq * 32 * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_row, row.data(), n_seqs * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_len, len.data(), n_seqs * 4, hipMemcpyHostToDevice);
+  }
+  QkvAttnParams f{};
+  f.x = (const bf16_t*)x;
+  f.w = (const bf16_t*)w;
+  f.ln_mu = mu;
+  f.ln_rstd = rstd;
+  f.ln_s = lns;
+  f.rope_cos = cs;
+  f.rope_sin = cs;
+  f.o = (bf16_t*)o;
+  f.seq_row = d_row;
+  f.seq_len = d_len;
+  f.n_seqs = n_seqs;
+  f.H = H;
+  f.nh = nh;
+  f.Tp = (int)Tp;
+  f.window = window;
+  f.op_dtype = getenv("VRAG_DEBUG_GEMM_F16") ? kOpF16 : kOpBf16;
+  f.q_scale = 0.125f * 1.4426950408889634f;
+  f.debug_flags = flags;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  hipError_t le = hipSuccess;
+  for (int i = 0; i < 3 && le == hipSuccess; ++i) le = launch_qkv_attention(f, local != 0, 0);
+  (void)hipEventRecord(a, 0);
+  for (int i = 0; i < iters && le == hipSuccess; ++i) le = launch_qkv_attention(f, local != 0, 0);
+  (void)hipEventRecord(b, 0);
+  hipError_t se = hipEventSynchronize(b);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  cleanup();
+  if (le != hipSuccess || se != hipSuccess) {
+    set_error("debug fused attention failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+    return VRAG_ERR_HIP;
+  }
+  *ms_out = ms / iters;
+  return VRAG_OK;
+}
+
 int vrag_encoder_f16_saturated(vrag_encoder* e, int32_t reset, int32_t* saturated) {
   ARG_CHECK(e && saturated, "null argument");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
@@ -2002,6 +2140,7 @@ int vrag_encoder_f16_saturated(vrag_encoder* e, int32_t reset, int32_t* saturate
   unsigned any = f16_sat_take(reset != 0);                 // conversions in this file (weight packing)
   any |= gemm_f16_saturated(reset != 0);
   any |= attention_f16_saturated(reset != 0);
+  any |= qkv_attn_f16_saturated(reset != 0);
   any |= norm_heads_f16_saturated(reset != 0);
   *saturated = any ? 1 : 0;
   return VRAG_OK;

@@ -1,0 +1,35 @@
+// Wqkv GEMM + RoPE + attention in ONE kernel per (sequence, head), for sequences of at most 512 tokens (gfx950).
+#pragma once
+#include "common.h"
+
+namespace vrag {
+
+constexpr int kFusedMaxSeq = 512;   // tokens one workgroup holds: 8 waves x 64 rows
+
+struct QkvAttnParams {
+  const bf16_t* x;         // [Tp, H] the Wqkv GEMM's A operand rows (op16(h - c) under the LayerNorm fold, else LN(h))
+  const bf16_t* w;         // [nh][192][H] per-head weight rows: q(64) k(64) v(64) (permute_qkv_heads), LayerNorm gain folded in
+  const float* ln_mu;      // [Tp] or null (no fold): see GemmParams
+  const float* ln_rstd;    // [Tp]
+  const float* ln_s;       // [nh * 192] row sums of w, same permutation
+  const float* rope_cos;   // [max_pos, 32]
+  const float* rope_sin;
+  bf16_t* o;               // [Tp, H] attention output (the Wo GEMM's A operand)
+  const int* seq_row;      // [n_seqs] first packed row of every sequence
+  const int* seq_len;      // [n_seqs] tokens (<= kFusedMaxSeq)
+  int n_seqs;
+  int H, nh, Tp;
+  int window;              // banded layers: keep |i - j| <= window
+  int op_dtype;
+  float q_scale;           // head_dim^-1/2 * log2(e): the softmax runs in exp2 units
+  int debug_flags;         // tuning probe (vrag_debug_qkv_attn_ms): 1 = no attention phase, 2 = no main-loop MFMAs, 4 = no operand DMA
+};
+
+hipError_t launch_qkv_attention(const QkvAttnParams& p, bool local, hipStream_t stream);
+
+// out[(h * 3 + part) * 64 + d][:] = w[part * H + h * 64 + d][:]  (and the same for the optional row-sum / bias vectors)
+hipError_t permute_qkv_heads(const bf16_t* w, const float* s, int H, int nh, bf16_t* w_out, float* s_out, hipStream_t stream);
+
+unsigned qkv_attn_f16_saturated(bool reset);
+
+}  // namespace vrag

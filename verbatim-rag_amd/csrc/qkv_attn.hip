@@ -1,0 +1,512 @@
+// Wqkv GEMM + RoPE + attention fused per (sequence, head) for gfx950 -- ModernBertAttention.forward
+// (transformers modeling_modernbert.py:271 Wqkv, :188-219 rotary, :166-185 eager attention, mask masking_utils.py:141-151)
+// without the round trip of Q, K and V^T through HBM.
+//
+// Unfused, a 65 536-token micro-batch writes 300 MB of Q / K / V^T per layer (the QKV GEMM's epilogue: 95 of its 268 us) and
+// attention reads them back; that is 26 of the step's 101 GB.  Here one workgroup (8 waves) owns one
+// sequence of <= 512 tokens and one head:
+//   1. main loop: C^T[192 features][512 tokens] = W_head[192, H] . X_seq[512, H]^T with v_mfma_f32_16x16x32, wave w owns
+//      tokens 64 w .. 64 w + 63 and ALL 192 features (192 accumulator registers).  Operands by 16-byte LDS-DMA in 64-k
+//      stages of 128-byte rows (16-byte chunk index XOR-swizzled by (row >> 1) & 7, as in gemm_bf16.hip): the weight rows
+//      double-buffered and shared (one raw barrier per stage), the token rows in a buffer private to their wave.
+//      q and k products are issued "swapped" (lane = token, registers = 4 consecutive features), v
+//      un-swapped (lane = feature, registers = 4 consecutive tokens) -- the layouts the attention operands want.
+//   2. epilogue in registers: LayerNorm fold, RoPE (the (d, d + 32) partners sit in the same lane), q scaled by
+//      head_dim^-1/2 log2 e.  K rows and V^T rows go to LDS (64 KiB each, over the operand ring), Q stays in registers as
+//      the B operand of S^T = K . Q^T.  The k-slot <-> feature map of an accumulator pair, slot j of step s <-> feature
+//      (2 s + j / 4) * 16 + 4 g + j % 4 (g = lane >> 4), is used for Q and K alike (a dot product does not care), and the
+//      same map over keys pairs P (straight from the S^T accumulators) with V^T: no shuffles, no transposes.
+//   3. attention: every wave walks the 64-key tiles of its band (global: all of them) on the LDS-resident K / V^T -- no
+//      DMA, no barriers, waves run free; online softmax in exp2 units, per-lane partial row sums.
+//   4. O rows are staged through LDS and stored as whole 128-byte head rows.
+// Sequences longer than 512 tokens, BERT-family encoders and launch-bound batches keep the two-kernel path.
+#include "qkv_attn.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace vrag {
+
+constexpr int QA_WB = 192 * 128;             // one weight stage: 192 rows x 64 k-values
+constexpr int QA_XOFF = 2 * QA_WB;           // the waves' private token stages (64 rows x 128 B each) behind the two weight buffers
+constexpr int QA_SMEM = 131072;              // main loop: 48 + 64 KiB; afterwards K and V^T of the whole sequence: 2 x 64 KiB
+constexpr int QA_V_OFF = 65536;              // K rows [512][128 B] at 0, V^T rows [64][1024 B] behind them
+
+constexpr float QA_LAZY = 8.0f;   // log2 units: the softmax reference moves when a score exceeds it by more than 2^8
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // one v_max3_f32
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool LOCAL, bool FOLD, typename T>
+__global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p) {
+  typedef typename Op<T>::v4 V4;
+  typedef typename Op<T>::v8 V8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uniform(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int H = p.H, Tp = p.Tp, nh = p.nh;
+  // workgroup b runs on XCD b % 8: the heads of one sequence are dealt to ONE XCD back to back, so its token rows are
+  // fetched from HBM once and re-read from that XCD's L2 by the other heads
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int seq = (slot / nh) * 8 + xcd, head = slot % nh;
+  if (seq >= p.n_seqs) return;
+  const int t0 = p.seq_row[seq], S = p.seq_len[seq];
+  const int qrow0 = wave * 64;           // first token of this wave inside the sequence
+  const bool active = qrow0 < S;         // wave-uniform: a wave past the end of a short sequence only helps with the weight DMA
+  const T* X = reinterpret_cast<const T*>(p.x);
+  const T* Wh = reinterpret_cast<const T*>(p.w) + (size_t)head * 192 * H;
+
+  // ---------------------------------------------------------------- 1. main loop
+  // 64-k stages with 128-byte operand rows (whole cache lines per DMA row: 64-byte rows -- a 32-k ring -- halve the L1's
+  // effective rate).  Weight rows are shared by the eight waves: two 24 KiB buffers, the next stage's DMA issued right
+  // after the barrier that retires the previous one.  Token rows are PRIVATE to their wave (8 KiB each): no barrier guards
+  // them -- a wave reads its eight fragments of the stage into registers, waits for those reads, and refills its own buffer
+  // for the next stage while the MFMAs of this one run.
+  // DMA sources as (uniform base) + (32-bit lane offset): the scalar-base addressing form, one VGPR per distinct lane pattern
+  unsigned voffX[2], voffW[3];   // bytes
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int r = par * 8 + (lane >> 3);   // row inside a 16-row block of the wave's 64
+    voffX[par] = (unsigned)(r * H + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = wave * 24 + i * 8 + (lane >> 3);
+    voffW[i] = (unsigned)(row * H + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
+  }
+  const char* const Xw = reinterpret_cast<const char*>(X + (size_t)(t0 + qrow0) * H);   // this wave's first token row (uniform)
+  const char* const Wb = reinterpret_cast<const char*>(Wh);
+  char* const xbuf = smem + QA_XOFF + wave * 8192;
+  // one DMA instruction of the next stage: weight rows (i < 3, 8 rows each) or this wave's token rows (i < 8)
+  auto dma_w = [&](int kt, int buf, int i) {
+    if (p.debug_flags & 4) return;
+    glds16(Wb + kt * 128 + voffW[i], smem + buf * QA_WB + (wave * 24 + i * 8) * 128);
+  };
+  auto dma_x = [&](int kt, int i) {
+    if (!active || (p.debug_flags & 4)) return;
+    glds16(Xw + ((size_t)(i >> 1) * 16 * H + kt * 64) * 2 + voffX[i & 1], xbuf + i * 1024);
+  };
+
+  f32x4 acc[12][4];
+#pragma unroll
+  for (int a = 0; a < 12; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = H >> 6;
+  int fo[2];   // fragment of a 16-row block: row l15, k-values 32 s + 8 g .. + 7
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) fo[s2] = l15 * 128 + ((((4 * s2 + g) ^ ((l15 >> 1) & 7))) << 4);
+  const bool mm = active && !(p.debug_flags & 2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dma_w(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_x(0, i);
+  for (int kt = 0; kt < KT; ++kt) {
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // stage kt has landed everywhere; every wave is past its reads of weight buffer (kt + 1) & 1
+    asm volatile("" ::: "memory");
+    const char* sW = smem + (kt & 1) * QA_WB;
+    const bool more = kt + 1 < KT;
+    V8 xf[2][4], wa;
+    if (mm) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) xf[s2][rt] = *reinterpret_cast<const V8*>(xbuf + rt * 16 * 128 + fo[s2]);
+      wa = *reinterpret_cast<const V8*>(sW + fo[0]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my token fragments are in registers: the buffer may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    const bool burst = (p.debug_flags & 32) != 0;   // A/B: the whole next stage issued here instead of dealt out below
+    if (burst && more) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dma_w(kt + 1, (kt + 1) & 1, i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_x(kt + 1, i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (mm) {
+      // Weight fragments are software-pipelined by hand (the read of block i + 1 sits in front of the four MFMAs of block i),
+      // and the 11 DMA instructions of the next stage are dealt out one per two blocks: issued in one burst after the barrier
+      // they fill the CU's memory queue, every wave then sits in its DMA issue and the matrix pipe idles -- measured as
+      // (DMA time) + (MFMA time) instead of their maximum.
+#pragma unroll
+      for (int it = 0; it < 24; ++it) {   // it = 12 s + nj
+        const int s2 = it / 12, nj = it % 12;
+        V8 na = wa;
+        if (it < 23) na = *reinterpret_cast<const V8*>(sW + ((it + 1) % 12) * 16 * 128 + fo[(it + 1) / 12]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          if (nj < 8) acc[nj][rt] = Op<T>::mfma16(wa, xf[s2][rt], acc[nj][rt]);   // q, k: lane = token, registers = features
+          else acc[nj][rt] = Op<T>::mfma16(xf[s2][rt], wa, acc[nj][rt]);          // v: lane = feature, registers = tokens
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !burst && (it & 1) == 0) {
+          const int slot = it >> 1;   // 0 .. 11
+          if (slot < 8) dma_x(kt + 1, slot);
+          else if (slot < 11) dma_w(kt + 1, (kt + 1) & 1, slot - 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wa = na;
+      }
+    } else if (more && !burst) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dma_w(kt + 1, (kt + 1) & 1, i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma_x(kt + 1, i);
+    }
+  }
+  __syncthreads();   // every wave is past its last operand read: the ring becomes the K / V^T store
+  if (p.debug_flags & 16) return;
+
+  // ---------------------------------------------------------------- 2. epilogue: fold, RoPE, K / V^T -> LDS, Q -> registers
+  // Two batches of gathers, each issued whole before its first use (one exposed L2 round trip per batch, not one per row
+  // tile): the statistics for the V^T third, then -- in the registers the V accumulators leave behind -- the rotary rows of all
+  // four row tiles and the fold vectors of K and Q.
+  const float* ls = p.ln_s + head * 192;
+  float mu[4], rs[4];
+  f32x4 mu4[4], rs4[4];
+  float lsv[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    mu[rt] = 0.f;
+    rs[rt] = 1.f;
+    mu4[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    rs4[rt] = f32x4{1.f, 1.f, 1.f, 1.f};
+    lsv[rt] = 0.f;
+    if constexpr (FOLD) {
+      const int row = min(t0 + qrow0 + rt * 16 + l15, Tp - 1);
+      const int row4 = min(t0 + qrow0 + rt * 16 + 4 * g, Tp - 4);
+      mu[rt] = p.ln_mu[row];
+      rs[rt] = p.ln_rstd[row];
+      mu4[rt] = *reinterpret_cast<const f32x4*>(p.ln_mu + row4);
+      rs4[rt] = *reinterpret_cast<const f32x4*>(p.ln_rstd + row4);
+      lsv[rt] = ls[128 + rt * 16 + l15];   // rt doubles as the feature block index here
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- V^T third (un-swapped accumulators: lane = feature d, registers = tokens)
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int d = db * 16 + l15;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      V8 vv;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int rt = 2 * tp + a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = rs4[rt][r] * (acc[8 + db][rt][r] - mu4[rt][r] * lsv[db]);
+          // keys past the end are masked to probability 0: their V must be a finite number for 0 * v to stay 0
+          vv[a * 4 + r] = qrow0 + rt * 16 + 4 * g + r < S ? Op<T>::to(v) : (T)0.f;
+        }
+      }
+      const int c = wave * 8 + tp * 4 + g;   // 16-byte chunk of the row: keys 64 w + 32 tp .. + 31, slot order (see top)
+      *reinterpret_cast<V8*>(smem + QA_V_OFF + d * 1024 + ((c ^ l15) << 4)) = vv;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 cz[4][2], sz[4][2], lk1[2], lk2[2], lq1[2], lq2[2];
+#pragma unroll
+  for (int np = 0; np < 2; ++np) {
+    const int dd = np * 16 + 4 * g;
+    lk1[np] = lk2[np] = lq1[np] = lq2[np] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) {
+      lq1[np] = *reinterpret_cast<const f32x4*>(ls + dd);
+      lq2[np] = *reinterpret_cast<const f32x4*>(ls + 32 + dd);
+      lk1[np] = *reinterpret_cast<const f32x4*>(ls + 64 + dd);
+      lk2[np] = *reinterpret_cast<const f32x4*>(ls + 96 + dd);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int ps = min(qrow0 + rt * 16 + l15, S - 1);   // position inside the sequence (rows past the end: any row in range)
+      cz[rt][np] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)ps * 32 + dd);
+      sz[rt][np] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)ps * 32 + dd);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // rotate one (q or k) third: accumulators a0 .. a0 + 3, out[s] = the two 8-value operand fragments of row tile rt
+  auto rope_rows = [&](int a0, int rt, const f32x4 (&l1)[2], const f32x4 (&l2)[2], float scale, V8 (&out)[2]) {
+    const bool live = qrow0 + rt * 16 + l15 < S;
+#pragma unroll
+    for (int np = 0; np < 2; ++np) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x1 = acc[a0 + np][rt][j], x2 = acc[a0 + 2 + np][rt][j];
+        if constexpr (FOLD) {
+          x1 = rs[rt] * (x1 - mu[rt] * l1[np][j]);
+          x2 = rs[rt] * (x2 - mu[rt] * l2[np][j]);
+        }
+        // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
+        const float o1 = (x1 * cz[rt][np][j] - x2 * sz[rt][np][j]) * scale, o2 = (x2 * cz[rt][np][j] + x1 * sz[rt][np][j]) * scale;
+        // rows past the end of the sequence are masked (keys) or never stored (queries); only the fp16 conversion cares,
+        // because it reports values it has to clamp
+        if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) {
+          out[0][np * 4 + j] = live ? Op<T>::to(o1) : (T)0.f;
+          out[1][np * 4 + j] = live ? Op<T>::to(o2) : (T)0.f;
+        } else {
+          out[0][np * 4 + j] = Op<T>::to(o1);
+          out[1][np * 4 + j] = Op<T>::to(o2);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    V8 kf[2];
+    rope_rows(4, rt, lk1, lk2, 1.0f, kf);
+    const int row = qrow0 + rt * 16 + l15;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) *reinterpret_cast<V8*>(smem + row * 128 + (((4 * s + g) ^ ((row >> 1) & 7)) << 4)) = kf[s];
+  }
+  V8 qf[4][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) rope_rows(0, rt, lq1, lq2, p.q_scale, qf[rt]);
+  __syncthreads();   // K and V^T of the whole sequence are in LDS
+
+  // ---------------------------------------------------------------- 3. attention over the LDS-resident keys
+  // The arithmetic of attn2_fwd_kernel (attention.hip): the running reference rides into S^T = K . Q^T as the MFMA's C operand,
+  // so p = exp2(s) needs no subtraction; the reference moves (cross-lane maximum, rescale) only when a score exceeds it by
+  // more than 2^8 or a row meets its first key -- a rare wave-uniform branch; row sums come from the matrix pipe (an all-ones
+  // A operand against the very P fragments the P . V product uses).  Per score: half a v_max3, one v_exp, half a packed
+  // convert.  A 32-row group (u) is scored at a time: half of the score registers live, K fragments read twice from LDS
+  // (no DMA competes for it here).
+  f32x4 ot[4][4];   // O^T[d = 16 dt + 4 g + r][query l15] of column block c
+  f32x4 lo[4];      // row sums of column block c (every register holds the same value)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    lo[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[c][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float m_run[4] = {0.f, 0.f, 0.f, 0.f};   // the reference of the lane's query in block c (log2 units); meaningful once seen
+  bool seen[4] = {false, false, false, false};
+  V8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+  const int W = p.window;
+  int kt_lo = 0, kt_hi = (S - 1) >> 6;
+  if constexpr (LOCAL) {
+    kt_lo = max(0, qrow0 - W) >> 6;
+    kt_hi = min(S - 1, qrow0 + 63 + W) >> 6;
+  }
+  const int ksw = (l15 >> 1) & 7;
+  if (active && !(p.debug_flags & 1)) {
+    for (int kt = kt_lo; kt <= kt_hi; ++kt) {
+      // 32-row group u against the 32-key half t2 of the tile: outside the band / beyond the sequence -> skipped (no MFMA,
+      // p = 0); cut by the band edge or the sequence end -> masked element by element; else mask-free
+      bool skip[2][2], tri[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int q_lo = qrow0 + 32 * u, kh = kt * 64 + t2 * 32;
+          skip[u][t2] = kh >= S || q_lo >= S;
+          tri[u][t2] = kh + 31 >= S;
+          if constexpr (LOCAL) {
+            skip[u][t2] = skip[u][t2] || (kh + 31 < q_lo - W) || (kh > q_lo + 31 + W);
+            tri[u][t2] = tri[u][t2] || (kh < q_lo + 31 - W) || (kh + 31 > q_lo + W);
+          }
+        }
+      V8 pf[4][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (skip[u][0] && skip[u][1]) {
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) pf[2 * u + cc][t2][j] = (T)0.f;
+          continue;
+        }
+        f32x4 st[2][4];   // S^T - reference: lane (l15 = query of column block 2u + cc, g) holds keys 16 kb + 4 g + r
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const float seed = -m_run[2 * u + cc];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) st[cc][kb] = f32x4{seed, seed, seed, seed};
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          if (skip[u][kb >> 1]) continue;
+          const char* krow = smem + (kt * 64 + kb * 16 + l15) * 128;
+          const V8 k0 = *reinterpret_cast<const V8*>(krow + ((g ^ ksw) << 4));
+          const V8 k1 = *reinterpret_cast<const V8*>(krow + (((4 + g) ^ ksw) << 4));
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            st[cc][kb] = Op<T>::mfma16(k0, qf[2 * u + cc][0], st[cc][kb]);
+            st[cc][kb] = Op<T>::mfma16(k1, qf[2 * u + cc][1], st[cc][kb]);
+          }
+        }
+        // masks and in-lane maxima (scores are relative to m_run already)
+        float mx[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          mx[cc] = -INFINITY;
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            if (skip[u][t2]) {
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) st[cc][2 * t2 + h2] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+              continue;
+            }
+            if (tri[u][t2]) {
+              const int qi = qrow0 + 32 * u + 16 * cc + l15;
+              int lo_k = 0, hi_k = S - 1;
+              if constexpr (LOCAL) {
+                lo_k = max(0, qi - W);
+                hi_k = min(S - 1, qi + W);
+              }
+              const unsigned span = hi_k >= lo_k ? (unsigned)(hi_k - lo_k) : 0u;
+              int d0 = hi_k >= lo_k ? kt * 64 + t2 * 32 + 4 * g - lo_k : -100000;
+              asm volatile("" : "+v"(d0));   // keep the predicate arithmetic inside this branch
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const bool ok = (unsigned)(d0 + 16 * h2 + r) <= span;
+                  st[cc][2 * t2 + h2][r] = ok ? st[cc][2 * t2 + h2][r] : -INFINITY;
+                }
+            }
+            const f32x4& a = st[cc][2 * t2];
+            const f32x4& b2 = st[cc][2 * t2 + 1];
+            mx[cc] = max3f(mx[cc], max3f(a[0], a[1], a[2]), max3f(a[3], b2[0], b2[1]));
+            mx[cc] = max3f(mx[cc], b2[2], b2[3]);
+          }
+        }
+        // move the reference?  (wave-uniform; steady state: no)
+        bool move = false;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) move = move || mx[cc] > QA_LAZY || (!seen[2 * u + cc] && mx[cc] > -INFINITY);
+        if (__any(move)) {
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const int c = 2 * u + cc;
+            float m_all = fmaxf(mx[cc], __shfl_xor(mx[cc], 16, 64));   // over the four lane groups of the query
+            m_all = fmaxf(m_all, __shfl_xor(m_all, 32, 64));
+            const bool has = m_all > -INFINITY;
+            const float delta = seen[c] ? fmaxf(m_all, 0.f) : (has ? m_all : 0.f);
+            // a row's first reference may sit far below zero: nothing has been accumulated yet, so nothing is rescaled
+            // (2^-delta would overflow); afterwards delta >= 0 and alpha <= 1
+            const float alpha = seen[c] ? __builtin_amdgcn_exp2f(-delta) : 1.0f;
+            seen[c] = seen[c] || has;
+            m_run[c] += delta;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) st[cc][kb][r] -= delta;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ot[c][dt][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo[c][r] *= alpha;
+          }
+        }
+        // p = exp2(s - m) straight into the B-operand fragments of O^T += V^T . P^T: k-slot (g, j) of the 32-key step t2 is the
+        // accumulator row j & 3 of key block 2 t2 + (j >> 2)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[2 * u + cc][t2][j] = (T)__builtin_amdgcn_exp2f(st[cc][2 * t2 + (j >> 2)][j & 3]);
+      }
+      // ---- O^T += V^T . P^T, l += 1 . P^T (V^T fragments read once for the four column blocks)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (skip[0][t2] && skip[1][t2]) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (!skip[c >> 1][t2]) lo[c] = Op<T>::mfma16(ones, pf[c][t2], lo[c]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const V8 vf = *reinterpret_cast<const V8*>(smem + QA_V_OFF + (dt * 16 + l15) * 1024 + (((kt * 8 + t2 * 4 + g) ^ l15) << 4));
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (!skip[c >> 1][t2]) ot[c][dt] = Op<T>::mfma16(vf, pf[c][t2], ot[c][dt]);
+        }
+      }
+    }
+  }
+  __syncthreads();   // every wave is done with K / V^T: the K area becomes the output staging (8 KiB per wave)
+
+  // ---------------------------------------------------------------- 4. normalise, stage, store whole head rows
+  if (active) {
+    char* stg = smem + wave * 8192;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int row = rt * 16 + l15;
+      const bool live = qrow0 + row < S;
+      const float inv = live ? 1.0f / lo[rt][0] : 0.f;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        V4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = live ? Op<T>::to(ot[rt][db][j] * inv) : (T)0.f;
+        const int c16 = db * 2 + (g >> 1);
+        *reinterpret_cast<V4*>(stg + row * 128 + ((c16 ^ (row & 7)) << 4) + ((g & 1) << 3)) = o;
+      }
+    }
+    // private to the wave: program order + the compiler's lgkmcnt wait order the reads below
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((c16 ^ (row & 7)) << 4));
+      if (qrow0 + row < S && !(p.debug_flags & 8)) store16_nt(reinterpret_cast<T*>(p.o) + (size_t)(t0 + qrow0 + row) * H + head * 64 + c16 * 8, v);
+    }
+  }
+}
+
+template <bool LOCAL, bool FOLD, typename T>
+static hipError_t launch_t(const QkvAttnParams& p, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_kernel<LOCAL, FOLD, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, QA_SMEM);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int grid = ((p.n_seqs + 7) / 8) * 8 * p.nh;
+  hipLaunchKernelGGL((qkv_attn_kernel<LOCAL, FOLD, T>), dim3(grid), dim3(512), QA_SMEM, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_qkv_attention(const QkvAttnParams& p, bool local, hipStream_t stream) {
+  if (p.n_seqs <= 0) return hipSuccess;
+  if (p.H % 64 != 0 || p.H != p.nh * 64 || (size_t)p.Tp * p.H >= (size_t)1 << 31) return hipErrorInvalidValue;
+  const bool fold = p.ln_mu != nullptr;
+  if (p.op_dtype == kOpF16) {
+    if (fold) return local ? launch_t<true, true, f16_t>(p, stream) : launch_t<false, true, f16_t>(p, stream);
+    return local ? launch_t<true, false, f16_t>(p, stream) : launch_t<false, false, f16_t>(p, stream);
+  }
+  if (fold) return local ? launch_t<true, true, bf16_t>(p, stream) : launch_t<false, true, bf16_t>(p, stream);
+  return local ? launch_t<true, false, bf16_t>(p, stream) : launch_t<false, false, bf16_t>(p, stream);
+}
+
+__global__ void permute_qkv_heads_kernel(const bf16_t* __restrict__ w, const float* __restrict__ s, int H, int nh,
+                                         bf16_t* __restrict__ w_out, float* __restrict__ s_out) {
+  const int orow = blockIdx.x;   // (head * 3 + part) * 64 + d
+  const int head = orow / 192, part = (orow % 192) / 64, d = orow % 64;
+  const int src = part * H + head * 64 + d;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) w_out[(size_t)orow * H + i] = w[(size_t)src * H + i];
+  if (threadIdx.x == 0 && s && s_out) s_out[orow] = s[src];
+}
+
+hipError_t permute_qkv_heads(const bf16_t* w, const float* s, int H, int nh, bf16_t* w_out, float* s_out, hipStream_t stream) {
+  hipLaunchKernelGGL(permute_qkv_heads_kernel, dim3(3 * H), dim3(256), 0, stream, w, s, H, nh, w_out, s_out);
+  return hipGetLastError();
+}
+
+unsigned qkv_attn_f16_saturated(bool reset) { return f16_sat_take(reset); }
+
+}  // namespace vrag

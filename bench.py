@@ -485,7 +485,14 @@ def main() -> None:
         breakdown = {k: {"ms_per_step": v[0] / max(1, args.steps), "launches_per_step": v[1] / max(1, args.steps)}
                      for k, v in prof.items() if v[1] > 0}
         # Kernel classes by rocprofv3 kernel name: both residual GEMMs (attention Wo, mlp Wo) are ONE instantiation.
+        # the fused kernel's class carries the Wqkv product AND the attention of its layers
+        n_glob = len([l for l in range(shape.num_hidden_layers) if l % shape.global_attn_every_n_layers == 0])
+        tok = n_chunks * SEQ
+        fl["qkv_attn_global"] = fl["gemm_qkv"] * n_glob / shape.num_hidden_layers + n_glob * 4.0 * tok * SEQ * shape.hidden_size
+        fl["qkv_attn_local"] = fl["gemm_qkv"] * (1 - n_glob / shape.num_hidden_layers) + \
+            (shape.num_hidden_layers - n_glob) * 4.0 * tok * (2 * (shape.local_attention // 2) + 1) * shape.hidden_size
         classes = {
+            "vrag::qkv_attn_kernel (Wqkv + RoPE + attention per sequence and head)": ["qkv_attn_global", "qkv_attn_local"],
             "vrag::gemm_bf16_kernel<EPI_QKV_ROPE> (Wqkv + RoPE + V^T)": ["gemm_qkv"],
             "vrag::gemm_bf16_kernel<EPI_RESIDUAL> (attn Wo + mlp Wo, fp32 residual RMW)": ["gemm_wo", "gemm_wo_mlp"],
             "vrag::gemm_bf16_kernel<EPI_GEGLU> (Wi + GeGLU)": ["gemm_wi"],
@@ -526,7 +533,9 @@ def main() -> None:
             # main loop and an HBM-speed fp32 read-modify-write epilogue, so both fractions are reported
             M_mb = min(args.micro_batch_tokens or n_chunks * SEQ, n_chunks * SEQ)
             Hs, Is = shape.hidden_size, shape.intermediate_size
-            alg_bytes = {"gemm_qkv": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + 3 * M_mb * Hs * 2,
+            alg_bytes = {"qkv_attn_global": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + M_mb * Hs * 2,
+                         "qkv_attn_local": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + M_mb * Hs * 2,
+                         "gemm_qkv": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + 3 * M_mb * Hs * 2,
                          "gemm_wi": M_mb * Hs * 2 + 2 * Is * Hs * 2 + M_mb * Is * 2,
                          "gemm_wo": M_mb * Hs * 2 + Hs * Hs * 2 + 2 * M_mb * Hs * 4 + 2 * M_mb * Hs,
                          "gemm_wo_mlp": M_mb * Is * 2 + Hs * Is * 2 + 2 * M_mb * Hs * 4 + 2 * M_mb * Hs}

@@ -37,7 +37,7 @@ extern "C" {
 #define VRAG_ERR_CAPACITY (-3)/* batch does not fit the workspace the handle was created with */
 #define VRAG_ERR_NO_DEVICE (-4)
 
-#define VRAG_ABI_VERSION 4
+#define VRAG_ABI_VERSION 5
 
 /* MFMA operand type of an encoder handle.  bf16: fp32's exponent range (safe for any checkpoint), 8 significant bits --
  * sentence logits within 3e-4 of the fp32 reference.  fp16: 11 significant bits at the same matrix-core rate, values
@@ -242,7 +242,9 @@ int vrag_encoder_f16_saturated(vrag_encoder* enc, int32_t reset, int32_t* satura
 #define VRAG_PROF_GEMM_WI 6
 #define VRAG_PROF_GEMM_WO_MLP 7
 #define VRAG_PROF_HEAD 8
-#define VRAG_PROF_COUNT 9
+#define VRAG_PROF_QKV_ATTN_GLOBAL 9 /* fused Wqkv + RoPE + attention kernel (csrc/qkv_attn.hip), global layers */
+#define VRAG_PROF_QKV_ATTN_LOCAL 10 /* the same, banded layers */
+#define VRAG_PROF_COUNT 11
 /* Micro-batches (cfg.micro_batch_tokens) are issued on 2 internal streams by default so that the
  * HBM-bound kernels of one overlap the MFMA-bound kernels of the other; 1 serialises them. */
 int vrag_encoder_set_concurrency(vrag_encoder* enc, int32_t n_streams);

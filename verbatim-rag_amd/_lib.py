@@ -11,10 +11,10 @@ _LOCK = threading.Lock()
 _LIB = None
 
 VRAG_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 PROF_CLASSES = (
     "embed", "layernorm", "gemm_qkv", "attn_global", "attn_local",
-    "gemm_wo", "gemm_wi", "gemm_wo_mlp", "head",
+    "gemm_wo", "gemm_wi", "gemm_wo_mlp", "head", "qkv_attn_global", "qkv_attn_local",
 )
 
 

@@ -216,7 +216,7 @@ struct vrag_encoder {
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   int n_streams = 1;
   bool ln_fold = true;   // LayerNorm folded into the producer/consumer GEMM epilogues (VRAG_LN_FOLD=0: separate LN kernels)
-  int fused_qkv_attn = 0;   // Wqkv GEMM + RoPE + attention in one kernel per (sequence, head) when every sequence of the micro-batch has <= 512 tokens (VRAG_FUSED_QKV_ATTN)
+  int fused_qkv_attn = 1;   // Wqkv GEMM + RoPE + attention in one kernel per (sequence, head) when every sequence of the micro-batch has <= 512 tokens (VRAG_FUSED_QKV_ATTN)
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
 
@@ -501,7 +501,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       const bool consumer_stats = fold && gemm_consumer_finalizes(M);
       // sequences of <= 512 tokens, throughput-sized micro-batch: one kernel per (sequence, head) instead of the QKV GEMM and the
       // attention launch -- Q, K and V^T never leave the CU (qkv_attn.hip)
-      const bool fused_attn = e->fused_qkv_attn && L.wqkv_h && mb.max_len <= kFusedMaxSeq && (!consumer_stats || e->fused_qkv_attn == 2);
+      const bool fused_attn = e->fused_qkv_attn && L.wqkv_h && mb.max_len <= kFusedMaxSeq &&
+                              (!gemm_consumer_finalizes(M) || e->fused_qkv_attn == 2);
       auto finalize_stats = [&](bool first, bool for_qkv = false) -> int {
         if (consumer_stats && !(for_qkv && fused_attn)) return VRAG_OK;
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
@@ -540,7 +541,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         f.q_scale = 0.125f * 1.4426950408889634f;
         static const int fused_dbg = getenv("VRAG_FUSED_DEBUG") ? atoi(getenv("VRAG_FUSED_DEBUG")) : 0;
         f.debug_flags = fused_dbg;
-        ProfScope ps(e, VRAG_PROF_GEMM_QKV, st);
+        ProfScope ps(e, global ? VRAG_PROF_QKV_ATTN_GLOBAL : VRAG_PROF_QKV_ATTN_LOCAL, st);
         HIP_TRY(launch_qkv_attention(f, !global, st));
       } else {
       {
@@ -1014,7 +1015,9 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   TRY(init_streams(e));
 
   if (const char* lf = getenv("VRAG_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
-  if (const char* fq = getenv("VRAG_FUSED_QKV_ATTN")) e->fused_qkv_attn = cfg->hidden_size == cfg->num_heads * 64 ? atoi(fq) : 0;   // 2: launch-bound batches too
+  // 0: always the QKV GEMM + attention launch; 1 (default): fused kernel for throughput-sized micro-batches; 2: launch-bound batches too
+  if (const char* fq = getenv("VRAG_FUSED_QKV_ATTN")) e->fused_qkv_attn = atoi(fq);
+  if (cfg->hidden_size != cfg->num_heads * 64) e->fused_qkv_attn = 0;
 
   // ---- weights
   const int Ip = (int)align_up(I, 128);

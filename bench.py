@@ -34,7 +34,7 @@ def _gemm_source_sha16() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("gemm_bf16.hip", "gemm_bf16.h", "common.h"):
+    for f in ("gemm_bf16.hip", "gemm_bf16.h", "common.h", "qkv_attn.hip", "qkv_attn.h"):
         with open(os.path.join(ROOT, "verbatim-rag_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

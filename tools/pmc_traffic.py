@@ -55,11 +55,22 @@ def main(pmc_path, bench_path):
             "note": "FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes; L2-fabric side, "
                     "Infinity-Cache hits included; kernel<3> = mean over the Wo and mlp-Wo launches",
         }
+    for cls, tag in (("qkv_attn_global", "qkv_attn_kernel<false"), ("qkv_attn_local", "qkv_attn_kernel<true")):
+        name = next((k for k in pmc if tag in k and "FETCH_SIZE" in pmc[k]), None)
+        if not name:
+            continue
+        f, w = pmc[name]["FETCH_SIZE"], pmc[name].get("WRITE_SIZE", 0.0)
+        res[cls] = {
+            "kernel": name, "rows_per_launch": rows, "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,
+            "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
+            "algorithmic_bytes_per_launch": rows * H * 2 + 3 * H * H * 2 + rows * H * 2,   # token rows in, weights, attention rows out
+            "note": "fused Wqkv + RoPE + attention kernel: Q / K / V^T never reach the fabric; FETCH_SIZE x 2 + WRITE_SIZE as above",
+        }
     import hashlib
 
     h = hashlib.sha256()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for f in ("gemm_bf16.hip", "gemm_bf16.h", "common.h"):      # bench.py refuses the summary once these change
+    for f in ("gemm_bf16.hip", "gemm_bf16.h", "common.h", "qkv_attn.hip", "qkv_attn.h"):      # bench.py refuses the summary once these change
         with open(os.path.join(root, "verbatim-rag_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     res["_gemm_source_sha16"] = h.hexdigest()[:16]

@@ -530,6 +530,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         }
         f.rope_cos = global ? e->cos_g : e->cos_l;
         f.rope_sin = global ? e->sin_g : e->sin_l;
+        f.rope_rows = c.max_seq_len;
         f.o = e->o;
         f.seq_row = e->d_seq_meta + mb.seq0;
         f.seq_len = e->d_seq_meta + 2 * c.max_seqs + mb.seq0;
@@ -1040,7 +1041,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
                     fold && l > 0 ? ly.attn_norm : nullptr, fold && l > 0 ? &ly.s_qkv : nullptr));
     if (e->fused_qkv_attn) {
       TRY(dev_alloc(e, &ly.wqkv_h, (size_t)3 * H * H, false));
-      if (ly.s_qkv) TRY(dev_alloc(e, &ly.s_qkv_h, (size_t)3 * H, false));
+      if (ly.s_qkv) TRY(dev_alloc(e, &ly.s_qkv_h, (size_t)3 * H + 64));   // the kernel's 256-float DMA of a head's 192 sums reads 64 floats on
       HIP_TRY(permute_qkv_heads(ly.wqkv, ly.s_qkv, H, cfg->num_heads, ly.wqkv_h, ly.s_qkv_h, nullptr));
     }
     TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
@@ -2067,7 +2068,7 @@ int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, 
   if (e == hipSuccess) e = hipMalloc(&o, Tp * H * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&mu, Tp * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&rstd, Tp * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&lns, (size_t)3 * H * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&lns, ((size_t)3 * H + 64) * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&cs, (size_t)kFusedMaxSeq * 32 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&d_row, n_seqs * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&d_len, n_seqs * 4);
@@ -2102,6 +2103,7 @@ int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, 
   f.ln_s = lns;
   f.rope_cos = cs;
   f.rope_sin = cs;
+  f.rope_rows = kFusedMaxSeq;
   f.o = (bf16_t*)o;
   f.seq_row = d_row;
   f.seq_len = d_len;

@@ -11,9 +11,10 @@ struct QkvAttnParams {
   const bf16_t* w;         // [nh][192][H] per-head weight rows: q(64) k(64) v(64) (permute_qkv_heads), LayerNorm gain folded in
   const float* ln_mu;      // [Tp] or null (no fold): see GemmParams
   const float* ln_rstd;    // [Tp]
-  const float* ln_s;       // [nh * 192] row sums of w, same permutation
-  const float* rope_cos;   // [max_pos, 32]
+  const float* ln_s;       // [nh * 192 (+ 64 readable floats behind the last head)] row sums of w, same permutation
+  const float* rope_cos;   // [rope_rows, 32]
   const float* rope_sin;
+  int rope_rows;           // positions the rotary tables hold (>= the longest sequence)
   bf16_t* o;               // [Tp, H] attention output (the Wo GEMM's A operand)
   const int* seq_row;      // [n_seqs] first packed row of every sequence
   const int* seq_len;      // [n_seqs] tokens (<= kFusedMaxSeq)

@@ -29,7 +29,10 @@ namespace vrag {
 
 constexpr int QA_WB = 192 * 128;             // one weight stage: 192 rows x 64 k-values
 constexpr int QA_XOFF = 2 * QA_WB;           // the waves' private token stages (64 rows x 128 B each) behind the two weight buffers
-constexpr int QA_SMEM = 131072;              // main loop: 48 + 64 KiB; afterwards K and V^T of the whole sequence: 2 x 64 KiB
+constexpr int QA_TAB = 131072;               // main loop: 48 + 64 KiB; afterwards K and V^T of the whole sequence: 2 x 64 KiB; then the tables:
+constexpr int QA_MU = QA_TAB, QA_RS = QA_TAB + 2048, QA_LS = QA_TAB + 4096;            // row statistics of the 512 tokens, fold sums of the head
+constexpr int QA_CA = QA_TAB + 5120, QA_SA = QA_CA + 4096, QA_CB = QA_SA + 4096, QA_SB = QA_CB + 2048;   // rotary rows 16 b (b < 32) and 0 .. 15
+constexpr int QA_SMEM = QA_SB + 2048;        // 145 KiB
 constexpr int QA_V_OFF = 65536;              // K rows [512][128 B] at 0, V^T rows [64][1024 B] behind them
 
 constexpr float QA_LAZY = 8.0f;   // log2 units: the softmax reference moves when a score exceeds it by more than 2^8
@@ -92,6 +95,30 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     glds16(Xw + ((size_t)(i >> 1) * 16 * H + kt * 64) * 2 + voffX[i & 1], xbuf + i * 1024);
   };
 
+  // Everything the epilogue gathers -- the row statistics of the sequence, the head's fold sums, rotary rows -- comes in by DMA
+  // NOW, behind the K / V^T area, and is read from LDS when the main loop is over: no global round trip sits between the main
+  // loop and attention.  Rotary rows by angle addition: pos = 16 b + i, cos(pos f) = cos(16 b f) cos(i f) - sin(16 b f) sin(i f):
+  // table rows 16 b (b < 32) and rows 0 .. 15 are all a 512-token sequence needs (12 KiB instead of 128).
+  if (!(p.debug_flags & 4)) {
+    if (FOLD && wave < 2) {
+      const float* src = wave == 0 ? p.ln_mu : p.ln_rstd;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(src + min(t0 + i * 256 + lane * 4, Tp - 4), smem + (wave == 0 ? QA_MU : QA_RS) + i * 1024);
+    }
+    if (FOLD && wave == 2) glds16(p.ln_s + head * 192 + lane * 4, smem + QA_LS);
+    if (wave == 2 || wave == 3) {   // rows 0 .. 15 (8 rows of 128 bytes per instruction)
+      const float* tab = wave == 2 ? p.rope_cos : p.rope_sin;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(tab + (i * 8 + (lane >> 3)) * 32 + (lane & 7) * 4, smem + (wave == 2 ? QA_CB : QA_SB) + i * 1024);
+    }
+    if (wave == 4 || wave == 5) {   // rows 16 b
+      const float* tab = wave == 4 ? p.rope_cos : p.rope_sin;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        glds16(tab + (size_t)min(16 * (i * 8 + (lane >> 3)), p.rope_rows - 1) * 32 + (lane & 7) * 4, smem + (wave == 4 ? QA_CA : QA_SA) + i * 1024);
+    }
+  }
+
   f32x4 acc[12][4];
 #pragma unroll
   for (int a = 0; a < 12; ++a)
@@ -123,19 +150,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my token fragments are in registers: the buffer may be refilled
     __builtin_amdgcn_sched_barrier(0);
-    const bool burst = (p.debug_flags & 32) != 0;   // A/B: the whole next stage issued here instead of dealt out below
-    if (burst && more) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) dma_w(kt + 1, (kt + 1) & 1, i);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dma_x(kt + 1, i);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     if (mm) {
       // Weight fragments are software-pipelined by hand (the read of block i + 1 sits in front of the four MFMAs of block i),
-      // and the 11 DMA instructions of the next stage are dealt out one per two blocks: issued in one burst after the barrier
-      // they fill the CU's memory queue, every wave then sits in its DMA issue and the matrix pipe idles -- measured as
-      // (DMA time) + (MFMA time) instead of their maximum.
+      // and the 11 DMA instructions of the next stage are dealt out one per two blocks instead of in one burst after the barrier
+      // (measured inside the bench step: 392 vs 409 us per launch).
 #pragma unroll
       for (int it = 0; it < 24; ++it) {   // it = 12 s + nj
         const int s2 = it / 12, nj = it % 12;
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
           else acc[nj][rt] = Op<T>::mfma16(xf[s2][rt], wa, acc[nj][rt]);          // v: lane = feature, registers = tokens
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !burst && (it & 1) == 0) {
+        if (more && (it & 1) == 0) {
           const int slot = it >> 1;   // 0 .. 11
           if (slot < 8) dma_x(kt + 1, slot);
           else if (slot < 11) dma_w(kt + 1, (kt + 1) & 1, slot - 8);
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         __builtin_amdgcn_sched_barrier(0);
         wa = na;
       }
-    } else if (more && !burst) {
+    } else if (more) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) dma_w(kt + 1, (kt + 1) & 1, i);
 #pragma unroll
@@ -167,44 +185,28 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   if (p.debug_flags & 16) return;
 
   // ---------------------------------------------------------------- 2. epilogue: fold, RoPE, K / V^T -> LDS, Q -> registers
-  // Two batches of gathers, each issued whole before its first use (one exposed L2 round trip per batch, not one per row
-  // tile): the statistics for the V^T third, then -- in the registers the V accumulators leave behind -- the rotary rows of all
-  // four row tiles and the fold vectors of K and Q.
-  const float* ls = p.ln_s + head * 192;
-  float mu[4], rs[4];
-  f32x4 mu4[4], rs4[4];
-  float lsv[4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    mu[rt] = 0.f;
-    rs[rt] = 1.f;
-    mu4[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rs4[rt] = f32x4{1.f, 1.f, 1.f, 1.f};
-    lsv[rt] = 0.f;
-    if constexpr (FOLD) {
-      const int row = min(t0 + qrow0 + rt * 16 + l15, Tp - 1);
-      const int row4 = min(t0 + qrow0 + rt * 16 + 4 * g, Tp - 4);
-      mu[rt] = p.ln_mu[row];
-      rs[rt] = p.ln_rstd[row];
-      mu4[rt] = *reinterpret_cast<const f32x4*>(p.ln_mu + row4);
-      rs4[rt] = *reinterpret_cast<const f32x4*>(p.ln_rstd + row4);
-      lsv[rt] = ls[128 + rt * 16 + l15];   // rt doubles as the feature block index here
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  const float* l_mu = reinterpret_cast<const float*>(smem + QA_MU) + qrow0;
+  const float* l_rs = reinterpret_cast<const float*>(smem + QA_RS) + qrow0;
+  const float* l_ls = reinterpret_cast<const float*>(smem + QA_LS);
   // ---- V^T third (un-swapped accumulators: lane = feature d, registers = tokens)
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
     const int d = db * 16 + l15;
+    const float lsv = FOLD ? l_ls[128 + d] : 0.f;
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp) {
       V8 vv;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int rt = 2 * tp + a;
+        f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, r4 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (FOLD) {
+          m4 = *reinterpret_cast<const f32x4*>(l_mu + rt * 16 + 4 * g);
+          r4 = *reinterpret_cast<const f32x4*>(l_rs + rt * 16 + 4 * g);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = rs4[rt][r] * (acc[8 + db][rt][r] - mu4[rt][r] * lsv[db]);
+          const float v = r4[r] * (acc[8 + db][rt][r] - m4[r] * lsv);
           // keys past the end are masked to probability 0: their V must be a finite number for 0 * v to stay 0
           vv[a * 4 + r] = qrow0 + rt * 16 + 4 * g + r < S ? Op<T>::to(v) : (T)0.f;
         }
@@ -213,43 +215,35 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
       *reinterpret_cast<V8*>(smem + QA_V_OFF + d * 1024 + ((c ^ l15) << 4)) = vv;
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 cz[4][2], sz[4][2], lk1[2], lk2[2], lq1[2], lq2[2];
-#pragma unroll
-  for (int np = 0; np < 2; ++np) {
-    const int dd = np * 16 + 4 * g;
-    lk1[np] = lk2[np] = lq1[np] = lq2[np] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (FOLD) {
-      lq1[np] = *reinterpret_cast<const f32x4*>(ls + dd);
-      lq2[np] = *reinterpret_cast<const f32x4*>(ls + 32 + dd);
-      lk1[np] = *reinterpret_cast<const f32x4*>(ls + 64 + dd);
-      lk2[np] = *reinterpret_cast<const f32x4*>(ls + 96 + dd);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int ps = min(qrow0 + rt * 16 + l15, S - 1);   // position inside the sequence (rows past the end: any row in range)
-      cz[rt][np] = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)ps * 32 + dd);
-      sz[rt][np] = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)ps * 32 + dd);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // rotate one (q or k) third: accumulators a0 .. a0 + 3, out[s] = the two 8-value operand fragments of row tile rt
-  auto rope_rows = [&](int a0, int rt, const f32x4 (&l1)[2], const f32x4 (&l2)[2], float scale, V8 (&out)[2]) {
+  // ---- q and k thirds: rotate accumulators a0 .. a0 + 3 of row tile rt, out[s] = the two 8-value operand fragments
+  auto rope_rows = [&](int a0, int rt, int ls_off, float scale, V8 (&out)[2]) {
     const bool live = qrow0 + rt * 16 + l15 < S;
+    const float mu = FOLD ? l_mu[rt * 16 + l15] : 0.f, rs = FOLD ? l_rs[rt * 16 + l15] : 1.f;
 #pragma unroll
     for (int np = 0; np < 2; ++np) {
+      const int dd = np * 16 + 4 * g;
+      const f32x4 ca = *reinterpret_cast<const f32x4*>(smem + QA_CA + ((4 * wave + rt) * 32 + dd) * 4);
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(smem + QA_SA + ((4 * wave + rt) * 32 + dd) * 4);
+      const f32x4 cb = *reinterpret_cast<const f32x4*>(smem + QA_CB + (l15 * 32 + dd) * 4);
+      const f32x4 sb = *reinterpret_cast<const f32x4*>(smem + QA_SB + (l15 * 32 + dd) * 4);
+      f32x4 l1 = {0.f, 0.f, 0.f, 0.f}, l2 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (FOLD) {
+        l1 = *reinterpret_cast<const f32x4*>(l_ls + ls_off + dd);
+        l2 = *reinterpret_cast<const f32x4*>(l_ls + ls_off + 32 + dd);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x1 = acc[a0 + np][rt][j], x2 = acc[a0 + 2 + np][rt][j];
         if constexpr (FOLD) {
-          x1 = rs[rt] * (x1 - mu[rt] * l1[np][j]);
-          x2 = rs[rt] * (x2 - mu[rt] * l2[np][j]);
+          x1 = rs * (x1 - mu * l1[j]);
+          x2 = rs * (x2 - mu * l2[j]);
         }
+        const float c = ca[j] * cb[j] - sa[j] * sb[j], sn = sa[j] * cb[j] + ca[j] * sb[j];   // cos / sin of (16 b + i) f
         // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
-        const float o1 = (x1 * cz[rt][np][j] - x2 * sz[rt][np][j]) * scale, o2 = (x2 * cz[rt][np][j] + x1 * sz[rt][np][j]) * scale;
+        const float o1 = (x1 * c - x2 * sn) * scale, o2 = (x2 * c + x1 * sn) * scale;
         // rows past the end of the sequence are masked (keys) or never stored (queries); only the fp16 conversion cares,
         // because it reports values it has to clamp
-        if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) {
+        if constexpr (!std::is_same<T, bf16_t>::value) {
           out[0][np * 4 + j] = live ? Op<T>::to(o1) : (T)0.f;
           out[1][np * 4 + j] = live ? Op<T>::to(o2) : (T)0.f;
         } else {
@@ -262,14 +256,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     V8 kf[2];
-    rope_rows(4, rt, lk1, lk2, 1.0f, kf);
+    rope_rows(4, rt, 64, 1.0f, kf);
     const int row = qrow0 + rt * 16 + l15;
 #pragma unroll
     for (int s = 0; s < 2; ++s) *reinterpret_cast<V8*>(smem + row * 128 + (((4 * s + g) ^ ((row >> 1) & 7)) << 4)) = kf[s];
   }
   V8 qf[4][2];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) rope_rows(0, rt, lq1, lq2, p.q_scale, qf[rt]);
+  for (int rt = 0; rt < 4; ++rt) rope_rows(0, rt, 0, p.q_scale, qf[rt]);
   __syncthreads();   // K and V^T of the whole sequence are in LDS
 
   // ---------------------------------------------------------------- 3. attention over the LDS-resident keys

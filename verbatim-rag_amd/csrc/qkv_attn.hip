@@ -295,25 +295,34 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   const int ksw = (l15 >> 1) & 7;
   if (active && !(p.debug_flags & 1)) {
     for (int kt = kt_lo; kt <= kt_hi; ++kt) {
-      // 32-row group u against the 32-key half t2 of the tile: outside the band / beyond the sequence -> skipped (no MFMA,
-      // p = 0); cut by the band edge or the sequence end -> masked element by element; else mask-free
-      bool skip[2][2], tri[2][2];
+      // 32-row group u against the 32-key half t2 of the tile: `cut` = some element of the 32 x 32 block is outside the band or
+      // beyond the sequence (masked element by element; a block wholly outside is simply all -inf); `dead` = the whole 64-key
+      // tile is outside for the group (no MFMA, p = 0).  Coarse on purpose: one wave-uniform branch per group, straight-line
+      // MFMA runs inside -- a branch per skipped 16 x 16 block (as attention.hip does between barriers) chops the matrix work
+      // into pieces the scheduler cannot interleave with the softmax arithmetic.
+      bool cut[2][2], dead[2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) {
+        const int q_lo = qrow0 + 32 * u;
+        bool out_all = true;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-          const int q_lo = qrow0 + 32 * u, kh = kt * 64 + t2 * 32;
-          skip[u][t2] = kh >= S || q_lo >= S;
-          tri[u][t2] = kh + 31 >= S;
+          const int kh = kt * 64 + t2 * 32;
+          bool outside = kh >= S || q_lo >= S;
+          cut[u][t2] = kh + 31 >= S;
           if constexpr (LOCAL) {
-            skip[u][t2] = skip[u][t2] || (kh + 31 < q_lo - W) || (kh > q_lo + 31 + W);
-            tri[u][t2] = tri[u][t2] || (kh < q_lo + 31 - W) || (kh + 31 > q_lo + W);
+            outside = outside || (kh + 31 < q_lo - W) || (kh > q_lo + 31 + W);
+            cut[u][t2] = cut[u][t2] || (kh < q_lo + 31 - W) || (kh + 31 > q_lo + W);
           }
+          cut[u][t2] = cut[u][t2] || outside;
+          out_all = out_all && outside;
         }
+        dead[u] = out_all;
+      }
       V8 pf[4][2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        if (skip[u][0] && skip[u][1]) {
+        if (dead[u]) {
 #pragma unroll
           for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
@@ -331,7 +340,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          if (skip[u][kb >> 1]) continue;
           const char* krow = smem + (kt * 64 + kb * 16 + l15) * 128;
           const V8 k0 = *reinterpret_cast<const V8*>(krow + ((g ^ ksw) << 4));
           const V8 k1 = *reinterpret_cast<const V8*>(krow + (((4 + g) ^ ksw) << 4));
@@ -348,12 +356,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
           mx[cc] = -INFINITY;
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2) {
-            if (skip[u][t2]) {
-#pragma unroll
-              for (int h2 = 0; h2 < 2; ++h2) st[cc][2 * t2 + h2] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-              continue;
-            }
-            if (tri[u][t2]) {
+            if (cut[u][t2]) {
               const int qi = qrow0 + 32 * u + 16 * cc + l15;
               int lo_k = 0, hi_k = S - 1;
               if constexpr (LOCAL) {
@@ -418,16 +421,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
       // ---- O^T += V^T . P^T, l += 1 . P^T (V^T fragments read once for the four column blocks)
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
-        if (skip[0][t2] && skip[1][t2]) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (!skip[c >> 1][t2]) lo[c] = Op<T>::mfma16(ones, pf[c][t2], lo[c]);
+        for (int c = 0; c < 4; ++c) lo[c] = Op<T>::mfma16(ones, pf[c][t2], lo[c]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const V8 vf = *reinterpret_cast<const V8*>(smem + QA_V_OFF + (dt * 16 + l15) * 1024 + (((kt * 8 + t2 * 4 + g) ^ l15) << 4));
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (!skip[c >> 1][t2]) ot[c][dt] = Op<T>::mfma16(vf, pf[c][t2], ot[c][dt]);
+          for (int c = 0; c < 4; ++c) ot[c][dt] = Op<T>::mfma16(vf, pf[c][t2], ot[c][dt]);
         }
       }
     }

@@ -300,11 +300,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
       // tile is outside for the group (no MFMA, p = 0).  Coarse on purpose: one wave-uniform branch per group, straight-line
       // MFMA runs inside -- a branch per skipped 16 x 16 block (as attention.hip does between barriers) chops the matrix work
       // into pieces the scheduler cannot interleave with the softmax arithmetic.
-      bool cut[2][2], dead[2];
+      bool cut[2][2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int q_lo = qrow0 + 32 * u;
-        bool out_all = true;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
           const int kh = kt * 64 + t2 * 32;
@@ -315,28 +314,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
             cut[u][t2] = cut[u][t2] || (kh < q_lo + 31 - W) || (kh + 31 > q_lo + W);
           }
           cut[u][t2] = cut[u][t2] || outside;
-          out_all = out_all && outside;
         }
-        dead[u] = out_all;
       }
       V8 pf[4][2];
+      {
+        f32x4 st[4][4];   // S^T - reference: lane (l15 = query of column block c, g) holds keys 16 kb + 4 g + r
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (dead[u]) {
+        for (int c = 0; c < 4; ++c) {
+          const float seed = -m_run[c];
 #pragma unroll
-          for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-              for (int j = 0; j < 8; ++j) pf[2 * u + cc][t2][j] = (T)0.f;
-          continue;
-        }
-        f32x4 st[2][4];   // S^T - reference: lane (l15 = query of column block 2u + cc, g) holds keys 16 kb + 4 g + r
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const float seed = -m_run[2 * u + cc];
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) st[cc][kb] = f32x4{seed, seed, seed, seed};
+          for (int kb = 0; kb < 4; ++kb) st[c][kb] = f32x4{seed, seed, seed, seed};
         }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -344,20 +331,21 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
           const V8 k0 = *reinterpret_cast<const V8*>(krow + ((g ^ ksw) << 4));
           const V8 k1 = *reinterpret_cast<const V8*>(krow + (((4 + g) ^ ksw) << 4));
 #pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            st[cc][kb] = Op<T>::mfma16(k0, qf[2 * u + cc][0], st[cc][kb]);
-            st[cc][kb] = Op<T>::mfma16(k1, qf[2 * u + cc][1], st[cc][kb]);
+          for (int c = 0; c < 4; ++c) {
+            st[c][kb] = Op<T>::mfma16(k0, qf[c][0], st[c][kb]);
+            st[c][kb] = Op<T>::mfma16(k1, qf[c][1], st[c][kb]);
           }
         }
         // masks and in-lane maxima (scores are relative to m_run already)
-        float mx[2];
+        float mx[4];
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          mx[cc] = -INFINITY;
+        for (int c = 0; c < 4; ++c) {
+          const int u = c >> 1;
+          mx[c] = -INFINITY;
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2) {
             if (cut[u][t2]) {
-              const int qi = qrow0 + 32 * u + 16 * cc + l15;
+              const int qi = qrow0 + 16 * c + l15;
               int lo_k = 0, hi_k = S - 1;
               if constexpr (LOCAL) {
                 lo_k = max(0, qi - W);
@@ -371,24 +359,23 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const bool ok = (unsigned)(d0 + 16 * h2 + r) <= span;
-                  st[cc][2 * t2 + h2][r] = ok ? st[cc][2 * t2 + h2][r] : -INFINITY;
+                  st[c][2 * t2 + h2][r] = ok ? st[c][2 * t2 + h2][r] : -INFINITY;
                 }
             }
-            const f32x4& a = st[cc][2 * t2];
-            const f32x4& b2 = st[cc][2 * t2 + 1];
-            mx[cc] = max3f(mx[cc], max3f(a[0], a[1], a[2]), max3f(a[3], b2[0], b2[1]));
-            mx[cc] = max3f(mx[cc], b2[2], b2[3]);
+            const f32x4& a = st[c][2 * t2];
+            const f32x4& b2 = st[c][2 * t2 + 1];
+            mx[c] = max3f(mx[c], max3f(a[0], a[1], a[2]), max3f(a[3], b2[0], b2[1]));
+            mx[c] = max3f(mx[c], b2[2], b2[3]);
           }
         }
         // move the reference?  (wave-uniform; steady state: no)
         bool move = false;
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) move = move || mx[cc] > QA_LAZY || (!seen[2 * u + cc] && mx[cc] > -INFINITY);
+        for (int c = 0; c < 4; ++c) move = move || mx[c] > QA_LAZY || (!seen[c] && mx[c] > -INFINITY);
         if (__any(move)) {
 #pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            const int c = 2 * u + cc;
-            float m_all = fmaxf(mx[cc], __shfl_xor(mx[cc], 16, 64));   // over the four lane groups of the query
+          for (int c = 0; c < 4; ++c) {
+            float m_all = fmaxf(mx[c], __shfl_xor(mx[c], 16, 64));   // over the four lane groups of the query
             m_all = fmaxf(m_all, __shfl_xor(m_all, 32, 64));
             const bool has = m_all > -INFINITY;
             const float delta = seen[c] ? fmaxf(m_all, 0.f) : (has ? m_all : 0.f);
@@ -400,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) st[cc][kb][r] -= delta;
+              for (int r = 0; r < 4; ++r) st[c][kb][r] -= delta;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -412,11 +399,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         // p = exp2(s - m) straight into the B-operand fragments of O^T += V^T . P^T: k-slot (g, j) of the 32-key step t2 is the
         // accumulator row j & 3 of key block 2 t2 + (j >> 2)
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[2 * u + cc][t2][j] = (T)__builtin_amdgcn_exp2f(st[cc][2 * t2 + (j >> 2)][j & 3]);
+            for (int j = 0; j < 8; ++j) pf[c][t2][j] = (T)__builtin_amdgcn_exp2f(st[c][2 * t2 + (j >> 2)][j & 3]);
       }
       // ---- O^T += V^T . P^T, l += 1 . P^T (V^T fragments read once for the four column blocks)
 #pragma unroll

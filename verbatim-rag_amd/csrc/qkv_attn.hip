@@ -109,7 +109,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     if (wave == 2 || wave == 3) {   // rows 0 .. 15 (8 rows of 128 bytes per instruction)
       const float* tab = wave == 2 ? p.rope_cos : p.rope_sin;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) glds16(tab + (i * 8 + (lane >> 3)) * 32 + (lane & 7) * 4, smem + (wave == 2 ? QA_CB : QA_SB) + i * 1024);
+      for (int i = 0; i < 2; ++i) {   // 16-byte chunk index XOR (row >> 1) & 7: the epilogue reads one chunk of 16 DIFFERENT rows per lane group
+        const int r = i * 8 + (lane >> 3);
+        glds16(tab + r * 32 + (((lane & 7) ^ ((r >> 1) & 7)) << 2), smem + (wave == 2 ? QA_CB : QA_SB) + i * 1024);
+      }
     }
     if (wave == 4 || wave == 5) {   // rows 16 b
       const float* tab = wave == 4 ? p.rope_cos : p.rope_sin;
@@ -224,8 +227,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
       const int dd = np * 16 + 4 * g;
       const f32x4 ca = *reinterpret_cast<const f32x4*>(smem + QA_CA + ((4 * wave + rt) * 32 + dd) * 4);
       const f32x4 sa = *reinterpret_cast<const f32x4*>(smem + QA_SA + ((4 * wave + rt) * 32 + dd) * 4);
-      const f32x4 cb = *reinterpret_cast<const f32x4*>(smem + QA_CB + (l15 * 32 + dd) * 4);
-      const f32x4 sb = *reinterpret_cast<const f32x4*>(smem + QA_SB + (l15 * 32 + dd) * 4);
+      const int bsw = l15 * 128 + ((((dd >> 2) ^ ((l15 >> 1) & 7))) << 4);
+      const f32x4 cb = *reinterpret_cast<const f32x4*>(smem + QA_CB + bsw);
+      const f32x4 sb = *reinterpret_cast<const f32x4*>(smem + QA_SB + bsw);
       f32x4 l1 = {0.f, 0.f, 0.f, 0.f}, l2 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (FOLD) {
         l1 = *reinterpret_cast<const f32x4*>(l_ls + ls_off + dd);

@@ -516,19 +516,20 @@ def main() -> None:
             traffic, traffic_src = None, None
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
                 if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-            if cands:      # PMC passes cannot run inside this process: the newest committed summary of tools/profile_round.sh
+            # PMC passes cannot run inside this process: a committed summary of tools/profile_round.sh.  A summary measured on OTHER
+            # kernels is not this build's traffic: it must carry the hash of the kernel sources it was taken from
+            # (tools/pmc_traffic.py) and that hash must be the current one.
+            for cand in reversed(cands):
                 try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-                    keys = classes[dom]
-                    vals = [tj[k]["hbm_bytes_per_launch"] for k in keys if k in tj and tj[k].get("hbm_bytes_per_launch")]
-                    # a summary measured on OTHER kernels is not this build's traffic: it must carry the hash of the GEMM
-                    # source it was taken from (tools/pmc_traffic.py) and that hash must be the current one
-                    if vals and tj.get("_gemm_source_sha16") == _gemm_source_sha16():
-                        traffic, traffic_src = float(np.mean(vals)), cands[-1]
-                    elif vals:
-                        traffic_src = f"{cands[-1]} is stale (GEMM source changed since): re-run tools/profile_round.sh"
+                    tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 except Exception:
-                    traffic = None
+                    continue
+                vals = [tj[k]["hbm_bytes_per_launch"] for k in classes[dom] if k in tj and tj[k].get("hbm_bytes_per_launch")]
+                if vals and tj.get("_gemm_source_sha16") == _gemm_source_sha16():
+                    traffic, traffic_src = float(np.mean(vals)), cand
+                    break
+                if vals and traffic_src is None:
+                    traffic_src = f"{cand} is stale (kernel sources changed since): re-run tools/profile_round.sh"
             # algorithmic HBM bytes per launch of the class: the residual GEMMs are the sum of an MFMA
             # main loop and an HBM-speed fp32 read-modify-write epilogue, so both fractions are reported
             M_mb = min(args.micro_batch_tokens or n_chunks * SEQ, n_chunks * SEQ)

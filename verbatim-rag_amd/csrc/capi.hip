@@ -197,6 +197,7 @@ struct MicroBatch {
   int lblk0, lblk1;  // banded-layer q-block range
   int seq0 = 0, seq1 = 0;   // sequences of the micro-batch
   int max_len = 0;          // longest of them
+  int tokens = 0;           // their lengths summed
 };
 
 struct ProfRec {
@@ -501,8 +502,12 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       const bool consumer_stats = fold && gemm_consumer_finalizes(M);
       // sequences of <= 512 tokens, throughput-sized micro-batch: one kernel per (sequence, head) instead of the QKV GEMM and the
       // attention launch -- Q, K and V^T never leave the CU (qkv_attn.hip)
+      // The fused kernel spends a 512-token workgroup per (sequence, head) whatever the sequence's length (waves past its end
+      // idle): it wins from a mean length of ~350 tokens up and loses below (tools/bench_seq_len.py: 49.4 vs 40.6 ms per
+      // 131 072-token step at 192 tokens, 39.2 vs 42.0 at 512), so short-chunk batches keep the packed two-kernel path.
       const bool fused_attn = e->fused_qkv_attn && L.wqkv_h && mb.max_len <= kFusedMaxSeq &&
-                              (!gemm_consumer_finalizes(M) || e->fused_qkv_attn == 2);
+                              (e->fused_qkv_attn == 2 ||
+                               (!gemm_consumer_finalizes(M) && (int64_t)mb.tokens >= (int64_t)kFusedMinMeanLen * (mb.seq1 - mb.seq0)));
       auto finalize_stats = [&](bool first, bool for_qkv = false) -> int {
         if (consumer_stats && !(for_qkv && fused_attn)) return VRAG_OK;
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
@@ -1444,7 +1449,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
     t = (int)align_up(t, kSeqAlign);
     if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
       const int row1 = (int)align_up(t, kRowPad);
-      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, s, mb_max_len});
+      e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, s, mb_max_len, mb_tokens});
       mb_seq0 = s;
       mb_max_len = 0;
       t = row1;
@@ -1501,7 +1506,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   }
   // rows up to max(rows, previous rows) get pad ids so stale tokens of an older batch vanish
   const int fill_to = std::min(e->cap_rows, std::max(rows, prev_rows));
-  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, n_seqs, mb_max_len});
+  e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, n_seqs, mb_max_len, mb_tokens});
   e->n_seqs = n_seqs;
   e->n_tokens = (int)total;
   e->rows = rows;

@@ -88,6 +88,35 @@ def test_final_hidden_and_padding_free_batching(tiny):
     assert np.array_equal(alone, got[33:33 + 510])
 
 
+def test_sharp_attention_rows_vs_oracle():
+    """Random-init weights give near-uniform attention, where a wrong softmax reference or a masking slip hides.  Here the q and k
+    rows of Wqkv are scaled by 8 (logit standard deviation ~3-4, row maxima above +10: a few keys carry most of a row's mass),
+    over lengths on and off the 64-key tile grid and both layer types -- the lazy running reference of the fused QKV + attention
+    kernel (tests/test_fused_attention_gpu.py runs this module through it) has to move, the banded masks have to cut."""
+    cfg = O.EncoderConfig(**TINY)
+    w = dict(O.random_weights(cfg, seed=21))
+    H = cfg.hidden_size
+    for l in range(cfg.num_hidden_layers):
+        wq = w[f"layers.{l}.attn.Wqkv.weight"].copy()
+        wq[: 2 * H] *= 8.0
+        w[f"layers.{l}.attn.Wqkv.weight"] = wq
+    eng = _engine(cfg, w, max_tokens=4096, max_seqs=32, max_seq_len=512, max_ranges=64)
+    try:
+        rng = np.random.default_rng(22)
+        seqs = _seqs(rng, [512, 200, 65, 130, 447, 64, 9], cfg.vocab_size)
+        eng.load_batch(seqs)
+        eng.run()
+        got = eng.read_hidden(final_norm=True)
+        o = 0
+        for s in seqs:
+            ref = O.encoder_forward(cfg, w, s)
+            err = np.abs(got[o:o + len(s)] - ref)
+            assert err.max() < 6e-2 and err.mean() < 6e-3, f"S={len(s)} max {err.max()} mean {err.mean()}"
+            o += len(s)
+    finally:
+        eng.close()
+
+
 def test_qa_logits_within_1e3(tiny):
     cfg, w, eng = tiny
     rng = np.random.default_rng(11)

@@ -12,14 +12,18 @@
 //      q and k products are issued "swapped" (lane = token, registers = 4 consecutive features), v
 //      un-swapped (lane = feature, registers = 4 consecutive tokens) -- the layouts the attention operands want.
 //   2. epilogue in registers: LayerNorm fold, RoPE (the (d, d + 32) partners sit in the same lane), q scaled by
-//      head_dim^-1/2 log2 e.  K rows and V^T rows go to LDS (64 KiB each, over the operand ring), Q stays in registers as
+//      head_dim^-1/2 log2 e.  K rows and V^T rows go to LDS (64 KiB each, over the operand buffers), Q stays in registers as
 //      the B operand of S^T = K . Q^T.  The k-slot <-> feature map of an accumulator pair, slot j of step s <-> feature
 //      (2 s + j / 4) * 16 + 4 g + j % 4 (g = lane >> 4), is used for Q and K alike (a dot product does not care), and the
 //      same map over keys pairs P (straight from the S^T accumulators) with V^T: no shuffles, no transposes.
+//      Row statistics, fold sums and rotary rows (48 table rows, angle addition) arrive by DMA at kernel start and are read
+//      from LDS: no global round trip between the main loop and attention.
 //   3. attention: every wave walks the 64-key tiles of its band (global: all of them) on the LDS-resident K / V^T -- no
-//      DMA, no barriers, waves run free; online softmax in exp2 units, per-lane partial row sums.
+//      DMA, no barriers, waves run free; softmax in exp2 units with a lazily moved reference that rides into the S^T MFMAs
+//      as their C operand, row sums from an all-ones MFMA (the arithmetic of attn2_fwd_kernel, attention.hip).
 //   4. O rows are staged through LDS and stored as whole 128-byte head rows.
-// Sequences longer than 512 tokens, BERT-family encoders and launch-bound batches keep the two-kernel path.
+// Sequences longer than 512 tokens, BERT-family encoders, launch-bound batches and batches of short sequences (mean length
+// below kFusedMinMeanLen: a 512-token workgroup per sequence wastes its idle waves) keep the two-kernel path.
 #include "qkv_attn.h"
 
 #include <cstdlib>

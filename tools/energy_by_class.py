@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=5.0)
     ap.add_argument("--tokens", type=int, default=65536)
     ap.add_argument("--out", default="gpurun_out/energy_by_class.json")
+    ap.add_argument("--only", default="", help="comma-separated substrings of class names to run")
     args = ap.parse_args()
     lib = _lib.load()
     hw = _hwmon()
@@ -76,7 +77,12 @@ def main():
         ("mainloop N=768 K=1152 (EPI_NONE)", "gemm", (7, M, H, I), 2.0 * M * H * I),
         ("attn_global (S=512)", "attn", (0, M // S, S, H, 64), 4.0 * M * S * H),
         ("attn_local (S=512, |i-j|<=64)", "attn", (1, M // S, S, H, 64), 4.0 * M * 129 * H),
+        # the fused Wqkv + RoPE + attention kernel (csrc/qkv_attn.hip): replaces gemm_qkv + attn_* of its layers
+        ("qkv_attn fused global (S=512)", "fused", (0, M // S, S, H, 64), 2.0 * M * 3 * H * H + 4.0 * M * S * H),
+        ("qkv_attn fused banded (S=512, |i-j|<=64)", "fused", (1, M // S, S, H, 64), 2.0 * M * 3 * H * H + 4.0 * M * 129 * H),
     ]
+    if args.only:
+        classes = [c for c in classes if any(t in c[0] for t in args.only.split(","))]
     idle = [read_power(hw) for _ in range(5) if time.sleep(0.2) is None]
     idle_w = sum(w for w in idle if w) / max(1, len([w for w in idle if w]))
     out = {"power_source": hw or "rocm-smi --showpower", "idle_w": idle_w, "tokens_per_launch": M, "classes": {}}
@@ -85,6 +91,8 @@ def main():
         ms = C.c_float()
         if kind == "gemm":
             _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
+        elif kind == "fused":
+            _lib.check("fused", lib.vrag_debug_qkv_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, 0, C.byref(ms)))
         else:
             _lib.check("attn", lib.vrag_debug_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, C.byref(ms)))
         return ms.value
@@ -114,10 +122,16 @@ def main():
     # the step = 22 layers x 2 micro-batches of (qkv, attention, wo, wi, wo_mlp): energy budget per class
     per_step = {"gemm_qkv (EPI_QKV_ROPE, N=2304 K=768)": 44, "gemm_wi (EPI_GEGLU, N=2304 K=768)": 44, "gemm_wo (EPI_RESIDUAL, N=768 K=768)": 44,
                 "gemm_wo_mlp (EPI_RESIDUAL, N=768 K=1152)": 44, "attn_global (S=512)": 16, "attn_local (S=512, |i-j|<=64)": 28}
+    # with the fused kernel (the default for this batch): 16 + 28 launches of it instead of 44 QKV GEMMs and 44 attention launches
+    per_step_fused = {"qkv_attn fused global (S=512)": 16, "qkv_attn fused banded (S=512, |i-j|<=64)": 28, "gemm_wi (EPI_GEGLU, N=2304 K=768)": 44,
+                      "gemm_wo (EPI_RESIDUAL, N=768 K=768)": 44, "gemm_wo_mlp (EPI_RESIDUAL, N=768 K=1152)": 44}
+    if all(k in out["classes"] for k in per_step_fused):
+        out["joules_per_step_sum_fused_schedule"] = sum(out["classes"][k].get("joules_per_launch", 0) * n for k, n in per_step_fused.items())
+        out["ms_per_step_sum_isolated_fused_schedule"] = sum(out["classes"][k]["us_per_launch"] * n for k, n in per_step_fused.items()) / 1e3
     step = {k: out["classes"][k].get("joules_per_launch", 0) * n for k, n in per_step.items() if k in out["classes"]}
     out["joules_per_step_by_class"] = step
     out["joules_per_step_sum"] = sum(step.values())
-    out["ms_per_step_sum_isolated"] = sum(out["classes"][k]["us_per_launch"] * n for k, n in per_step.items()) / 1e3
+    out["ms_per_step_sum_isolated"] = sum(out["classes"][k]["us_per_launch"] * n for k, n in per_step.items() if k in out["classes"]) / 1e3
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("idle_w", "joules_per_step_by_class", "joules_per_step_sum", "ms_per_step_sum_isolated")}))

@@ -1048,6 +1048,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
       TRY(dev_alloc(e, &ly.wqkv_h, (size_t)3 * H * H, false));
       if (ly.s_qkv) TRY(dev_alloc(e, &ly.s_qkv_h, (size_t)3 * H + 64));   // the kernel's 256-float DMA of a head's 192 sums reads 64 floats on
       HIP_TRY(permute_qkv_heads(ly.wqkv, ly.s_qkv, H, cfg->num_heads, ly.wqkv_h, ly.s_qkv_h, nullptr));
+      HIP_TRY(hipDeviceSynchronize());   // null-stream work does not order against the handle's non-blocking streams
     }
     TRY(upload_bf16(e, &ly.wo, w->wo[l], H, H, H, 0, stage, stage_elems));
     TRY(upload_bf16(e, &ly.wi, w->wi[l], 2 * I, H, 2 * Ip, I, stage, stage_elems, fold ? ly.mlp_norm : nullptr,

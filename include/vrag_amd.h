@@ -339,6 +339,19 @@ int vrag_split_sentences(const uint8_t* text, const int64_t* doc_off /*[n_docs+1
                          int32_t* counts /*[n_docs]*/, int32_t* starts /*[n_docs, cap]*/, int32_t* ends /*[n_docs, cap]*/,
                          int32_t device);
 
+/* Host-side packer of the (question, chunk) pairs of ONE question for the sentence-classification extractor -- the layout
+ *   [CLS] q [SEP] s1 [SEP] s2 ... ([SEP])   with inclusive token ranges per sentence, budget = max_length - 2, sentences that do
+ * not fit dropped from the first one that does not (extractor_models/dataset.py:127-243).  The question-independent pieces of a
+ * chunk are cached by the caller: tail = [SEP] s1 [SEP] s2 ... (int32) and cum[i] = tokens of the first i + 1 `[SEP] sentence`
+ * groups (int64); tails[p] / cums[p] are their ADDRESSES for pair p, n_groups[p] the sentence count.  q_ids = the question's ids
+ * without a trailing [SEP] (q_len of them).  Per pair: kept[p] sentences fit (0 = none: the caller's general routine decides),
+ * seq_lens[p] ids are appended to ids_out, kept[p] ranges to starts_out / ends_out; totals_out = {ids, ranges} written.
+ * Pure host code (no device, no allocation); VRAG_ERR_CAPACITY when an output capacity would be exceeded. */
+int vrag_pack_qa_pairs(const int32_t* q_ids, int32_t q_len, int32_t n_pairs, const uint64_t* tails, const uint64_t* cums,
+                       const int32_t* n_groups, int32_t budget, int32_t sep_id, int32_t* ids_out, int64_t ids_cap,
+                       int64_t* starts_out, int64_t* ends_out, int64_t ranges_cap, int32_t* seq_lens /*[n_pairs]*/,
+                       int32_t* kept /*[n_pairs]*/, int64_t* totals_out /*[2]*/);
+
 /* -inf / -1 lists in device memory: the contribution of a rank that holds none of the rows. */
 int vrag_topk_fill_empty(float* scores /*[n] device*/, int64_t* ids /*[n] device*/, int64_t n, int32_t device, void* stream);
 

@@ -168,3 +168,23 @@ def test_highlighter_cross_query_batching_host_logic(tokenizer):
     want = [ext.extract_spans(q, r) for q, r in zip(qs, rs)]
     assert got == want and got[1][""] == [] and eng.batches - n_batched >= n_batched > 1
     assert all(s in c for d in got for c, spans in d.items() for s in spans) and any(v for d in got for v in d.values())
+
+
+def test_native_packer_equals_the_python_fast_path(tokenizer):
+    """`_pack_fast_many` (one `vrag_pack_qa_pairs` call per question: host code of the C ABI) against `_pack_fast` chunk by chunk:
+    same ids, same inclusive ranges, None in the same places (question at the budget, empty sentence, nothing fits)."""
+    rng = np.random.default_rng(8)
+    for qa_max_length in (512, 96, 40, 12):
+        ext = GpuModelSpanExtractor(engine=RecordingEngine(), tokenizer=tokenizer, threshold=0.5, qa_max_length=qa_max_length)
+        texts = [_text(rng, int(rng.integers(1, 20)), 2, 40) for _ in range(40)] + ["", "x.", _text(rng, 1, 300, 400)]
+        entries = ext._entries(texts) + [ext._cache_entry(["a.", "​", "b."], [[5], [], [7]])]
+        for question in ("what?", "", _text(rng, 1, 6, 9), _text(rng, 1, 60, 90)):
+            q_ids = ext._tok.ids(question, add_special_tokens=True, max_length=qa_max_length - 2)
+            many = ext._pack_fast_many(q_ids, entries)
+            assert len(many) == len(entries)
+            for e, got in zip(entries, many):
+                want = ext._pack_fast(q_ids, e) if e[0] else None
+                assert (got is None) == (want is None), (qa_max_length, question[:20], e[0][:2])
+                if want is not None:
+                    assert got[0].dtype == np.int32 and got[1].dtype == np.int64
+                    assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist() and got[2].tolist() == want[2].tolist()

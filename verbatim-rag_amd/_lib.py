@@ -123,6 +123,8 @@ SIGNATURES = {
                                                  C.c_void_p, C.c_void_p]),
     "vrag_sparse_index_search_device": (C.c_int, [_H, _LP, _IP, _FP, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vrag_pack_qa_pairs": (C.c_int, [_IP, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _IP, C.c_int32, C.c_int32, _IP, C.c_int64,
+                                      _LP, _LP, C.c_int64, _IP, _IP, _LP]),
     "vrag_split_sentences": (C.c_int, [C.c_void_p, _LP, C.c_int32, C.c_int32, _IP, _IP, _IP, C.c_int32]),
     "vrag_topk_fill_empty": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "vrag_sparse_index_create": (C.c_int, [C.c_int32, C.c_int64, _LP, _IP, _FP, C.c_int32, C.POINTER(_H)]),

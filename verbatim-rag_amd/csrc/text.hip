@@ -9,6 +9,7 @@
 #include "../../include/vrag_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include <cstdint>
 
@@ -152,5 +153,57 @@ extern "C" int vrag_split_sentences(const uint8_t* text, const int64_t* doc_off,
   if (e != hipSuccess) return fail(e);
   for (void* p : {(void*)d_text, (void*)d_off, (void*)d_counts, (void*)d_starts, (void*)d_ends}) (void)hipFree(p);
   (void)hipStreamDestroy(st);
+  return VRAG_OK;
+}
+
+// Host code: the question-dependent half of the packer for all pairs of one question (see include/vrag_amd.h).
+extern "C" int vrag_pack_qa_pairs(const int32_t* q_ids, int32_t q_len, int32_t n_pairs, const uint64_t* tails, const uint64_t* cums,
+                                  const int32_t* n_groups, int32_t budget, int32_t sep_id, int32_t* ids_out, int64_t ids_cap,
+                                  int64_t* starts_out, int64_t* ends_out, int64_t ranges_cap, int32_t* seq_lens, int32_t* kept,
+                                  int64_t* totals_out) {
+  if (!q_ids || !tails || !cums || !n_groups || !ids_out || !starts_out || !ends_out || !seq_lens || !kept || !totals_out ||
+      q_len < 0 || n_pairs < 0 || budget <= 0) {
+    set_error("vrag_pack_qa_pairs: bad arguments");
+    return VRAG_ERR_INVALID;
+  }
+  int64_t n_ids = 0, n_rng = 0;
+  const int64_t room = (int64_t)budget - q_len;   // tokens left for `[SEP] sentence` groups
+  for (int32_t p = 0; p < n_pairs; ++p) {
+    const int32_t* tail = reinterpret_cast<const int32_t*>(tails[p]);
+    const int64_t* cum = reinterpret_cast<const int64_t*>(cums[p]);
+    const int32_t ng = n_groups[p];
+    int32_t m = 0;
+    if (room > 0 && ng > 0 && tail && cum) {   // groups with q_len + cum[i] <= budget: a prefix (cum is increasing)
+      int32_t lo = 0, hi = ng;
+      while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (cum[mid] <= room) lo = mid + 1;
+        else hi = mid;
+      }
+      m = lo;
+    }
+    kept[p] = m;
+    seq_lens[p] = 0;
+    if (m == 0) continue;
+    const int64_t body = cum[m - 1], n = q_len + body;
+    const int32_t len = (int32_t)(n + (n < budget ? 1 : 0));   // a closing [SEP] if it fits (dataset.py:202-205)
+    if (n_ids + len > ids_cap || n_rng + m > ranges_cap) {
+      set_error("vrag_pack_qa_pairs: output capacity exceeded at pair %d", p);
+      return VRAG_ERR_CAPACITY;
+    }
+    int32_t* dst = ids_out + n_ids;
+    memcpy(dst, q_ids, (size_t)q_len * sizeof(int32_t));
+    memcpy(dst + q_len, tail, (size_t)body * sizeof(int32_t));
+    if (n < budget) dst[n] = sep_id;
+    for (int32_t i = 0; i < m; ++i) {   // inclusive ranges: group i = [SEP] at q_len + cum[i-1], sentence behind it
+      starts_out[n_rng + i] = q_len + (i ? cum[i - 1] : 0) + 1;
+      ends_out[n_rng + i] = q_len + cum[i] - 1;
+    }
+    seq_lens[p] = len;
+    n_ids += len;
+    n_rng += m;
+  }
+  totals_out[0] = n_ids;
+  totals_out[1] = n_rng;
   return VRAG_OK;
 }

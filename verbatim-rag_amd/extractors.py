@@ -315,14 +315,15 @@ class GpuModelSpanExtractor(SpanExtractor):
         sep = self._tok.sep_token_id
         tail = np.fromiter((x for sent in ids for x in [sep, *sent]), dtype=np.int32) if ids else np.zeros(0, np.int32)
         cum = np.cumsum([len(sent) + 1 for sent in ids], dtype=np.int64) if ids else np.zeros(0, np.int64)
-        return (sents, ids, tail, cum, all(len(sent) > 0 for sent in ids))
+        # the addresses of tail / cum ride along for the native packer (vrag_pack_qa_pairs): the arrays live in this tuple
+        return (sents, ids, tail, cum, all(len(sent) > 0 for sent in ids), tail.ctypes.data, cum.ctypes.data)
 
     def _pack_fast(self, q_ids: List[int], entry):
         """The packer (packing.encode_question_and_sentences, dataset.py:127-243) on the cached pieces: the sentences
         that fit are a prefix (the reference stops at the first one that does not), so the cut is one searchsorted.
         Returns (input ids, inclusive starts, inclusive ends) or None when the general routine must decide (the
         question alone reaches the budget, or a sentence without tokens makes an empty range)."""
-        sents, ids, tail, cum, no_empty = entry
+        sents, ids, tail, cum, no_empty = entry[:5]
         budget = self.qa_max_length - 2
         q = q_ids[:-1] if len(q_ids) > 1 and q_ids[-1] == self._tok.sep_token_id else q_ids
         qlen = len(q)
@@ -344,6 +345,50 @@ class GpuModelSpanExtractor(SpanExtractor):
         if m < len(cum):
             logger.warning("Legacy QA input exceeded the %d-token budget; dropping %d sentence(s)", budget + 2, len(cum) - m)
         return out, starts, ends
+
+    def _pack_fast_many(self, q_ids: List[int], entries):
+        """`_pack_fast` for every chunk of ONE question in one native call (`vrag_pack_qa_pairs`, host code of the C ABI): element
+        i is what `_pack_fast(q_ids, entries[i])` returns -- views into three flat arrays instead of a dozen small numpy
+        operations per chunk (3-4 ms of interpreter time per 256-chunk call: a tenth of the device time at 512 tokens)."""
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        if lib is None:   # the CPU test suites stub the library out: the same packer, chunk by chunk, in numpy
+            return [self._pack_fast(q_ids, e) if e[0] else None for e in entries]
+        res = [None] * len(entries)
+        budget = self.qa_max_length - 2
+        q = q_ids[:-1] if len(q_ids) > 1 and q_ids[-1] == self._tok.sep_token_id else q_ids
+        qlen = len(q)
+        idx = [i for i, e in enumerate(entries) if e[0] and e[4] and len(e[3])] if qlen < budget else []
+        if not idx:
+            return res
+        n = len(idx)
+        ng = [len(entries[i][3]) for i in idx]
+        tails = (C.c_uint64 * n)(*[entries[i][5] for i in idx])
+        cums = (C.c_uint64 * n)(*[entries[i][6] for i in idx])
+        ng_a = np.asarray(ng, np.int32)
+        q_a = np.asarray(q, np.int32) if qlen else np.zeros(1, np.int32)
+        ids_out = np.empty(n * budget, np.int32)
+        n_rng = int(ng_a.sum())
+        starts, ends = np.empty(n_rng, np.int64), np.empty(n_rng, np.int64)
+        seq_lens, kept, totals = np.empty(n, np.int32), np.empty(n, np.int32), np.zeros(2, np.int64)
+        ip, lp = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        _lib.check("vrag_pack_qa_pairs", lib.vrag_pack_qa_pairs(
+            q_a.ctypes.data_as(ip), qlen, n, tails, cums, ng_a.ctypes.data_as(ip), budget, self._tok.sep_token_id,
+            ids_out.ctypes.data_as(ip), ids_out.size, starts.ctypes.data_as(lp), ends.ctypes.data_as(lp), n_rng,
+            seq_lens.ctypes.data_as(ip), kept.ctypes.data_as(ip), totals.ctypes.data_as(lp)))
+        io = ro = 0
+        for i, m, ln, g in zip(idx, kept.tolist(), seq_lens.tolist(), ng):
+            if m == 0:
+                continue                                   # nothing fits: the general routine decides (and logs)
+            res[i] = (ids_out[io:io + ln], starts[ro:ro + m], ends[ro:ro + m])
+            io += ln
+            ro += m
+            if m < g:
+                logger.warning("Legacy QA input exceeded the %d-token budget; dropping %d sentence(s)", budget + 2, g - m)
+        return res
 
     def _extract_qa_model(self, question: str, search_results: List[Any]) -> Dict[str, List[str]]:
         return self.extract_spans_batch([question], [search_results])[0]
@@ -380,10 +425,12 @@ class GpuModelSpanExtractor(SpanExtractor):
                 texts = [getattr(r, "text", "") for r in results]
                 out.append({t: [] for t in texts})
                 q_ids = self._tok.ids(question, add_special_tokens=True, max_length=budget)
-                for i, (t, entry) in enumerate(zip(texts, self._entries(texts))):
+                entries = self._entries(texts)
+                fasts = self._pack_fast_many(q_ids, entries)
+                for i, (t, entry) in enumerate(zip(texts, entries)):
                     if not entry[0]:
                         continue                              # blank chunk -> [] (extractors.py:209-211)
-                    fast = self._pack_fast(q_ids, entry)
+                    fast = fasts[i]
                     if fast is not None:
                         add((qi, t, entry[0], fast[0], fast[1], fast[2]))
                         continue
@@ -432,10 +479,17 @@ class GpuModelSpanExtractor(SpanExtractor):
                 if self._f16_clamped(engine):
                     return self._run_sub_batch(batch, out, which)          # once more, on the bf16 engines
                 keep = softmax_rows(flat)[:, 1] > self.threshold
-                o = 0
-                for (qi, text, sents, _ids, _st, _en), c in zip(batch, counts.tolist()):
-                    out[qi][text] = [sents[i] for i in np.nonzero(keep[o:o + c])[0].tolist() if i < len(sents)]
-                    o += c
+                # selected sentences chunk by chunk, from ONE nonzero over the batch's ranges (every chunk starts as [])
+                sel = np.nonzero(keep)[0]
+                ends = np.cumsum(counts)
+                owner = np.searchsorted(ends, sel, side="right")
+                local = sel - (ends - counts)[owner]
+                picked: Dict[int, List[int]] = {}
+                for b, i in zip(owner.tolist(), local.tolist()):
+                    picked.setdefault(b, []).append(i)
+                for b, (qi, text, sents, _ids, _st, _en) in enumerate(batch):   # in batch order: a chunk listed twice keeps its last evaluation
+                    idx = picked.get(b)
+                    out[qi][text] = [sents[i] for i in idx if i < len(sents)] if idx else []
             except Exception as exc:  # same contract as extractors.py:225-227: log, [] for the chunk(s)
                 logger.error("GPU span extraction failed: %s", exc)
 

@@ -90,13 +90,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   const char* const Wb = reinterpret_cast<const char*>(Wh);
   char* const xbuf = smem + QA_XOFF + wave * 8192;
   // one DMA instruction of the next stage: weight rows (i < 3, 8 rows each) or this wave's token rows (i < 8)
+  // The lane offset is re-read through an opaque asm at every use: otherwise the eleven 64-bit lane addresses are hoisted out
+  // of the K loop as loop invariants -- 22 registers the loop does not have, i.e. spills and reloads in front of every DMA.
   auto dma_w = [&](int kt, int buf, int i) {
     if (p.debug_flags & 4) return;
-    glds16(Wb + kt * 128 + voffW[i], smem + buf * QA_WB + (wave * 24 + i * 8) * 128);
+    unsigned vo = voffW[i];
+    asm volatile("" : "+v"(vo));
+    glds16(Wb + kt * 128 + vo, smem + buf * QA_WB + (wave * 24 + i * 8) * 128);
   };
   auto dma_x = [&](int kt, int i) {
     if (!active || (p.debug_flags & 4)) return;
-    glds16(Xw + ((size_t)(i >> 1) * 16 * H + kt * 64) * 2 + voffX[i & 1], xbuf + i * 1024);
+    unsigned vo = voffX[i & 1];
+    asm volatile("" : "+v"(vo));
+    glds16(Xw + ((size_t)(i >> 1) * 16 * H + kt * 64) * 2 + vo, xbuf + i * 1024);
   };
 
   // Everything the epilogue gathers -- the row statistics of the sequence, the head's fold sums, rotary rows -- comes in by DMA

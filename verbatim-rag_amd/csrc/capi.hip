@@ -503,8 +503,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       // sequences of <= 512 tokens, throughput-sized micro-batch: one kernel per (sequence, head) instead of the QKV GEMM and the
       // attention launch -- Q, K and V^T never leave the CU (qkv_attn.hip)
       // The fused kernel spends a 512-token workgroup per (sequence, head) whatever the sequence's length (waves past its end
-      // idle): it wins from a mean length of ~350 tokens up and loses below (tools/bench_seq_len.py: 49.4 vs 40.6 ms per
-      // 131 072-token step at 192 tokens, 39.2 vs 42.0 at 512), so short-chunk batches keep the packed two-kernel path.
+      // idle): it wins from a mean length of ~270 tokens up and loses below (tools/bench_seq_len.py: 42.7 vs 38.6 ms per
+      // 131 072-token step at 192 tokens, a tie at 256, 35.8 vs 39.9 at 512), so short-chunk batches keep the packed two-kernel path.
       const bool fused_attn = e->fused_qkv_attn && L.wqkv_h && mb.max_len <= kFusedMaxSeq &&
                               (e->fused_qkv_attn == 2 ||
                                (!gemm_consumer_finalizes(M) && (int64_t)mb.tokens >= (int64_t)kFusedMinMeanLen * (mb.seq1 - mb.seq0)));

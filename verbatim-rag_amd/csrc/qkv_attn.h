@@ -5,7 +5,7 @@
 namespace vrag {
 
 constexpr int kFusedMaxSeq = 512;   // tokens one workgroup holds: 8 waves x 64 rows
-constexpr int kFusedMinMeanLen = 352;   // mean sequence length of a micro-batch from which the kernel beats the two-kernel path
+constexpr int kFusedMinMeanLen = 288;   // mean sequence length of a micro-batch from which the kernel beats the two-kernel path (profiles/r03_fused_by_sequence_length.txt)
 
 struct QkvAttnParams {
   const bf16_t* x;         // [Tp, H] the Wqkv GEMM's A operand rows (op16(h - c) under the LayerNorm fold, else LN(h))

@@ -188,3 +188,37 @@ def test_native_packer_equals_the_python_fast_path(tokenizer):
                 if want is not None:
                     assert got[0].dtype == np.int32 and got[1].dtype == np.int64
                     assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist() and got[2].tolist() == want[2].tolist()
+
+
+def test_native_packer_argument_and_capacity_errors():
+    """`vrag_pack_qa_pairs` through ctypes: a full output buffer is an error status with a message (never a partial, silent
+    result), null pointers are rejected, zero pairs is a no-op."""
+    import ctypes as C
+
+    from verbatim_rag_amd import _lib
+
+    lib = _lib.load()
+    ip, lp = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    q = np.asarray([1, 9, 9], np.int32)
+    tail = np.asarray([2, 5, 6, 2, 7], np.int32)            # [SEP] 5 6 [SEP] 7
+    cum = np.asarray([3, 5], np.int64)
+    tails, cums = (C.c_uint64 * 1)(tail.ctypes.data), (C.c_uint64 * 1)(cum.ctypes.data)
+    ng = np.asarray([2], np.int32)
+
+    def call(ids_cap, rng_cap, n=1, q_ptr=None):
+        ids, st, en = np.full(16, -1, np.int32), np.full(4, -1, np.int64), np.full(4, -1, np.int64)
+        lens, kept, tot = np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(2, np.int64)
+        rc = lib.vrag_pack_qa_pairs(q.ctypes.data_as(ip) if q_ptr is None else q_ptr, 3, n, tails, cums, ng.ctypes.data_as(ip), 510, 2,
+                                    ids.ctypes.data_as(ip), ids_cap, st.ctypes.data_as(lp), en.ctypes.data_as(lp), rng_cap,
+                                    lens.ctypes.data_as(ip), kept.ctypes.data_as(ip), tot.ctypes.data_as(lp))
+        return rc, ids, st, en, lens, kept, tot
+
+    rc, ids, st, en, lens, kept, tot = call(16, 4)
+    assert rc == 0 and kept[0] == 2 and lens[0] == 9 and tot.tolist() == [9, 2]
+    assert ids[:9].tolist() == [1, 9, 9, 2, 5, 6, 2, 7, 2] and st[:2].tolist() == [4, 7] and en[:2].tolist() == [5, 7]
+    for ids_cap, rng_cap in ((8, 4), (16, 1)):
+        rc = call(ids_cap, rng_cap)[0]
+        assert rc == -3 and "capacity" in _lib.last_error()          # VRAG_ERR_CAPACITY
+    assert call(16, 4, q_ptr=C.cast(None, ip))[0] == -1              # VRAG_ERR_INVALID
+    rc, *_rest, tot = call(16, 4, n=0)
+    assert rc == 0 and tot.tolist() == [0, 0]

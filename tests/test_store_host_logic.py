@@ -103,9 +103,26 @@ def test_single_comparison_filters_use_the_value_index(store):
         assert not hasattr(vs.parse_filter(flt), "lookup")       # general predicates keep the per-row evaluation
     r = st.query(dense_query=q, top_k=50, search_type="dense", filter='metadata["n"] >= 390 and document_id != "d0"')
     assert sorted(x.metadata["n"] for x in r) == [n for n in range(390, 400) if n % 3 != 0]                # range comparison
-    assert "document_id" in st._value_indexes
+    assert "document_id" in st._value_indexes and "n" in st._value_indexes
+    # inserts EXTEND the indexes that exist (no rebuild over every stored row): several inserts, new and known values,
+    # rows without the key, a key never asked for
+    before = {k: {v: sum(len(x) for x in segs) for v, segs in idx.items()} for k, idx in st._value_indexes.items()}
     st.add_vectors(["new"], [dense[0].tolist()], [sparse[0]], ["t"], ["e"], [{"document_id": "d2", "n": 1000}])
-    assert st._value_indexes == {} and st._mask('metadata["n"] == 1000').sum() == 1
+    st.add_vectors(["new2", "new3", "new4"], [dense[1].tolist()] * 3, [sparse[1]] * 3, ["t"] * 3, ["e"] * 3,
+                   [{"document_id": "d7", "n": 1000.0}, {"other": 1}, {"document_id": "d2", "n": "1000"}])
+    assert set(st._value_indexes) == {"document_id", "n", "missing"}
+    assert sum(len(x) for x in st._value_indexes["document_id"][("s", "d2")]) == before["document_id"][("s", "d2")] + 2
+    for flt in ('metadata["n"] == 1000', 'metadata["document_id"] == "d7"', 'metadata["document_id"] in ["d2", "d7"]', 'other == 1',
+                'metadata["n"] == "1000"'):
+        pred = vs.parse_filter(flt)
+        want = np.asarray([bool(pred(md)) for md in st._meta])
+        got = st._mask(flt)
+        assert np.array_equal(np.ones(len(want), bool) if got is None else got, want), flt
+    assert st._mask('metadata["n"] == 1000').sum() == 2 and all(len(segs) == 1 for segs in st._value_indexes["n"].values())
+    fresh = vs.GpuVectorStore(dense_dim=st.dense_dim, enable_sparse=False)
+    fresh.add_vectors(list(st._ids), [r.tolist() for r in st._dense_rows.data], None, list(st._texts), list(st._enh), [dict(m) for m in st._meta])
+    for flt in ('metadata["document_id"] == "d2"', 'metadata["n"] in [7, 1000]'):
+        assert np.array_equal(fresh._mask(flt), st._mask(flt)), flt
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -746,7 +746,7 @@ class GpuVectorStore(VectorStore):
         # under a running search.  (Sharded stores are SPMD: one caller thread per rank.)
         self._mu = threading.RLock()
         self._masks: Dict[str, Optional[np.ndarray]] = {}
-        self._value_indexes: Dict[str, Dict[Any, np.ndarray]] = {}
+        self._value_indexes: Dict[str, Dict[Any, List[np.ndarray]]] = {}   # key -> typed value -> row segments
         self._all_ids_truthy = True
         self._documents: Dict[str, Dict[str, Any]] = {}      # document records (add_documents / get_document)
         self._subsets: Dict[Any, Tuple[Any, np.ndarray, Any]] = {}   # (kind, mask bytes) -> (subset shard, global row of each subset row, device copy)
@@ -822,7 +822,17 @@ class GpuVectorStore(VectorStore):
                 self._sp_val.extend(new_csr[2])
             self._dirty = True
             self._drop_subsets()
-            self._value_indexes.clear()
+            # value indexes that exist are extended by the new rows' values (a segment per insert, merged on the next read):
+            # rebuilding them is a Python pass over EVERY stored row, per key, after every insert
+            meta_base = len(self._meta) - len(new_meta)
+            for key, index in self._value_indexes.items():
+                fresh: Dict[Any, List[int]] = {}
+                for j, md in enumerate(new_meta):
+                    t = _typed(md.get(key))
+                    if t is not None:
+                        fresh.setdefault(t, []).append(meta_base + j)
+                for t, rows in fresh.items():
+                    index.setdefault(t, []).append(np.asarray(rows, dtype=np.int64))
 
     def _note_id(self, key, row: int) -> None:
         have = self._id_rows.get(key)
@@ -970,8 +980,13 @@ class GpuVectorStore(VectorStore):
                     t = _typed(md.get(key))
                     if t is not None:
                         buckets.setdefault(t, []).append(i)
-                index = self._value_indexes[key] = {v: np.asarray(rows, dtype=np.int64) for v, rows in buckets.items()}
-            return index
+                index = self._value_indexes[key] = {v: [np.asarray(rows, dtype=np.int64)] for v, rows in buckets.items()}
+            out = {}
+            for v, segs in index.items():       # buckets are lists of row segments (one per insert since the build): merge on read
+                if len(segs) > 1:
+                    segs[:] = [np.concatenate(segs)]
+                out[v] = segs[0]
+            return out
 
     def _hit(self, row: int, score: float) -> dict:
         """A search hit in the shape `merge_hybrid_results` works on; the entity (text, metadata copy) is attached

@@ -264,7 +264,7 @@ def test_layernorm_fold_with_row_mean_offsets_and_outlier_channels(monkeypatch):
 
 def test_graph_replay_is_bit_identical_to_the_eager_launches():
     """Launch-bound batches (the reference's call shape: one question x k = 5 chunks, verbatim_rag/core.py:238-255) replay a
-    captured HIP graph from the third call of a geometry on: same kernels, same arguments -> the same bits as eager launches,
+    captured HIP graph from the fourth call of a geometry on: same kernels, same arguments -> the same bits as eager launches,
     for new contents of the same geometry, across geometry changes and back."""
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
 
@@ -289,7 +289,7 @@ def test_graph_replay_is_bit_identical_to_the_eager_launches():
 
     geoms = [(190, 201, 187, 170, 199), (60, 70), (300, 301, 280, 290, 310)]
     try:
-        for rep in range(4):
+        for rep in range(5):
             for gi, lens in enumerate(geoms):
                 seqs, bounds = batch(lens, 100 * rep + gi)
                 a = eager.qa_logits(seqs, bounds)
@@ -297,10 +297,49 @@ def test_graph_replay_is_bit_identical_to_the_eager_launches():
                 assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, gi)
                 assert np.array_equal(eager.read_hidden(final_norm=True), graphed.read_hidden(final_norm=True)), (rep, gi)
         replays, cached = graphed.graph_stats()
-        assert cached == len(geoms) and replays == len(geoms) * 3        # call 1 eager, call 2 capture + launch, calls 3, 4 replay
+        assert cached == len(geoms) and replays == len(geoms) * 3        # calls 1, 2 eager, call 3 capture + launch, calls 4, 5 replay
         assert eager.graph_stats() == (0, 0)
         ref = O.qa_sentence_logits(O.encoder_forward(cfg, w, seqs[0]), bounds[0], qa_w, qa_b)
         assert np.abs(b[0] - ref).max() < 1e-3
     finally:
+        eager.close()
+        graphed.close()
+
+
+def test_graph_cache_keeps_the_two_attention_paths_apart():
+    """Two batches with the same packed rows, sequence count and query-block counts, one all <= 512 tokens (fused QKV + attention
+    kernel), one holding a longer sequence (QKV GEMM + attention launch): a graph captured for one must never be replayed for the
+    other (the key now carries the attention path).  Graphs are enabled above their default row limit and the
+    small-row GEMM configuration is switched off so that these row counts take the throughput schedule."""
+    from verbatim_rag_amd import _lib
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+
+    cfg = O.EncoderConfig(**TINY)
+    w = O.random_weights(cfg, seed=11)
+    rng = np.random.default_rng(6)
+    qa_w, qa_b = rng.standard_normal((2, 128)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
+    lib = _lib.load()
+    lib.vrag_debug_set_gemm_small_m(0)
+
+    def engine(graphs):
+        e = EncoderEngine(ModernBertShape(**TINY), w, max_tokens=8192, max_seqs=64, max_seq_len=1024, max_ranges=1024)
+        e.set_qa_head(qa_w, qa_b)
+        e.graph_stats(enable=65536 if graphs else 0)
+        return e
+
+    eager, graphed = engine(False), engine(True)
+    geoms = [(512, 512, 304), (600, 512, 216), (512, 512, 304), (520, 512, 296)]   # 1 328 rows, 3 sequences each
+    try:
+        for rep in range(5):
+            for gi, lens in enumerate(geoms):
+                r = np.random.default_rng(1000 * rep + gi)
+                seqs = [r.integers(3, 512, size=n).astype(np.int32) for n in lens]
+                bounds = [[(1, n // 2), (n // 2 + 1, n - 1)] for n in lens]
+                a = eager.qa_logits(seqs, bounds)
+                b = graphed.qa_logits(seqs, bounds)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, gi, lens)
+        assert graphed.graph_stats()[0] > 0
+    finally:
+        lib.vrag_debug_set_gemm_small_m(8192)
         eager.close()
         graphed.close()

@@ -22,6 +22,8 @@ import verbatim_rag_amd  # noqa: E402,F401
 from verbatim_rag_amd import _lib  # noqa: E402
 
 POWER_RE = re.compile(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)")
+SCLK_RE = re.compile(r"sclk clock level:.*\((\d+)Mhz\)")
+LAST_SCLK = [None]
 
 
 def _hwmon():
@@ -37,7 +39,10 @@ def read_power(hw):
         except Exception:
             pass
     try:
-        m = POWER_RE.search(subprocess.run(["rocm-smi", "--showpower"], capture_output=True, text=True, timeout=10).stdout)
+        txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        m = POWER_RE.search(txt)
+        c = SCLK_RE.search(txt)
+        LAST_SCLK[0] = float(c.group(1)) if c else None
         return float(m.group(1)) if m else None
     except Exception:
         return None
@@ -47,12 +52,14 @@ class Sampler(threading.Thread):
     def __init__(self, hw, interval):
         super().__init__(daemon=True)
         self.hw, self.interval, self.samples, self.stop = hw, interval, [], threading.Event()
+        self.clocks = []
 
     def run(self):
         while not self.stop.is_set():
             w = read_power(self.hw)
             if w is not None:
                 self.samples.append((time.perf_counter(), w))
+                self.clocks.append((time.perf_counter(), LAST_SCLK[0]))
             self.stop.wait(self.interval)
 
 
@@ -75,6 +82,10 @@ def main():
         ("mainloop N=768 K=768 (EPI_NONE)", "gemm", (7, M, H, H), 2.0 * M * H * H),
         ("gemm_wo_mlp (EPI_RESIDUAL, N=768 K=1152)", "gemm", (3, M, H, I), 2.0 * M * H * I),
         ("mainloop N=768 K=1152 (EPI_NONE)", "gemm", (7, M, H, I), 2.0 * M * H * I),
+        # the residual epilogue (almost) alone: one K-step of main loop in front of it -- what does the read-modify-write phase draw?
+        ("resid epilogue-only (EPI_RESIDUAL, N=768 K=64)", "gemm", (3, M, H, 64), 2.0 * M * H * 64),
+        ("resid plain epilogue-only (no fold outputs, N=768 K=64)", "gemm_plain", (3, M, H, 64), 2.0 * M * H * 64),
+        ("geglu epilogue-only (EPI_GEGLU, N=2304 K=64)", "gemm", (4, M, 2 * I, 64), 2.0 * M * 2 * I * 64),
         ("attn_global (S=512)", "attn", (0, M // S, S, H, 64), 4.0 * M * S * H),
         ("attn_local (S=512, |i-j|<=64)", "attn", (1, M // S, S, H, 64), 4.0 * M * 129 * H),
         # the fused Wqkv + RoPE + attention kernel (csrc/qkv_attn.hip): replaces gemm_qkv + attn_* of its layers
@@ -89,7 +100,13 @@ def main():
 
     def run(kind, a, iters):
         ms = C.c_float()
-        if kind == "gemm":
+        if kind == "gemm_plain":
+            os.environ["VRAG_DEBUG_GEMM_PLAIN_RESID"] = "1"
+            try:
+                _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
+            finally:
+                del os.environ["VRAG_DEBUG_GEMM_PLAIN_RESID"]
+        elif kind == "gemm":
             _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
         elif kind == "fused":
             _lib.check("fused", lib.vrag_debug_qkv_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, 0, C.byref(ms)))
@@ -111,14 +128,15 @@ def main():
         lo = t1 - iters * ms * 1e-3 * 0.7
         busy = [w for t, w in smp.samples if lo <= t <= t1]
         avg = sum(busy) / len(busy) if busy else None
+        clk = [c for t, c in smp.clocks if lo <= t <= t1 and c]
         rec = {"us_per_launch": ms * 1e3, "launches": iters, "tflops": flop / (ms * 1e-3) / 1e12, "power_samples": len(busy),
-               "avg_w": avg, "max_w": max(busy) if busy else None}
+               "avg_w": avg, "max_w": max(busy) if busy else None, "avg_sclk_mhz": sum(clk) / len(clk) if clk else None}
         if avg:
             rec["joules_per_launch"] = avg * ms * 1e-3
             rec["dynamic_joules_per_launch"] = (avg - idle_w) * ms * 1e-3
             rec["pj_per_flop"] = (avg - idle_w) * ms * 1e-3 / flop * 1e12
         out["classes"][name] = rec
-        print(f"{name:44s} {ms * 1e3:8.1f} us  {rec['tflops']:7.1f} TF  {avg or 0:7.1f} W  {rec.get('joules_per_launch', 0) * 1e3:7.1f} mJ/launch", flush=True)
+        print(f"{name:44s} {ms * 1e3:8.1f} us  {rec['tflops']:7.1f} TF  {avg or 0:7.1f} W  {rec['avg_sclk_mhz'] or 0:6.0f} MHz  {rec.get('joules_per_launch', 0) * 1e3:7.1f} mJ/launch", flush=True)
     # the step = 22 layers x 2 micro-batches of (qkv, attention, wo, wi, wo_mlp): energy budget per class
     per_step = {"gemm_qkv (EPI_QKV_ROPE, N=2304 K=768)": 44, "gemm_wi (EPI_GEGLU, N=2304 K=768)": 44, "gemm_wo (EPI_RESIDUAL, N=768 K=768)": 44,
                 "gemm_wo_mlp (EPI_RESIDUAL, N=768 K=1152)": 44, "attn_global (S=512)": 16, "attn_local (S=512, |i-j|<=64)": 28}

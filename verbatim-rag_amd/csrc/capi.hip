@@ -301,7 +301,7 @@ struct vrag_encoder {
     int seen = 0;
     uint64_t last_use = 0;
   };
-  std::map<std::array<int, 6>, GraphEntry> graphs;
+  std::map<std::array<int, 7>, GraphEntry> graphs;
   uint64_t graph_clock = 0;
   int graph_rows_max = 8192;   // 0 disables (VRAG_GRAPHS=0); batches above it are throughput-bound, not launch-bound
   int64_t graph_replays = 0;
@@ -458,6 +458,15 @@ int check_ready(vrag_encoder* e) {
   return VRAG_OK;
 }
 
+// Does this micro-batch take the fused Wqkv + RoPE + attention kernel (qkv_attn.hip)?  One rule for the schedule and for the
+// HIP-graph cache key: a graph captured on one path must never be replayed for a batch that takes the other.
+static bool fused_attention_for(const vrag_encoder* e, const MicroBatch& mb) {
+  if (!e->fused_qkv_attn || mb.max_len > kFusedMaxSeq) return false;
+  if (e->fused_qkv_attn == 2) return true;
+  const int M = mb.row1 - mb.row0;
+  return !gemm_consumer_finalizes(M) && (int64_t)mb.tokens >= (int64_t)kFusedMinMeanLen * (mb.seq1 - mb.seq0);
+}
+
 int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
   const auto& c = e->cfg;
   const int H = c.hidden_size, I = e->i_pad;   // padded GeGLU width (zero rows of Wi / zero columns of mlp.Wo)
@@ -505,9 +514,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       // The fused kernel spends a 512-token workgroup per (sequence, head) whatever the sequence's length (waves past its end
       // idle): it wins from a mean length of ~270 tokens up and loses below (tools/bench_seq_len.py: 42.7 vs 38.6 ms per
       // 131 072-token step at 192 tokens, a tie at 256, 35.8 vs 39.9 at 512), so short-chunk batches keep the packed two-kernel path.
-      const bool fused_attn = e->fused_qkv_attn && L.wqkv_h && mb.max_len <= kFusedMaxSeq &&
-                              (e->fused_qkv_attn == 2 ||
-                               (!gemm_consumer_finalizes(M) && (int64_t)mb.tokens >= (int64_t)kFusedMinMeanLen * (mb.seq1 - mb.seq0)));
+      const bool fused_attn = L.wqkv_h && fused_attention_for(e, mb);
       auto finalize_stats = [&](bool first, bool for_qkv = false) -> int {
         if (consumer_stats && !(for_qkv && fused_attn)) return VRAG_OK;
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
@@ -1526,16 +1533,31 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   return VRAG_OK;
 }
 
-// Eager or graph-replayed layer schedule (see vrag_encoder::graphs).  First sight of a geometry: eager (this also runs every
-// first-use hipFuncSetAttribute of the instantiations involved, which must not happen inside a capture); second: capture,
+// Eager or graph-replayed layer schedule (see vrag_encoder::graphs).  First two sights of a geometry: eager (the first also runs
+// every first-use hipFuncSetAttribute of the instantiations involved, which must not happen inside a capture); third: capture,
 // instantiate, launch; afterwards: one hipGraphLaunch.
+constexpr size_t kGraphCacheMax = 48;      // entries of vrag_encoder::graphs (sighted geometries, instantiated or not)
+constexpr int kGraphCaptureAfter = 2;      // eager sightings of a geometry before it is captured
 static int run_layers_maybe_graphed(vrag_encoder* e, int n_layers, hipStream_t st) {
   auto eager = [&]() { return e->arch == 1 ? run_layers_bert_locked(e, n_layers, st) : run_layers_locked(e, n_layers, st); };
   const bool eligible = e->graph_rows_max > 0 && e->mbs.size() == 1 && e->rows <= e->graph_rows_max && !e->prof_on &&
                         st != nullptr && n_layers > 0;
   if (!eligible) return eager();
   const MicroBatch& mb = e->mbs[0];
-  const std::array<int, 6> key = {e->rows, mb.blk1 - mb.blk0, mb.lblk1 - mb.lblk0, n_layers, e->types_loaded ? 1 : 0, mb.seq1 - mb.seq0};
+  // The key holds everything that selects kernels or launch geometry: row count, attention block counts, sequences, and the
+  // attention path (it depends on the longest sequence and the mean length, which the other fields do not determine).
+  const std::array<int, 7> key = {e->rows, mb.blk1 - mb.blk0, mb.lblk1 - mb.lblk0, n_layers, e->types_loaded ? 1 : 0, mb.seq1 - mb.seq0,
+                                  e->arch != 1 && fused_attention_for(e, mb) ? 1 : 0};
+  // Bound the whole map (instantiated or not): query traffic has many geometries, most of them seen once.  The least recently
+  // used entry goes first, whatever it holds.
+  while (e->graphs.size() >= kGraphCacheMax && e->graphs.find(key) == e->graphs.end()) {
+    auto victim = e->graphs.begin();
+    for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
+      if (it->second.last_use < victim->second.last_use) victim = it;
+    if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+    if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+    e->graphs.erase(victim);
+  }
   auto& g = e->graphs[key];
   g.last_use = ++e->graph_clock;
   if (g.exec) {
@@ -1544,18 +1566,9 @@ static int run_layers_maybe_graphed(vrag_encoder* e, int n_layers, hipStream_t s
     e->ran = true;
     return VRAG_OK;
   }
-  if (g.seen++ == 0) return eager();
-  if (e->graphs.size() > 32) {   // bound the cache: drop the least recently used instantiated graph
-    auto victim = e->graphs.end();
-    for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
-      if (it->second.exec && it->first != key && (victim == e->graphs.end() || it->second.last_use < victim->second.last_use)) victim = it;
-    if (victim != e->graphs.end()) {
-      (void)hipGraphExecDestroy(victim->second.exec);
-      (void)hipGraphDestroy(victim->second.graph);
-      e->graphs.erase(victim);
-    }
-  }
-  auto& slot = e->graphs[key];
+  // capture + instantiate costs milliseconds: only a geometry that keeps coming back (third sight) is worth it
+  if (g.seen++ < kGraphCaptureAfter) return eager();
+  auto& slot = g;
   hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (ce != hipSuccess) return eager();                    // a stream that cannot be captured: stay eager
   const int rc = eager();

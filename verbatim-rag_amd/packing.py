@@ -42,7 +42,13 @@ def split_into_sentences_batch(texts: Sequence[str], device: int = 0, cap: int =
         return []
     lib = _lib.load()
     _lib.require_gpu()
-    raw = [t.encode("utf-8") for t in texts]
+    raw, unencodable = [], set()
+    for d, t in enumerate(texts):
+        try:
+            raw.append(t.encode("utf-8"))
+        except UnicodeEncodeError:      # lone surrogates: the regex path accepts such text, so this document takes it
+            raw.append(b"")
+            unencodable.add(d)
     off = np.zeros(len(raw) + 1, np.int64)
     np.cumsum([len(b) for b in raw], out=off[1:])
     blob = b"".join(raw) or b"\x00"
@@ -56,7 +62,7 @@ def split_into_sentences_batch(texts: Sequence[str], device: int = 0, cap: int =
     out: List[List[str]] = []
     for d, (t, b) in enumerate(zip(texts, raw)):
         n = int(counts[d])
-        if n > cap:
+        if n > cap or d in unencodable:
             out.append(split_into_sentences(t))
         elif len(b) == len(t):           # pure ASCII: byte offsets are character offsets
             out.append([t[a:z] for a, z in zip(starts[d, :n].tolist(), ends[d, :n].tolist())])

@@ -286,6 +286,10 @@ def dicts_to_csr(rows: Sequence[Dict[int, float]]) -> Tuple[np.ndarray, np.ndarr
     total = int(indptr[-1])
     terms = np.fromiter(chain.from_iterable(rows), np.int64, total)                       # iterating a dict yields its keys
     weights = np.fromiter(chain.from_iterable(r.values() for r in rows), np.float64, total)
+    if total and (terms.min() < 0 or terms.max() > np.iinfo(np.int32).max):
+        # checked on the int64 keys: a term >= 2**31 would wrap in the int32 cast below and pass a later range check
+        bad = int(np.searchsorted(indptr, np.nonzero((terms < 0) | (terms > np.iinfo(np.int32).max))[0][0], side="right") - 1)
+        raise ValueError(f"sparse vector {bad} has a term outside [0, 2**31)")
     order = np.lexsort((terms, np.repeat(np.arange(n, dtype=np.int64), lens)))
     return indptr, terms[order].astype(np.int32), weights[order].astype(np.float32)
 
@@ -635,20 +639,24 @@ def _put_strings(path: str, stem: str, col: Sequence[str]) -> None:
             blob = None
     except TypeError:
         blob = None
-    for stale in (f"{stem}.txt", f"{stem}.json"):
-        if os.path.exists(os.path.join(path, stale)):
-            os.remove(os.path.join(path, stale))
+    # new file first (write beside + rename: a reader never sees the column missing), then the other extension's stale file
     if blob is not None:
         _replace_into(path, f"{stem}.txt", lambda tmp: _write_text(tmp, blob))
+        stale = f"{stem}.json"
     else:
         _replace_into(path, f"{stem}.json", lambda tmp: _write_text(tmp, json.dumps(list(col), ensure_ascii=False)))
+        stale = f"{stem}.txt"
+    if os.path.exists(os.path.join(path, stale)):
+        os.remove(os.path.join(path, stale))
 
 
 def _get_strings(path: str, stem: str, n: int) -> List[str]:
     import os
 
-    if os.path.exists(os.path.join(path, f"{stem}.txt")):
-        with open(os.path.join(path, f"{stem}.txt"), encoding="utf-8", newline="") as f:
+    txt, js = os.path.join(path, f"{stem}.txt"), os.path.join(path, f"{stem}.json")
+    # both present = an overwrite was interrupted between the rename of the new file and the removal of the old: newest wins
+    if os.path.exists(txt) and not (os.path.exists(js) and os.path.getmtime(js) > os.path.getmtime(txt)):
+        with open(txt, encoding="utf-8", newline="") as f:
             col = f.read().split("\x00") if n else []
     else:
         with open(os.path.join(path, f"{stem}.json"), encoding="utf-8") as f:

@@ -10,7 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libvrag_amd.so")
+# VRAG_BUILD_VARIANT=<tag> (tuning experiments only): objects under build_<tag>/, library libvrag_amd_<tag>.so -- load it with VRAG_AMD_LIB
+VARIANT = os.environ.get("VRAG_BUILD_VARIANT", "")
+LIB_PATH = os.path.join(HERE, f"libvrag_amd_{VARIANT}.so" if VARIANT else "libvrag_amd.so")
 SOURCES = ["gemm_bf16.hip", "attention.hip", "qkv_attn.hip", "norm_heads.hip", "topk.hip", "text.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 FLAGS += os.environ.get("VRAG_HIPCC_FLAGS", "").split()  # tuning experiments only
@@ -29,7 +31,7 @@ def _newer(src: str, dst: str) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, f"build_{VARIANT}" if VARIANT else "build")
     os.makedirs(objdir, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]

@@ -126,6 +126,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // Streaming (non-temporal) 16/8-byte accesses for data that is written once and consumed by a LATER
 // kernel (GEMM / attention outputs, the residual read-modify-write): keeps the XCD's 4 MiB L2 for
 // the operand panels that co-running tiles share.  Measured on the bf16-out GEMM: 594 -> 548 us.
+// -DVRAG_PLAIN_STREAMS (probe build, tools/probes/mall_probe.py): ordinary accesses instead -- does the non-temporal hint
+// keep the data out of the Infinity Cache as well?
+#ifdef VRAG_PLAIN_STREAMS
+__device__ __forceinline__ void store16_nt(void* dst, const f32x4& v) { *reinterpret_cast<f32x4*>(dst) = v; }
+template <typename V4>
+__device__ __forceinline__ void store8_nt(void* dst, const V4& v) { *reinterpret_cast<V4*>(dst) = v; }
+__device__ __forceinline__ f32x4 load16_nt(const void* src) { return *reinterpret_cast<const f32x4*>(src); }
+#else
 __device__ __forceinline__ void store16_nt(void* dst, const f32x4& v) {
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
 }
@@ -136,6 +144,7 @@ __device__ __forceinline__ void store8_nt(void* dst, const V4& v) {
 __device__ __forceinline__ f32x4 load16_nt(const void* src) {
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
 }
+#endif
 
 // Host side of vrag_f16_sat_flag for THIS translation unit: 1 if a conversion clamped since the last reset (synchronises
 // the device: callers use it on the read-back path, never between launches).

@@ -248,6 +248,8 @@ int vrag_encoder_f16_saturated(vrag_encoder* enc, int32_t reset, int32_t* satura
 /* Micro-batches (cfg.micro_batch_tokens) are issued on 2 internal streams by default so that the
  * HBM-bound kernels of one overlap the MFMA-bound kernels of the other; 1 serialises them. */
 int vrag_encoder_set_concurrency(vrag_encoder* enc, int32_t n_streams);
+/* enabled: 0 = off, 1 = a HIP event pair around every launch, n > 1 = around every n-th launch of each class (the totals
+ * vrag_encoder_read_profile returns are then the timed launches' mean x the launches issued). */
 int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
 /* Tuning / tests: GEMMs over at most `rows` token rows use the small-batch configuration (128x128 tiles, four LDS
  * stages in flight); 0 disables it.  Process-wide; returns the new threshold (default 8192). */

@@ -85,6 +85,9 @@ def main():
         # the residual epilogue (almost) alone: one K-step of main loop in front of it -- what does the read-modify-write phase draw?
         ("resid epilogue-only (EPI_RESIDUAL, N=768 K=64)", "gemm", (3, M, H, 64), 2.0 * M * H * 64),
         ("resid plain epilogue-only (no fold outputs, N=768 K=64)", "gemm_plain", (3, M, H, 64), 2.0 * M * H * 64),
+        ("resid split epilogue-only (two 16-bit planes, N=768 K=64)", "gemm_split", (3, M, H, 64), 2.0 * M * H * 64),
+        ("gemm_wo split (EPI_RESIDUAL, N=768 K=768)", "gemm_split", (3, M, H, H), 2.0 * M * H * H),
+        ("gemm_wo_mlp split (EPI_RESIDUAL, N=768 K=1152)", "gemm_split", (3, M, H, I), 2.0 * M * H * I),
         ("geglu epilogue-only (EPI_GEGLU, N=2304 K=64)", "gemm", (4, M, 2 * I, 64), 2.0 * M * 2 * I * 64),
         ("attn_global (S=512)", "attn", (0, M // S, S, H, 64), 4.0 * M * S * H),
         ("attn_local (S=512, |i-j|<=64)", "attn", (1, M // S, S, H, 64), 4.0 * M * 129 * H),
@@ -100,12 +103,13 @@ def main():
 
     def run(kind, a, iters):
         ms = C.c_float()
-        if kind == "gemm_plain":
-            os.environ["VRAG_DEBUG_GEMM_PLAIN_RESID"] = "1"
+        if kind in ("gemm_plain", "gemm_split"):
+            var = "VRAG_DEBUG_GEMM_PLAIN_RESID" if kind == "gemm_plain" else "VRAG_DEBUG_GEMM_SPLIT"
+            os.environ[var] = "1"
             try:
                 _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
             finally:
-                del os.environ["VRAG_DEBUG_GEMM_PLAIN_RESID"]
+                del os.environ[var]
         elif kind == "gemm":
             _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
         elif kind == "fused":

@@ -18,8 +18,6 @@ struct AttnParams {
   int Tp;      // padded token rows (leading dimension of vt)
   int window;  // banded layers: keep |i-j| <= window; ignored for global layers
   int op_dtype;  // kOpBf16 / kOpF16: what q, k, vt and o hold
-  float v2_lazy;   // second-generation kernel, filled by the launcher: how far (log2 units) a score may exceed the reference before it moves
-  int v2_noseed;   // debug: reference subtracted after the QK^T MFMAs instead of riding in as their C operand
 };
 
 hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream);

@@ -91,7 +91,7 @@ static void launch_cvt_rows(int op_dtype, dim3 grid, hipStream_t st, const float
 // bf16(h - c) operand), shift[r] <- c + d (the absolute mean: next shift, and the post-LN rebuild's mean).
 __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np, int H, float eps, int rows,
                                          float* __restrict__ mu_rel, float* __restrict__ rstd, const float* shift_in,
-                                         float* shift_out) {
+                                         float* shift_out, float* __restrict__ shift_prev_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float s1 = 0.f, s2 = 0.f;
@@ -104,6 +104,7 @@ __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np,
   const float c = shift_in ? shift_in[r] : 0.f;
   mu_rel[r] = d;
   rstd[r] = 1.0f / sqrtf(var + eps);
+  if (shift_prev_out) shift_prev_out[r] = c;   // what the split residual planes written before this call are relative to
   shift_out[r] = c + d;
 }
 
@@ -266,6 +267,9 @@ struct vrag_encoder {
   float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
   float *st_part = nullptr, *ln_mu = nullptr, *ln_rstd = nullptr;  // folded-LayerNorm row statistics (ln_mu relative to ln_shift's previous value)
   float* ln_shift = nullptr;                                        // absolute row means = the next residual epilogue's shift
+  float* ln_shift_prev = nullptr;                                   // the shift before the last advance: what the split planes in HBM are relative to
+  f16_t* lo16 = nullptr;                                            // [cap_rows, H] low plane of the split residual stream (gemm_bf16.h)
+  bool split_resid = true;                                          // VRAG_SPLIT_RESID=0: fp32 rows between all sub-layers (A/B)
   int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;     // global-layer q-blocks
   int *d_lblk_start = nullptr, *d_lblk_len = nullptr, *d_lblk_q0 = nullptr;  // banded-layer q-blocks
   int cap_blocks = 0;
@@ -311,7 +315,9 @@ struct vrag_encoder {
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_free;
   float prof_ms[VRAG_PROF_COUNT] = {0};
-  int64_t prof_n[VRAG_PROF_COUNT] = {0};
+  int64_t prof_n[VRAG_PROF_COUNT] = {0};      // launches timed
+  int64_t prof_seen[VRAG_PROF_COUNT] = {0};   // launches issued while profiling was on
+  int prof_period = 1;                        // vrag_encoder_set_profiling(enabled): every enabled-th launch of a class is timed
 };
 
 namespace {
@@ -430,6 +436,10 @@ struct ProfScope {
   bool on;
   ProfScope(vrag_encoder* e_, int cls, hipStream_t st_) : e(e_), st(st_), on(e_->prof_on) {
     if (!on) return;
+    // sampling: every launch is counted, every prof_period-th launch of a class is bracketed by events (an event pair between
+    // two launches keeps the second from starting under the first one's tail: 1.1 % of the bench step when every launch has one)
+    on = (e->prof_seen[cls]++ % e->prof_period) == 0;
+    if (!on) return;
     auto get = [&]() {
       hipEvent_t ev;
       if (!e->prof_free.empty()) {
@@ -496,6 +506,11 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
       // a tiny kernel turns those into (mu, rstd) and the consumer GEMM (gain folded into its weight)
       // normalises in its epilogue -- fewer bytes, but epilogue work is not overlapped (measured slower).
       const bool fold = e->ln_fold;
+      // Split residual stream (gemm_bf16.h): between the sub-layers of layers >= 1 the stream lives as the operand copy `a` plus
+      // a 16-bit low plane; the fp32 rows of `h` are written by layer 0 and by the LAST sub-layer of the run only (what the heads
+      // and vrag_encoder_read_hidden read).
+      const bool split = fold && e->split_resid;
+      const bool more_layers = l + 1 < n_layers;   // a further layer of THIS run consumes the fold outputs
       auto layer_norm = [&](const float* gain) -> int {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, gain, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr, nullptr,
@@ -520,7 +535,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st,
                            e->st_part + (size_t)r0 * (H / 64) * 2, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
-                           e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0);
+                           e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0, e->ln_shift_prev + r0);
         HIP_TRY(hipGetLastError());
         return VRAG_OK;
       };
@@ -528,6 +543,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         if (!consumer_stats) return;
         g.stats_in = e->st_part + (size_t)r0 * (H / 64) * 2;
         g.ln_shift = e->ln_shift + r0;
+        g.ln_shift_prev = e->ln_shift_prev + r0;
         g.fin_eps = c.norm_eps;
       };
       if (fused_attn) {
@@ -614,15 +630,15 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         // The fold's per-row shift is the row's previous mean; the very first sub-layer has none, so layer 0's
         // mlp_norm runs as a stand-alone (two-pass) LayerNorm that also records the exact row means.
         const bool fold_here = fold && l > 0;
-        bool fused_stats = false;   // the GEMM finishes the row statistics itself (row walk): no finalize launch
         if (fold_here) {
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
           g.ln_shift = e->ln_shift + r0;
-          g.fin_mu = e->ln_mu + r0;
-          g.fin_rstd = e->ln_rstd + r0;
-          g.fin_eps = c.norm_eps;
-          fused_stats = gemm_residual_finalizes(g);
+          if (split) {   // layers >= 1: the stream arrives split (mlp Wo of the previous layer) and leaves split (this layer's mlp Wo reads it)
+            g.lo_in = e->lo16 + (size_t)r0 * H;
+            g.lo_out = e->lo16 + (size_t)r0 * H;
+            g.ln_shift_prev = e->ln_shift_prev + r0;
+          }
         }
         {
           ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
@@ -632,7 +648,7 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
           HIP_TRY(launch_layernorm(e->h + (size_t)r0 * H, nullptr, c.norm_eps, H, M, e->a + (size_t)r0 * H, nullptr, st, nullptr,
                                    e->ln_shift + r0, e->op_dtype));
-        } else if (!fused_stats) {
+        } else {
           int rc = fold ? finalize_stats(false) : layer_norm(L.mlp_norm);
           if (rc) return rc;
         }
@@ -664,21 +680,22 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.N = H;
         g.K = I;
         g.out_f32 = e->h + (size_t)r0 * H;
-        bool fused_stats = false;
-        if (fold && l + 1 < c.num_layers) {  // the next layer's attn_norm is folded into its QKV GEMM
+        if (fold && more_layers) {  // the next layer's attn_norm is folded into its QKV GEMM
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
           g.ln_shift = e->ln_shift + r0;
-          g.fin_mu = e->ln_mu + r0;
-          g.fin_rstd = e->ln_rstd + r0;
-          g.fin_eps = c.norm_eps;
-          fused_stats = gemm_residual_finalizes(g);
+          if (split) g.lo_out = e->lo16 + (size_t)r0 * H;
+        }
+        if (split && l > 0) {   // this layer's attention Wo left the stream split; the last layer of a run writes the fp32 rows again
+          g.lo_in = e->lo16 + (size_t)r0 * H;
+          g.ln_shift_prev = e->ln_shift_prev + r0;
+          if (!g.resid_bf16) g.resid_bf16 = e->a + (size_t)r0 * H;   // the high plane is read from there
         }
         {
           ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
           HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
         }
-        if (fold && l + 1 < c.num_layers && !fused_stats) {
+        if (fold && more_layers) {
           int rc = finalize_stats(false, true);
           if (rc) return rc;
         }
@@ -731,7 +748,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
     auto finalize_stats = [&](bool first) -> int {
       ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
       hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, st_part, H / 64, H, c.norm_eps, M,
-                         e->ln_mu + r0, e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0);
+                         e->ln_mu + r0, e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0, (float*)nullptr);
       HIP_TRY(hipGetLastError());
       return VRAG_OK;
     };
@@ -920,6 +937,8 @@ int init_workspace(vrag_encoder* e) {
   TRY(dev_alloc(e, &e->ln_mu, R));
   TRY(dev_alloc(e, &e->ln_rstd, R));
   TRY(dev_alloc(e, &e->ln_shift, R));
+  TRY(dev_alloc(e, &e->ln_shift_prev, R));
+  TRY(dev_alloc(e, &e->lo16, (size_t)R * H));
   // the six q-block descriptor arrays are slices of ONE buffer (host and device alike): one upload per batch
   TRY(dev_alloc(e, &e->d_blk_start, (size_t)6 * e->cap_blocks));
   e->d_blk_len = e->d_blk_start + e->cap_blocks;
@@ -1028,6 +1047,7 @@ int vrag_encoder_create(const vrag_encoder_config* cfg, const vrag_encoder_weigh
   TRY(init_streams(e));
 
   if (const char* lf = getenv("VRAG_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
+  if (const char* sr = getenv("VRAG_SPLIT_RESID")) e->split_resid = atoi(sr) != 0;
   // 0: always the QKV GEMM + attention launch; 1 (default): fused kernel for throughput-sized micro-batches; 2: launch-bound batches too
   if (const char* fq = getenv("VRAG_FUSED_QKV_ATTN")) e->fused_qkv_attn = atoi(fq);
   if (cfg->hidden_size != cfg->num_heads * 64) e->fused_qkv_attn = 0;
@@ -1955,6 +1975,14 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
   if (epi == EPI_RESIDUAL && !getenv("VRAG_DEBUG_GEMM_PLAIN_RESID")) {   // as the encoder launches it with the LayerNorm fold
     g.resid_bf16 = (bf16_t*)outb;
     g.stats_part = (float*)q;                                              // Mp * N/64 * 2 floats <= Mp * N * 2 bytes
+    if (getenv("VRAG_DEBUG_GEMM_SPLIT")) {   // the split residual stream on both sides (layers >= 1 of the encoder schedule)
+      g.lo_in = (const f16_t*)kk;
+      g.lo_out = (f16_t*)kk;
+      g.ln_shift = (const float*)pos;        // zeros
+      g.ln_shift_prev = (float*)pos;
+      (void)hipMemset(kk, 0, Mp * N * 2);
+      (void)hipMemset(outb, 0, Mp * N * 2);
+    }
   }
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
@@ -2250,6 +2278,7 @@ int vrag_encoder_set_profiling(vrag_encoder* e, int32_t enabled) {
   ARG_CHECK(e, "null encoder handle");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   e->prof_on = enabled != 0;
+  e->prof_period = enabled > 1 ? enabled : 1;
   return VRAG_OK;
 }
 
@@ -2268,11 +2297,13 @@ int vrag_encoder_read_profile(vrag_encoder* e, float* ms, int64_t* launches, int
   }
   e->prof_pending.clear();
   for (int i = 0; i < VRAG_PROF_COUNT; ++i) {
-    ms[i] = e->prof_ms[i];
-    launches[i] = e->prof_n[i];
+    // sampled classes: the timed launches' mean duration times the launches issued (ms / launches stays the measured mean)
+    ms[i] = e->prof_n[i] > 0 ? e->prof_ms[i] * (float)((double)e->prof_seen[i] / (double)e->prof_n[i]) : 0.f;
+    launches[i] = e->prof_seen[i];
     if (reset) {
       e->prof_ms[i] = 0.f;
       e->prof_n[i] = 0;
+      e->prof_seen[i] = 0;
     }
   }
   return VRAG_OK;

@@ -53,20 +53,20 @@ struct GemmParams {
   const float* ln_shift;  // [Mpad] or null: per-row shift c subtracted before the bf16 copy / the statistics (see the epilogue)
   bf16_t* resid_bf16;     // [Mpad, N] or null  = bf16(updated residual - c)
   float* stats_part;      // [Mpad, N/64, 2] or null
-  // Row-walk form of EPI_RESIDUAL (launcher's choice, gemm_residual_finalizes()): a workgroup computes ALL column tiles of
-  // its 256-row block one after the other, keeps the row statistics in LDS and finishes them itself -- what
-  // ln_stats_finalize_kernel did in a launch of its own (capi.hip): fin_mu[r] = d = mean(h - c), fin_rstd[r] =
-  // 1/sqrt(E[(h-c)^2] - d^2 + eps), ln_shift[r] <- c + d, same operands in the same order (bit-identical).
-  // Consumer side of the same fusion, small-row configuration only (gemm_consumer_finalizes()): the LayerNorm-folding GEMM
+  // EPI_RESIDUAL, split residual stream (round 4): between two sub-layers the stream is kept as TWO 16-bit planes relative to the
+  // row shift, h = c + float(hi) + float(lo): hi = op16(h - c) is `resid_bf16` -- the very operand copy the next GEMM reads --
+  // and lo = fp16((h - c) - hi) (19-22 significant bits together; the fp32 rows are not written at all).  8 instead of 10 bytes
+  // per element and sub-layer.  lo_in: the stream arrives split (hi is read from resid_bf16, relative to ln_shift_prev);
+  // lo_out: it leaves split (relative to ln_shift).  Both null = the fp32 rows of out_f32 on both sides.
+  const f16_t* lo_in;     // [Mpad, N] or null
+  f16_t* lo_out;          // [Mpad, N] or null (may alias lo_in: every element is read and written by the same lane)
+  float* ln_shift_prev;   // [Mpad]: the shift the arriving planes are relative to (written by whoever advances ln_shift)
+  // Consumer-side finalisation of the row statistics, small-row configuration only (gemm_consumer_finalizes()): the LayerNorm-folding GEMM
   // (EPI_QKV_ROPE / EPI_GEGLU / EPI_BF16) finishes the producer's partial statistics itself -- every wave for its own 64 rows,
   // before its epilogue reads them -- and the wave of column 0 advances ln_shift.  One launch fewer per sub-layer where a
   // launch costs as much as the kernel (a query's handful of chunks).
   const float* stats_in;  // [Mpad, K/64, 2] or null (then ln_mu / ln_rstd were written by ln_stats_finalize_kernel)
-  float* fin_mu;          // [Mpad] or null
-  float* fin_rstd;        // [Mpad]
-  float fin_eps;
-  int row_walk;           // filled by the launcher
-  int col_groups;         // filled by the launcher: > 1 = every XCD walks its row blocks once per group of column tiles (see the kernel)
+  float fin_eps;          // LayerNorm eps of that finalisation
   int op_dtype;           // kOpBf16 (0) or kOpF16 (1): what A, W and every 16-bit output hold (pointers stay typed bf16_t*)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias
@@ -79,10 +79,6 @@ const char* gemm_kernel_name(GemmEpi epi);
 // GEMMs with M <= threshold rows use the small-batch configuration (128x128 tiles, four LDS stages).
 // set_to >= 0 changes the threshold (0 disables the configuration); returns the current value.
 int gemm_small_m_threshold(int set_to);
-
-// True when launch_gemm(EPI_RESIDUAL, p) will finish the LayerNorm statistics inside the GEMM (p.fin_mu set and the tile
-// geometry suits the row walk): the caller then skips its stand-alone finalize launch.
-bool gemm_residual_finalizes(const GemmParams& p);
 
 // True when a LayerNorm-folding GEMM over `rows` token rows takes the small-row configuration and therefore finishes the row
 // statistics itself when given `stats_in` (the caller then skips ln_stats_finalize_kernel).

@@ -40,11 +40,131 @@ constexpr int BK = 64;   // K-step: one LDS stage holds 64 k-values of every til
 
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
 
+// sum over each aligned group of 8 lanes (DPP: xor 1, xor 2, mirror within 8), result in every lane of the group
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  return v;
+}
+
+// EPI_RESIDUAL with the residual stream split into two 16-bit planes on one or both sides (GemmParams::lo_in / lo_out).
+// Same staging as the fp32 form (a pass = 64 rows x 64 columns of accumulators through the wave's 16 KiB, half-passes of 32
+// rows, the arriving rows of a half prefetched one half ahead), but a lane takes EIGHT consecutive columns of its row, so every
+// plane moves in 16-byte pieces per lane and whole 128-byte lines per 8 lanes: hi in, lo in, hi out, lo out -- four streams of
+// the width the three of the fp32 form have (a first probe of the split stream in round 2 used 8-byte pieces and bought nothing:
+// DESIGN.md section 3).  Arithmetic per element: v = (acc + h_in) + off, off = [c_prev if arriving split] - [c if leaving split];
+// leaving split: hi = op16(v), lo = fp16(v - hi), statistics of v (sum, sum of squares per 64-column slice) as the fp32 form.
+template <int RT, typename T>
+__device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* stg, int lane, int mw, int nw) {
+  typedef typename Op<T>::v8 V8;
+  constexpr int NI = 4;   // instructions per half-pass: 8 rows x (8 lanes x 8 columns)
+  const int q = lane >> 4, l15 = lane & 15, gq = lane >> 3, l7 = lane & 7;
+  const bool in_split = p.lo_in != nullptr, out_split = p.lo_out != nullptr;
+  float off[RT / 4];   // lane L: the offset of row ps * 64 + L
+#pragma unroll
+  for (int ps = 0; ps < RT / 4; ++ps) {
+    const int row = mw + ps * 64 + lane;
+    off[ps] = (in_split ? p.ln_shift_prev[row] : 0.f) - (out_split ? p.ln_shift[row] : 0.f);
+  }
+  f32x4 hA[NI][2], hB[NI][2];
+  // addresses as (wave-uniform row base) + (one 32-bit lane offset): a 64-bit lane address per plane and instruction would cost
+  // the epilogue the registers its two prefetch sets need
+  unsigned loff = (unsigned)(gq * p.N + 8 * l7);   // elements, inside the 8-row group of an instruction
+  asm volatile("" : "+v"(loff));
+  auto row_base = [&](int hp, int i) {   // uniform: first element of the instruction's first row
+    return ((size_t)(mw + (hp >> 1) * 64 + (hp & 1) * 32 + i * 8)) * p.N + nw;
+  };
+  auto prefetch = [&](f32x4 (&dst)[NI][2], int hp) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const size_t rb = row_base(hp, i);
+      if (in_split) {
+        dst[i][0] = load16_nt(p.resid_bf16 + rb + loff);
+        dst[i][1] = load16_nt(p.lo_in + rb + loff);
+      } else {
+        dst[i][0] = load16_nt(p.out_f32 + rb + loff);
+        dst[i][1] = load16_nt(p.out_f32 + rb + loff + 4);
+      }
+    }
+  };
+  auto finish_half = [&](const f32x4 (&hv)[NI][2], int hp) {
+    const int ps = hp >> 1;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int rowp = (hp & 1) * 32 + i * 8 + gq;   // row inside the pass
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rowp * 256 + (((2 * l7) ^ (rowp & 15)) << 4));
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + rowp * 256 + (((2 * l7 + 1) ^ (rowp & 15)) << 4));
+      const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rowp << 2, __builtin_bit_cast(int, off[ps])));
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = a0[j];
+        v[4 + j] = a1[j];
+      }
+      if (in_split) {
+        const V8 hi = __builtin_bit_cast(V8, hv[i][0]);
+        const f16x8 lo = __builtin_bit_cast(f16x8, hv[i][1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)hi[j] + (float)lo[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] += hv[i][0][j];
+          v[4 + j] += hv[i][1][j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += o;
+      const size_t rb = row_base(hp, i);
+      if (out_split) {
+        V8 ho;
+        f16x8 lw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ho[j] = Op<T>::to(v[j]);
+          lw[j] = (f16_t)(v[j] - (float)ho[j]);
+        }
+        store16_nt(p.resid_bf16 + rb + loff, __builtin_bit_cast(f32x4, ho));
+        store16_nt(p.lo_out + rb + loff, __builtin_bit_cast(f32x4, lw));
+        if (p.stats_part) {
+          float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          float s2 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+          s1 = row8_sum(s1);
+          s2 = row8_sum(s2);
+          if (l7 == 0) {
+            float* sp = p.stats_part + ((size_t)(mw + ps * 64 + rowp) * (p.N >> 6) + (nw >> 6)) * 2;
+            sp[0] = s1;
+            sp[1] = s2;
+          }
+        }
+      } else {
+        store16_nt(p.out_f32 + rb + loff, f32x4{v[0], v[1], v[2], v[3]});
+        store16_nt(p.out_f32 + rb + loff + 4, f32x4{v[4], v[5], v[6], v[7]});
+      }
+    }
+  };
+  prefetch(hA, 0);
+#pragma unroll
+  for (int ps = 0; ps < RT / 4; ++ps) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int row = rq * 16 + l15;
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) *reinterpret_cast<f32x4*>(stg + row * 256 + (((nj * 4 + q) ^ l15) << 4)) = acc[nj][ps * 4 + rq];
+    }
+    prefetch(hB, 2 * ps + 1);
+    finish_half(hA, 2 * ps);
+    if (ps + 1 < RT / 4) prefetch(hA, 2 * ps + 2);
+    finish_half(hB, 2 * ps + 1);
+  }
+}
+
 // Epilogue shared by the GEMM kernels. `acc[nj][rt]` are this wave's accumulators (swapped layout:
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
 template <int EPI, int RT, int WROWS, typename T, bool SMALL = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* smem, int wave, int lane,
-                                              int mw, int nw, bool v_block, int m0 = 0, char* stats_lds = nullptr) {
+                                              int mw, int nw, bool v_block) {
   typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
   // The lane index is re-read through an opaque asm: every per-lane address of the epilogue then depends on a value
   // defined inside the tile loop, so none of them is hoisted out of it to sit in (spilled) registers across the K loop.
@@ -76,7 +196,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       const float var = fmaxf(s2 / (float)p.K - d * d, 0.f);
       const_cast<float*>(p.ln_mu)[row] = d;
       const_cast<float*>(p.ln_rstd)[row] = 1.0f / sqrtf(var + p.fin_eps);
-      if (nw == 0) const_cast<float*>(p.ln_shift)[row] = p.ln_shift[row] + d;   // exactly one wave per row sits on column 0
+      if (nw == 0) {   // exactly one wave per row sits on column 0
+        const float c = p.ln_shift[row];
+        if (p.ln_shift_prev) p.ln_shift_prev[row] = c;
+        const_cast<float*>(p.ln_shift)[row] = c + d;
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
@@ -99,6 +223,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) asm volatile("" ::"v"(acc[nj][rt]));
   } else if constexpr (EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_RESIDUAL) {
+    if constexpr (EPI == EPI_RESIDUAL) {
+      if (p.lo_in || p.lo_out) {   // wave-uniform: the stream is split on at least one side (ModernBERT schedule: no bias, no post-LN rebuild)
+        residual_split_epilogue<RT, T>(p, acc, stg, lane, mw, nw);
+        return;
+      }
+    }
     // fp32 [64 rows][64 cols] per pass (256-byte rows, 16 chunks), RT/4 passes; a pass is read back in two halves of
     // 32 rows (8 row-segment instructions each).  Residual: the h rows of a half are prefetched one half ahead
     // (two 8 x 16-byte register sets, 8 KiB per wave in flight), so the fp32 read-modify-write is one HBM round trip
@@ -175,15 +305,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             s1 = row16_sum(s1);
             s2 = row16_sum(s2);
             if (c16 == 0) {
-              if (p.row_walk) {   // the workgroup owns the whole row block: partials stay in LDS (behind the operand ring)
-                float* sp = reinterpret_cast<float*>(stats_lds) + ((mw - m0 + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
-                sp[0] = s1;
-                sp[1] = s2;
-              } else {
-                float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
-                sp[0] = s1;
-                sp[1] = s2;
-              }
+              float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
+              sp[0] = s1;
+              sp[1] = s2;
             }
           }
         }
@@ -537,37 +661,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   // Staying resident lets a tile's epilogue stores drain while the next tile's operands stream in.
   const int nbn = p.N / BN;
   const int K = p.K;
-  const int n_tiles = (EPI == EPI_RESIDUAL && p.row_walk) ? p.n_tiles / nbn : p.n_tiles;   // units dealt to the workgroups
+  const int n_tiles = p.n_tiles;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int per_xcd_wgs = (gridDim.x + 7 - xcd) >> 3;  // workgroups of this grid that sit on my XCD
   const int tq = n_tiles >> 3, tr = n_tiles & 7;
   const int range_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const int range_len = xcd < tr ? tq + 1 : tq;
-  // Row walk (EPI_RESIDUAL with the LayerNorm statistics finished in-kernel): the unit dealt to a workgroup is a whole row
-  // block -- its nbn column tiles run back to back on this CU (the A panel is re-read from L2, the statistics meet in LDS).
-  const int sub = (EPI == EPI_RESIDUAL && p.row_walk) ? nbn : 1;
-  char* stats_lds = smem + NS * STAGE_BYTES;
   for (int tix = slot; tix < range_len; tix += per_xcd_wgs) {
-  for (int nt = 0; nt < sub; ++nt) {
-  int b = (range_lo + tix) * sub + nt;
-  if (p.col_groups > 1) {
-    // Column groups (wide GEMMs, N = 9 tiles): with n fastest the 32 workgroups of an XCD touch all nbn weight tiles at once
-    // (3.5 MB at N = 2304) next to 3-4 streaming A panels -- more than the XCD's 4 MiB L2 holds, so the weight tiles are
-    // re-fetched from the Infinity Cache every round (1.9x the algorithmic bytes, profiles/r02_pmc_traffic.json).  Here the
-    // XCD owns whole row blocks and walks them once per group of column tiles: a group's weight tiles stay in L2 and the A
-    // panels are read once per group instead.
-    const int rows = range_len / nbn;               // row blocks of this XCD (the launcher guarantees whole row blocks)
-    int t = tix, c_lo = 0;
-    for (int gi = 0; gi < p.col_groups; ++gi) {
-      const int gw = (nbn - c_lo + (p.col_groups - gi) - 1) / (p.col_groups - gi);   // columns of this group
-      if (t < rows * gw) {
-        b = (range_lo / nbn + t / gw) * nbn + c_lo + t % gw;
-        break;
-      }
-      t -= rows * gw;
-      c_lo += gw;
-    }
-  }
+  const int b = range_lo + tix;
   const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
@@ -699,53 +800,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<EPI, RT, WROWS, T, (NS == 4 && BM == 128 && BN == 128)>(p, acc, smem, wave, lane, mw, nw, v_block, m0, stats_lds);
+  gemm_epilogue<EPI, RT, WROWS, T, (NS == 4 && BM == 128 && BN == 128)>(p, acc, smem, wave, lane, mw, nw, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
-  if constexpr (EPI == EPI_RESIDUAL) {
-    if (p.row_walk && nt == sub - 1) {
-      // every column tile of rows m0 .. m0 + BM has passed: one thread per row finishes the statistics -- the arithmetic of
-      // ln_stats_finalize_kernel (capi.hip), partials summed in the same fixed order
-      if (tid < BM) {
-        const int np = p.N >> 6;
-        const float* part = reinterpret_cast<const float*>(stats_lds) + tid * np * 2;
-        float s1 = 0.f, s2 = 0.f;
-        for (int i = 0; i < np; ++i) {
-          s1 += part[2 * i];
-          s2 += part[2 * i + 1];
-        }
-        const float d = s1 / (float)p.N;
-        const float var = fmaxf(s2 / (float)p.N - d * d, 0.f);
-        const float c = p.ln_shift ? p.ln_shift[m0 + tid] : 0.f;
-        p.fin_mu[m0 + tid] = d;
-        p.fin_rstd[m0 + tid] = 1.0f / sqrtf(var + p.fin_eps);
-        const_cast<float*>(p.ln_shift)[m0 + tid] = c + d;
-      }
-      __syncthreads();   // the next row block's epilogues reuse the statistics area
-    }
-  }
-  }  // column tiles of the unit
-  }  // unit loop
+  }  // tile loop
 }
 
 int gemm_small_m_threshold(int set_to) {
   static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 8192};
   if (set_to >= 0) thr.store(set_to);
   return thr.load();
-}
-
-// Row walk for the residual GEMMs (256 x 256 tiles): worth it when dealing whole row blocks fills the grid as well as
-// dealing single tiles does (M = 65 536: 256 row blocks on 256 workgroups), and the statistics fit behind the operand ring.
-static bool residual_row_walk(const GemmParams& p, int grid_cap) {
-  // Opt-in (VRAG_GEMM_ROWWALK=1).  Measured on the headline step (r3d session, three alternating repetitions): 6 362 / 6 356 /
-  // 6 341 chunks/s with the row walk against 6 429 / 6 401 / 6 346 with the tile walk + 84 stand-alone finalize launches --
-  // the launches were never on the critical path of the two-stream schedule, and three column tiles back to back on one CU
-  // re-read their A panel from L2 a little slower than three CUs sharing it do.  Kept for single-stream / graph-captured
-  // schedules, where a launch is a launch.
-  static const bool on = getenv("VRAG_GEMM_ROWWALK") != nullptr;
-  if (!on || !p.fin_mu || !p.fin_rstd || !p.ln_shift || !p.resid_bf16 || p.N % 256 != 0 || p.N > 1024) return false;
-  const int nbm = (p.M + 255) / 256, nbn = p.N / 256;
-  auto fill = [&](int units) { return (double)units / (double)(((units + grid_cap - 1) / grid_cap) * grid_cap); };
-  return fill(nbm) >= fill(nbm * nbn) - 0.02;
 }
 
 // One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
@@ -761,25 +824,6 @@ static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   p.n_tiles = nbm * nbn;
-  p.row_walk = 0;
-  static const int col_groups = getenv("VRAG_GEMM_COLGROUPS") ? atoi(getenv("VRAG_GEMM_COLGROUPS")) : 0;   // tuning knob
-  p.col_groups = (col_groups > 1 && BM == 256 && nbn >= 2 * col_groups && nbm % 8 == 0 && grid_cap % 8 == 0) ? col_groups : 0;
-  if constexpr (EPI == EPI_RESIDUAL && BM == 256 && BN == 256 && NS == 2) {
-    if (residual_row_walk(p, grid_cap)) {
-      constexpr int SMEM_RW = SMEM + 256 * 4 * 4 * 2 * (int)sizeof(float);   // + [256 rows][<= 16 segments][2] statistics
-      static bool attr_rw = false;
-      if (!attr_rw) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_RW);
-        if (e != hipSuccess) return e;
-        attr_rw = true;
-      }
-      p.row_walk = 1;
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>), dim3(std::min(nbm, grid_cap)), dim3(WM * WN * 64),
-                         SMEM + nbn * 256 * 4 * 2 * (int)sizeof(float), stream, p);
-      return hipGetLastError();
-    }
-  }
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
                      stream, p);
   return hipGetLastError();
@@ -804,12 +848,6 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
   if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
     static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
-    if constexpr (EPI == EPI_NONE) {
-      // probe (round 3): the 128 x 256 tile a software-pipelined epilogue would need (64 accumulator registers per wave, so a
-      // second set fits) -- what does the smaller tile cost the main loop?
-      static const bool t128x256 = getenv("VRAG_GEMM_TILE_128x256") != nullptr;
-      if (t128x256) return launch_cfg<EPI, 128, 256, 2, 4, 0, 2, T>(p, pgrid, stream);
-    }
     if constexpr (EPI == EPI_NONE) {
       static const int env_debug = getenv("VRAG_GEMM_DEBUG") ? atoi(getenv("VRAG_GEMM_DEBUG")) : 0;
       if (env_debug) {   // main-loop decomposition probe: results are garbage by design
@@ -841,19 +879,14 @@ static hipError_t launch_typed(GemmEpi epi, const GemmParams& p, hipStream_t str
 hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
   if (p.M <= 0) return hipSuccess;
   if (p.N % 128 != 0 || p.K % BK != 0) return hipErrorInvalidValue;
+  if ((p.lo_in || p.lo_out) && (epi != EPI_RESIDUAL || p.bias || p.res_mu || !p.resid_bf16 || (p.lo_in && !p.ln_shift_prev) || (p.lo_out && !p.ln_shift)))
+    return hipErrorInvalidValue;   // the split stream exists for the pre-LN schedule's plain residual add only
   return p.op_dtype == kOpF16 ? launch_typed<f16_t>(epi, p, stream) : launch_typed<bf16_t>(epi, p, stream);
 }
 
 bool gemm_consumer_finalizes(int rows) {
   static const bool off = getenv("VRAG_GEMM_NO_CONSUMER_STATS") != nullptr;   // A/B knob
   return !off && rows > 0 && rows <= gemm_small_m_threshold(-1);               // launch_t's choice of the 128 x 128, NS = 4 configuration
-}
-
-bool gemm_residual_finalizes(const GemmParams& p) {
-  static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr, res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;
-  static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;
-  if (p.M <= gemm_small_m_threshold(-1) || force128 || res128 || p.N % 256 != 0 || p.M < 256) return false;   // launch_t's choice of the 256 x 256 configuration
-  return residual_row_walk(p, pgrid);
 }
 
 const char* gemm_kernel_name(GemmEpi epi) {

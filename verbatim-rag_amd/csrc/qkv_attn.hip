@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {   // 16-byte chunk index XOR (row >> 1) & 7: the epilogue reads one chunk of 16 DIFFERENT rows per lane group
         const int r = i * 8 + (lane >> 3);
-        glds16(tab + r * 32 + (((lane & 7) ^ ((r >> 1) & 7)) << 2), smem + (wave == 2 ? QA_CB : QA_SB) + i * 1024);
+        glds16(tab + min(r, p.rope_rows - 1) * 32 + (((lane & 7) ^ ((r >> 1) & 7)) << 2), smem + (wave == 2 ? QA_CB : QA_SB) + i * 1024);   // clamped like the 16 b rows: a handle may hold fewer than 16 positions
       }
     }
     if (wave == 4 || wave == 5) {   // rows 16 b

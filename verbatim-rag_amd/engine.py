@@ -332,7 +332,8 @@ class EncoderEngine:
     def set_concurrency(self, n_streams: int) -> None:
         _lib.check("vrag_encoder_set_concurrency", self._lib.vrag_encoder_set_concurrency(self._h, int(n_streams)))
 
-    def set_profiling(self, enabled: bool) -> None:
+    def set_profiling(self, enabled) -> None:
+        """False / 0 = off, True / 1 = HIP events around every launch, n > 1 = around every n-th launch of each kernel class."""
         _lib.check("vrag_encoder_set_profiling", self._lib.vrag_encoder_set_profiling(self._h, int(enabled)))
 
     def read_profile(self, reset: bool = True) -> Dict[str, Tuple[float, int]]:

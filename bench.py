@@ -371,11 +371,21 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
             eng.run_qa_head(stream)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        eng.set_concurrency(1)                  # untimed: the kernels of this batch one at a time, per class
+        eng.run(stream)
+        torch.cuda.synchronize()
+        eng.read_profile(reset=True)
+        eng.set_profiling(1)
+        eng.run(stream)
+        eng.run_qa_head(stream)
+        torch.cuda.synchronize()
+        eng.set_profiling(0)
+        iso = {k: {"avg_launch_us": v[0] / v[1] * 1e3, "ms_per_step": v[0], "launches": v[1]} for k, v in eng.read_profile(reset=True).items() if v[1] > 0}
         eng.close()
         tps = float(lens.sum()) / dt
         return {"ragged_chunks_per_s": len(lens) / dt, "ms_per_step": dt * 1e3, "chunks_per_step": int(len(lens)), "tokens_per_step": int(lens.sum()),
                 "length_min_mean_max": [int(lens.min()), float(lens.mean()), int(lens.max())], "tokens_per_s": tps,
-                "tokens_per_s_vs_512_token_batch": tps / headline_tokens_per_s,
+                "tokens_per_s_vs_512_token_batch": tps / headline_tokens_per_s, "single_stream_pass_by_class": iso,
                 "what": "encoder + sentence head over pairs of 64-512 tokens (seeded, mean ~200), same tokens per step as the headline, resident inputs"}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}

@@ -109,3 +109,70 @@ def test_sharded_gpu_store_world2_equals_single_rank_and_oracle():
     # unit rows of this data set are dyadic with 2 significant bits: exact in bf16 too, so both dtypes equal the oracle
     assert res[0][1]["f32"][1] == oracle
     assert res[0][1]["bf16"][1] == oracle
+
+
+def _extract_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    try:
+        import json
+        import types
+
+        import torch.distributed as dist
+        from tokenizers import Tokenizer
+
+        import verbatim_rag_amd  # noqa: F401
+        from oracle import modernbert_np as O
+        from verbatim_rag_amd.distributed import ShardComm, extract_spans_sharded
+        from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+        from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        G = os.path.join(ROOT, "tests", "golden")
+        tiny = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=192,
+                    pad_token_id=0, cls_token_id=1, sep_token_id=2)
+        w = O.random_weights(O.EncoderConfig(**tiny), seed=7)
+        z = np.load(os.path.join(G, "encoder_tiny.npz"))
+        eng = EncoderEngine(ModernBertShape(**tiny), w, max_tokens=8192, max_seqs=64, max_seq_len=512, max_ranges=1024)
+        eng.set_qa_head(z["qa_Wc"], z["qa_bc"])
+        ext = GpuModelSpanExtractor(engine=eng, tokenizer=Tokenizer.from_file(os.path.join(G, "tokenizer.json")), threshold=0.45)
+        with open(os.path.join(G, "host_fixtures.json")) as f:
+            fx = json.load(f)
+        texts = []
+        for run in fx["extract_e2e"]["runs"]:
+            texts += [t for t in run["texts"] if t not in texts]
+        results = [types.SimpleNamespace(text=t) for t in texts]
+        question = fx["extract_e2e"]["runs"][0]["question"]
+        out = {}
+        for n in (len(results), 5, 1):                       # 1 pair over 2 ranks: rank 1's shard is empty
+            sharded = extract_spans_sharded(ext, question, results[:n], ShardComm(device=0))
+            single = ext.extract_spans(question, results[:n])
+            out[n] = (sharded == single and list(sharded) == list(single), len(single), sum(len(v) for v in single.values()))
+        eng.close()
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:
+        import traceback
+
+        q.put((rank, f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
+
+
+def test_extraction_split_world2_equals_the_single_rank_call():
+    """The OTHER half of the N > 1 path: `shard_range` over the (question, chunk) pairs, one extractor
+    replica per rank (both on GPU 0 here), span dicts gathered -- equal to one rank extracting everything, keys in chunk order."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_extract_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+    for rank, out in res:
+        assert isinstance(out, dict), out
+        assert all(v[0] for v in out.values()), (rank, out)
+        assert out[max(out)][1] >= 4, out                 # the fixture really holds several chunks

@@ -453,3 +453,16 @@ def test_load_reads_the_earlier_on_disk_formats_and_reshards(store, tmp_path):
     back = vs.GpuVectorStore.load(str(tmp_path / "f3"))
     assert back._ids[-2:] == ["odd\nid", "nul"] and back._texts[-2:] == ["line1\nline2 é中", "a\x00b"] and back._meta[-2] == {"k": "v\x00w"}
     assert _answers(back, dense, sparse) == _answers(st, dense, sparse)
+
+
+def test_sparse_terms_beyond_int32_are_rejected_before_the_cast():
+    """a dict term >= 2**31 used to wrap in the int32 cast (2**32 + 5 became term 5) and pass the vocabulary check."""
+    import pytest
+
+    from verbatim_rag_amd.vector_stores import dicts_to_csr
+
+    for bad in (2 ** 32 + 5, 2 ** 31, -(2 ** 31) - 1):
+        with pytest.raises(ValueError):
+            dicts_to_csr([{3: 1.0}, {bad: 1.0}])
+    indptr, terms, weights = dicts_to_csr([{7: 1.0, 3: 2.0}, {}, {2 ** 31 - 1: 0.5}])
+    assert indptr.tolist() == [0, 2, 2, 3] and terms.tolist() == [3, 7, 2 ** 31 - 1] and weights.tolist() == [2.0, 1.0, 0.5]

@@ -1468,6 +1468,19 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   // multiple of kRowPad), micro-batch cuts, q-block descriptors -- plus ONE pass over the ids that copies them into the
   // pinned staging and range-checks them.  The per-row image (ids in their rows, positions, sequence index, pad rows) is
   // laid out on the device by pack_layout_kernel.
+  // Micro-batch cuts: as many micro-batches as the packed rows (tokens + alignment gaps) make at ~micro_batch_tokens each, of EQUAL
+  // size -- never a full one followed by a sliver: a remainder of a few hundred rows is a latency-bound launch chain (2 ms for 22
+  // layers) that runs alone at the end of the step, and a micro-batch a few rows past a whole number of GEMM tile rounds pays a
+  // round for them.  (Round 3 cut greedily at micro_batch_tokens: a ragged 131 072-token batch became 65 5xx + 65 5xx + ~300.)
+  int n_mb_target = 1;
+  int64_t mb_rows_target = 0;
+  if (c.micro_batch_tokens > 0) {
+    int64_t packed = 0;
+    for (int s = 0; s < n_seqs; ++s) packed = align_up(packed, kSeqAlign) + seq_lens[s];
+    n_mb_target = (int)std::max<int64_t>(1, (packed + c.micro_batch_tokens / 2) / c.micro_batch_tokens);
+    if (packed * 8 > (int64_t)n_mb_target * c.micro_batch_tokens * 9) ++n_mb_target;   // more than 1.125 x the nominal size each: one more
+    mb_rows_target = (packed + n_mb_target - 1) / n_mb_target;
+  }
   int t = 0, mb_row0 = 0, mb_blk0 = 0, nblk = 0, mb_lblk0 = 0, nlblk = 0, mb_tokens = 0, mb_seq0 = 0, mb_max_len = 0;
   size_t src = 0;
   const int prev_rows = e->rows;
@@ -1475,7 +1488,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   for (int s = 0; s < n_seqs; ++s) {
     const int Ls = seq_lens[s];
     t = (int)align_up(t, kSeqAlign);
-    if (c.micro_batch_tokens > 0 && mb_tokens > 0 && mb_tokens + Ls > c.micro_batch_tokens) {
+    if (c.micro_batch_tokens > 0 && mb_tokens > 0 && (int)e->mbs.size() + 1 < n_mb_target && (t - mb_row0) + Ls > mb_rows_target) {
       const int row1 = (int)align_up(t, kRowPad);
       e->mbs.push_back({mb_row0, row1, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, s, mb_max_len, mb_tokens});
       mb_seq0 = s;

@@ -221,3 +221,18 @@ class ShardedTopK:
         if not live or (self._comm.world == 1 and not self._comm.on_gpu):
             return np.where(ids >= 0, scores, -np.inf).astype(np.float32), ids
         return self._comm.allgather_merge(scores, ids, k)
+
+
+def extract_spans_sharded(extractor, question: str, search_results: list, comm: "ShardComm"):
+    """The extraction half of the data-parallel path: every rank holds a full extractor replica, takes its
+    contiguous `shard_range` of the (question, chunk) pairs -- the units are independent, so the GPUs exchange nothing while
+    they compute -- and the per-chunk span lists meet in one host-side `all_gather_object` (a few KB of strings).  Returns, on
+    every rank, what `extractor.extract_spans(question, search_results)` returns on one: `{chunk text: [spans]}` in the order
+    of `search_results` (the reference's contract: verbatim_core/extractors.py:233-268, call site verbatim_rag/core.py:255)."""
+    lo, hi = shard_range(len(search_results), comm.rank, comm.world)
+    local = extractor.extract_spans(question, search_results[lo:hi]) if hi > lo else {}
+    merged: dict = {}
+    for part in comm.gather_objects(local):      # rank order == chunk order; a text seen twice keeps its first entry's position
+        for text, spans in part.items():
+            merged.setdefault(text, spans)
+    return merged

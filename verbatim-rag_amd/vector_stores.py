@@ -286,10 +286,12 @@ def dicts_to_csr(rows: Sequence[Dict[int, float]]) -> Tuple[np.ndarray, np.ndarr
     total = int(indptr[-1])
     terms = np.fromiter(chain.from_iterable(rows), np.int64, total)                       # iterating a dict yields its keys
     weights = np.fromiter(chain.from_iterable(r.values() for r in rows), np.float64, total)
-    if total and (terms.min() < 0 or terms.max() > np.iinfo(np.int32).max):
-        # checked on the int64 keys: a term >= 2**31 would wrap in the int32 cast below and pass a later range check
-        bad = int(np.searchsorted(indptr, np.nonzero((terms < 0) | (terms > np.iinfo(np.int32).max))[0][0], side="right") - 1)
-        raise ValueError(f"sparse vector {bad} has a term outside [0, 2**31)")
+    i32 = np.iinfo(np.int32)
+    if total and (terms.min() < i32.min or terms.max() > i32.max):
+        # checked on the int64 keys: a term that does not fit int32 would wrap in the cast below and pass the later range checks
+        # (terms that fit but lie outside the vocabulary are rejected there, by the caller or the C layer)
+        bad = int(np.searchsorted(indptr, np.nonzero((terms < i32.min) | (terms > i32.max))[0][0], side="right") - 1)
+        raise ValueError(f"sparse vector {bad} has a term outside the int32 range")
     order = np.lexsort((terms, np.repeat(np.arange(n, dtype=np.int64), lens)))
     return indptr, terms[order].astype(np.int32), weights[order].astype(np.float32)
 

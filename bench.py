@@ -309,17 +309,26 @@ def token_head_f16_leg(shape, weights, seqs, micro_batch_tokens: int, device: in
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def ragged_lengths(total_tokens: int, seed: int = 4242, lo: int = 64, hi: int = SEQ, mean: float = 200.0) -> np.ndarray:
+def ragged_lengths(rows_per_micro_batch: int, n_micro_batches: int, seed: int = 4242, lo: int = 64, hi: int = SEQ, mean: float = 200.0) -> np.ndarray:
     """Seeded pair lengths in [lo, hi] with mean ~`mean` (what the reference's 512-CHARACTER chunker produces once the question
     is prepended: verbatim_rag/chunker_providers.py:531-572 cuts ~100-150-token windows; longer ones come from the markdown
-    chunkers) -- a shifted, clipped gamma; sequences are drawn until `total_tokens` is reached."""
+    chunkers) -- a shifted, clipped gamma.  The batch is formed the way a serving batcher fills the engine: pairs are drawn until
+    a micro-batch's packed rows (tokens + the 8-row alignment gap after every pair) are full, the last pair of a micro-batch
+    taking exactly the rows that are left -- so every micro-batch is a whole number of GEMM tile rounds, like the headline batch."""
     rng = np.random.default_rng(seed)
-    out, tot = [], 0
-    while tot < total_tokens:
-        n = int(np.clip(lo + rng.gamma(2.0, (mean - lo) / 2.0), lo, hi))
-        n = min(n, max(lo, total_tokens - tot))
-        out.append(n)
-        tot += n
+    out = []
+    for _ in range(n_micro_batches):
+        rows = 0
+        while True:
+            left = rows_per_micro_batch - rows
+            if left <= hi:
+                out.append(left)
+                break
+            n = int(np.clip(lo + rng.gamma(2.0, (mean - lo) / 2.0), lo, hi))
+            if left - (n + 7) // 8 * 8 < lo:          # do not leave a remainder shorter than the shortest pair
+                n = max(lo, n - lo - 8)
+            out.append(n)
+            rows += (n + 7) // 8 * 8
     return np.asarray(out, np.int32)
 
 
@@ -343,15 +352,16 @@ def synth_ragged_batch(shape, lens, seed: int):
 
 
 def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int, device: int, steps: int, headline_tokens_per_s: float):
-    """The headline step on the pair lengths real chunkers produce: the same number of tokens per step
-    (131 072) as pairs of 64-512 tokens, mean ~200, inputs resident, encoder + sentence head.  Reported beside the headline as
-    chunks/s and as tokens/s relative to the 512-token batch.  Never raises."""
+    """The headline step on the pair lengths real chunkers produce: the same packed rows per step (131 072,
+    two full micro-batches) as pairs of 64-512 tokens, mean ~200, inputs resident, encoder + sentence head.  Reported beside the
+    headline as chunks/s and as tokens/s (real tokens, alignment gaps not counted) relative to the 512-token batch.  Never raises."""
     try:
         import torch
 
         from verbatim_rag_amd.engine import EncoderEngine
 
-        lens = ragged_lengths(tokens)
+        mbt = micro_batch_tokens or tokens
+        lens = ragged_lengths(mbt, max(1, tokens // mbt))
         seqs, bounds = synth_ragged_batch(shape, lens, seed=77)
         n_rng = sum(len(b) for b in bounds)
         eng = EncoderEngine(shape, weights, max_tokens=int(lens.sum()) + 8 * len(lens), max_seqs=len(lens), max_seq_len=SEQ,
@@ -386,7 +396,7 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
         return {"ragged_chunks_per_s": len(lens) / dt, "ms_per_step": dt * 1e3, "chunks_per_step": int(len(lens)), "tokens_per_step": int(lens.sum()),
                 "length_min_mean_max": [int(lens.min()), float(lens.mean()), int(lens.max())], "tokens_per_s": tps,
                 "tokens_per_s_vs_512_token_batch": tps / headline_tokens_per_s, "single_stream_pass_by_class": iso,
-                "what": "encoder + sentence head over pairs of 64-512 tokens (seeded, mean ~200), same tokens per step as the headline, resident inputs"}
+                "what": "encoder + sentence head over pairs of 64-512 tokens (seeded, mean ~200) filling the same two 65 536-row micro-batches as the headline (8-row alignment gaps between pairs are rows, not tokens), resident inputs"}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}
 

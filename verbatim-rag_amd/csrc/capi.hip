@@ -568,8 +568,6 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         f.Tp = Tp;
         f.window = c.sliding_window;
         f.q_scale = 0.125f * 1.4426950408889634f;
-        static const int fused_dbg = getenv("VRAG_FUSED_DEBUG") ? atoi(getenv("VRAG_FUSED_DEBUG")) : 0;
-        f.debug_flags = fused_dbg;
         ProfScope ps(e, global ? VRAG_PROF_QKV_ATTN_GLOBAL : VRAG_PROF_QKV_ATTN_LOCAL, st);
         HIP_TRY(launch_qkv_attention(f, !global, st));
       } else {

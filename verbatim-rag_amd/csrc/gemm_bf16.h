@@ -70,7 +70,6 @@ struct GemmParams {
   int op_dtype;           // kOpBf16 (0) or kOpF16 (1): what A, W and every 16-bit output hold (pointers stay typed bf16_t*)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias
-  int debug_flags;        // EPI_NONE tuning probe (VRAG_GEMM_DEBUG): 1 = no operand DMA after the first K-step, 2 = no fragment reads (zero operands), 4 = with 2: fresh pseudo-random register operands, 8 = with 2: loop-invariant pseudo-random register operands
 };
 
 // Launches on `stream`. Requirements: N % 128 == 0, K % 64 == 0.

@@ -628,11 +628,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 }
 
 // BM x BN tile, WM x WN waves; every wave owns (BM/WM) x 64 outputs (RT = BM/WM/16 row tiles, 4 column tiles).
-// DBG = 1 compiles the main-loop decomposition probe (p.debug_flags), instantiated for EPI_NONE only.
 // NS = LDS stages.  2: the throughput configuration (one stage in flight, plain barriers).  4: the
 // small-batch configuration -- with a handful of tiles the K loop is a chain of memory round trips, and three
 // stages in flight (counted vmcnt, raw barriers) cut that chain to a third.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG = 0, int NS = 2, typename T = bf16_t>
+template <int EPI, int BM, int BN, int WM, int WN, int NS = 2, typename T = bf16_t>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
@@ -737,26 +736,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       if (i < KT) stage(i, i);
     wait_allow(min(NS - 1, KT) - 1);
     step_barrier();
-    auto pseudo_random = [&](unsigned seed) {   // sign + mantissa random, exponent 127
-      unsigned h = (unsigned)(lane * 2654435761u) ^ (seed * 40503u);
-      unsigned w4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        h = h * 1664525u + 1013904223u;
-        w4[j] = (h & 0x807f807fu) | 0x3f803f80u;
-      }
-      return __builtin_bit_cast(V8, f32x4{__builtin_bit_cast(float, w4[0]), __builtin_bit_cast(float, w4[1]),
-                                          __builtin_bit_cast(float, w4[2]), __builtin_bit_cast(float, w4[3])});
-    };
-    V8 dbg_f[RT + 4] = {};   // DBG flag 8: loop-invariant pseudo-random register operands
-    if (DBG && (p.debug_flags & 8)) {
-#pragma unroll
-      for (int i = 0; i < RT + 4; ++i) dbg_f[i] = pseudo_random(i);
-    }
     int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
       const int nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;   // the slot read in step kt-1: every wave passed the barrier since
-      const bool do_stage = nxt < KT && !(DBG && (p.debug_flags & 1) && kt >= 1);
+      const bool do_stage = nxt < KT;
       if (do_stage) stage(nxt, nbuf);   // right after the barrier (issuing half of the waves' share a substep later: no difference, r2s)
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
@@ -769,18 +752,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (DBG && (p.debug_flags & 8)) wf[s][i] = dbg_f[RT + i];
-          else if (DBG && (p.debug_flags & 4)) wf[s][i] = pseudo_random((unsigned)((RT + i) * KS + s + kt * 16));
-          if (!(DBG && (p.debug_flags & 2))) wf[s][i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
+          wf[s][i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
         }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         V8 af[KS] = {};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          if (DBG && (p.debug_flags & 8)) af[s] = dbg_f[rt];
-          else if (DBG && (p.debug_flags & 4)) af[s] = pseudo_random((unsigned)(rt * KS + s + kt * 16));
-          if (!(DBG && (p.debug_flags & 2))) af[s] = *reinterpret_cast<const V8*>(sA + rt * 16 * ROWB + fo[s]);
+          af[s] = *reinterpret_cast<const V8*>(sA + rt * 16 * ROWB + fo[s]);
         }
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj)
@@ -806,59 +785,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
 }
 
 int gemm_small_m_threshold(int set_to) {
-  static std::atomic<int> thr{getenv("VRAG_GEMM_SMALL_M") ? atoi(getenv("VRAG_GEMM_SMALL_M")) : 8192};
+  static std::atomic<int> thr{8192};
   if (set_to >= 0) thr.store(set_to);
   return thr.load();
 }
 
 // One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
-template <int EPI, int BM, int BN, int WM, int WN, int DBG, int NS, typename T>
+template <int EPI, int BM, int BN, int WM, int WN, int NS, typename T>
 static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
   constexpr int SMEM = NS * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   p.n_tiles = nbm * nbn;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, DBG, NS, T>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
                      stream, p);
   return hipGetLastError();
 }
 
 template <int EPI, typename T>
 hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
-  static const bool force128 = getenv("VRAG_GEMM_TILE128") != nullptr;  // tuning knob
   // Small batches (a query's handful of chunks): few tiles, so the K loop's chain of memory round trips is the
   // whole kernel -- 128x128 tiles (4x the workgroups) with four LDS stages (three K-steps in flight), 1 workgroup per CU.
   if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) {
     if constexpr (EPI == EPI_RESIDUAL) {
       // N = 768 at ~1 000 rows is 48 tiles of 128 x 128 on 256 CUs, and a K-step there is bound by what ONE CU's LDS-DMA
       // brings in (32 KiB per step: 1.2 us measured, profiles/r03_latency_kernel_stats.txt), not by its 0.25 us of MFMAs:
-      // 64 x 64 tiles (one wave each, 16 KiB per step) spread the same bytes over four times the CUs.
-      // Measured (r3i session, alternating runs): extract_spans(question, 5 chunks) 1.83 -> 1.74 ms, parity suite unchanged.
-      static const int small_res = getenv("VRAG_GEMM_SMALL_RES64") ? atoi(getenv("VRAG_GEMM_SMALL_RES64")) : 1;
-      if (small_res && (int64_t)((p.M + 127) / 128) * (p.N / 128) <= 128) return launch_cfg<EPI, 64, 64, 1, 1, 0, 4, T>(p, 1024, stream);
+      // 64 x 64 tiles (one wave each, 16 KiB per step) spread the same bytes over four times the CUs
+      // (extract_spans(question, 5 chunks) 1.83 -> 1.74 ms, profiles/r03_small_residual_tiles_ab.txt).
+      if ((int64_t)((p.M + 127) / 128) * (p.N / 128) <= 128) return launch_cfg<EPI, 64, 64, 1, 1, 4, T>(p, 1024, stream);
     }
-    return launch_cfg<EPI, 128, 128, 2, 2, 0, 4, T>(p, 256, stream);
+    return launch_cfg<EPI, 128, 128, 2, 2, 4, T>(p, 256, stream);
   }
-  static const bool res128 = getenv("VRAG_GEMM_RES_TILE128") != nullptr;  // tuning knob: residual GEMMs on 128x128 tiles, 2 workgroups / CU
-  if (!force128 && !(res128 && EPI == EPI_RESIDUAL) && p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0)) {
-    static const int pgrid = getenv("VRAG_GEMM_PGRID") ? atoi(getenv("VRAG_GEMM_PGRID")) : 256;  // workgroups (1 per CU)
-    if constexpr (EPI == EPI_NONE) {
-      static const int env_debug = getenv("VRAG_GEMM_DEBUG") ? atoi(getenv("VRAG_GEMM_DEBUG")) : 0;
-      if (env_debug) {   // main-loop decomposition probe: results are garbage by design
-        GemmParams pd = p;
-        pd.debug_flags = env_debug;
-        return launch_cfg<EPI, 256, 256, 2, 4, 1, 2, T>(pd, pgrid, stream);
-      }
-    }
-    return launch_cfg<EPI, 256, 256, 2, 4, 0, 2, T>(p, pgrid, stream);
-  }
-  return launch_cfg<EPI, 128, 128, 2, 2, 0, 2, T>(p, 512, stream);
+  if (p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0))
+    return launch_cfg<EPI, 256, 256, 2, 4, 2, T>(p, 256, stream);   // one persistent workgroup per CU
+  return launch_cfg<EPI, 128, 128, 2, 2, 2, T>(p, 512, stream);
 }
 
 template <typename T>
@@ -885,8 +851,7 @@ hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
 }
 
 bool gemm_consumer_finalizes(int rows) {
-  static const bool off = getenv("VRAG_GEMM_NO_CONSUMER_STATS") != nullptr;   // A/B knob
-  return !off && rows > 0 && rows <= gemm_small_m_threshold(-1);               // launch_t's choice of the 128 x 128, NS = 4 configuration
+  return rows > 0 && rows <= gemm_small_m_threshold(-1);               // launch_t's choice of the 128 x 128, NS = 4 configuration
 }
 
 const char* gemm_kernel_name(GemmEpi epi) {

@@ -230,16 +230,14 @@ __global__ __launch_bounds__(256) void dense_topk_kernel(const void* __restrict_
 
 // rows per workgroup of the streaming (non-MFMA) kernels: the shard is cut into <= DENSE_WGS equal contiguous ranges
 static int dense_rows_per_wg(long long n) {
-  static const int target = getenv("VRAG_TOPK_WGS") ? std::max(1, atoi(getenv("VRAG_TOPK_WGS"))) : DENSE_WGS;
-  const long long per = (n + target - 1) / target;
+  const long long per = (n + DENSE_WGS - 1) / DENSE_WGS;
   return (int)std::max<long long>(DROWS_MIN, (per + DROWS_MIN - 1) / DROWS_MIN * DROWS_MIN);
 }
 
 template <bool F32>
 static hipError_t dense_launch_pass(const void* rows, long long n, int dim, const float* dq, int nq, int q0, int qt, int k,
                                     u64* cand, int n_wg, hipStream_t st, const u64* bound) {
-  static const bool strided = getenv("VRAG_TOPK_STRIDED") != nullptr;
-  const int per = (strided && qt == 1) ? 0 : dense_rows_per_wg(n);
+  const int per = dense_rows_per_wg(n);
   const size_t lds = (size_t)qt * dim * sizeof(float) + (size_t)16 * qt * k * sizeof(u64);
   const int cstr = F32 ? 64 : 128;
   const int dimc = dim % cstr == 0 ? dim / cstr : -1;
@@ -921,8 +919,8 @@ struct Mfma2Plan {
   int n_wg0, per1, n_wg1;
 };
 static Mfma2Plan dense_mfma2_plan(long long n) {
-  static const int target = getenv("VRAG_TOPK_MWGS") ? std::max(1, atoi(getenv("VRAG_TOPK_MWGS"))) : 256;
-  static const long long pre = getenv("VRAG_TOPK_PREFIX") ? atoll(getenv("VRAG_TOPK_PREFIX")) : 32768;
+  constexpr int target = 256;           // workgroups of the main pass (one per CU)
+  constexpr long long pre = 32768;      // rows of the threshold-seeding prefix pass
   Mfma2Plan p{};
   p.prefix = (pre > 0 && n >= 4 * pre) ? pre / 128 * 128 : 0;
   p.n_wg0 = (int)(p.prefix / 128);
@@ -934,8 +932,7 @@ static Mfma2Plan dense_mfma2_plan(long long n) {
 }
 
 static bool dense_use_mfma2(int dim) {
-  static const bool off = getenv("VRAG_TOPK_MFMA1") != nullptr;   // tuning: force the first-generation kernel
-  return !off && (dim == 384 || dim == 768 || dim == 1024);
+  return dim == 384 || dim == 768 || dim == 1024;
 }
 static bool dense_use_exact(int dtype, int dim, int k) {
   static const bool off = getenv("VRAG_TOPK_NO_EXACT") != nullptr;   // tuning: fp32 rows on the scalar kernels
@@ -1012,8 +1009,7 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
     return pass(pl.prefix, n, pl.per1, pl.n_wg1, cand + (size_t)pl.n_wg0 * nq * k);
   }
   if (dense_use_mfma(dtype, dim, nq, k) && dense_use_mfma2(dim)) {
-    static const int dbg_fill = getenv("VRAG_TOPK_DEBUG_NOINSERT") ? 0xff : 0;   // probe: reject every key
-    hipError_t me = hipMemsetAsync(thr, dbg_fill, (size_t)nq * sizeof(u64), st);
+    hipError_t me = hipMemsetAsync(thr, 0, (size_t)nq * sizeof(u64), st);
     if (me != hipSuccess) return me;
     const size_t lds2 = (size_t)M2SLOTS * 16384 + (size_t)256 * k * 8;
     static bool attr2 = false;
@@ -1039,7 +1035,7 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
       return hipSuccess;
     };
     const Mfma2Plan pl = dense_mfma2_plan(n);
-    if (pl.prefix > 0 && !dbg_fill) {
+    if (pl.prefix > 0) {
       // seeding pass: exact top-k of the first `prefix` rows -> per-query entry threshold for the main pass
       hipError_t e = pass(0, pl.prefix, 128, pl.n_wg0, cand);
       if (e == hipSuccess) e = launch_topk_merge(cand, pl.n_wg0, nq, k, out, st);

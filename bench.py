@@ -638,8 +638,9 @@ def main() -> None:
                          "qkv_attn_local": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + M_mb * Hs * 2,
                          "gemm_qkv": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + 3 * M_mb * Hs * 2,
                          "gemm_wi": M_mb * Hs * 2 + 2 * Is * Hs * 2 + M_mb * Is * 2,
-                         "gemm_wo": M_mb * Hs * 2 + Hs * Hs * 2 + 2 * M_mb * Hs * 4 + 2 * M_mb * Hs,
-                         "gemm_wo_mlp": M_mb * Is * 2 + Hs * Is * 2 + 2 * M_mb * Hs * 4 + 2 * M_mb * Hs}
+                         # residual GEMMs, split stream (round 4): A operand + weights + two 16-bit planes in and out (8 B per element)
+                         "gemm_wo": M_mb * Hs * 2 + Hs * Hs * 2 + 2 * M_mb * Hs * 4,
+                         "gemm_wo_mlp": M_mb * Is * 2 + Hs * Is * 2 + 2 * M_mb * Hs * 4}
             dom_bytes = float(np.mean([alg_bytes[k] for k in classes[dom]]))
             gbps = dom_bytes / (t["avg_launch_ms"] * 1e-3) / 1e9
             frac_mfma, frac_hbm = t["tflops"] / PEAK_BF16_TFLOPS, gbps / PEAK_HBM_GBPS

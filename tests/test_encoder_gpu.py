@@ -343,3 +343,21 @@ def test_graph_cache_keeps_the_two_attention_paths_apart():
         lib.vrag_debug_set_gemm_small_m(8192)
         eager.close()
         graphed.close()
+
+
+def test_fp32_residual_rows_mode_in_a_child_process():
+    """`VRAG_SPLIT_RESID=0` (read once per handle, at creation): the residual stream as fp32 rows between all sub-layers -- the
+    round-3 form of the residual epilogue, kept as the A/B reference of the split stream.  A child process runs the per-layer
+    stream, fold-stress and logit tests of this module under it (both GEMM configurations)."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("VRAG_SPLIT_RESID") == "0":
+        pytest.skip("already inside the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_encoder_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+         "residual_stream_per_layer or qa_logits_within_1e3 or layernorm_fold_with_row_mean or final_hidden_and_padding"],
+        env={**os.environ, "VRAG_SPLIT_RESID": "0"}, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

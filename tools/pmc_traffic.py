@@ -32,12 +32,14 @@ def main(pmc_path, bench_path):
     bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
     rows = min(bench["config"]["micro_batch_tokens"] or 131072, bench["config"]["chunks_per_gpu_per_step"] * bench["config"]["seq_len"])
     H, I = 768, 1152
-    fold = 2 * rows * H  # bf16 copy of the new residual written by the residual epilogues (LayerNorm fold)
+    # residual GEMMs (round 4): the stream arrives and leaves as two 16-bit planes -- 4 B read + 4 B written per element, the
+    # written high plane being the next GEMM's operand copy (round 3: 8 B of fp32 read-modify-write + a 2 B copy)
+    stream = 2 * rows * H * 4
     alg = {
         "gemm_qkv": rows * H * 2 + 3 * H * H * 2 + 3 * rows * H * 2,
         "gemm_wi": rows * H * 2 + 2 * I * H * 2 + rows * I * 2,
-        "gemm_wo": rows * H * 2 + H * H * 2 + 2 * rows * H * 4 + fold,
-        "gemm_wo_mlp": rows * I * 2 + H * I * 2 + 2 * rows * H * 4 + fold,
+        "gemm_wo": rows * H * 2 + H * H * 2 + stream,
+        "gemm_wo_mlp": rows * I * 2 + H * I * 2 + stream,
     }
     epi = {"gemm_qkv": 5, "gemm_wi": 4, "gemm_wo": 3, "gemm_wo_mlp": 3}
     res = {}

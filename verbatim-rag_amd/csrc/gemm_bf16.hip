@@ -423,13 +423,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int nj = 0; nj < 2; ++nj) {
           V4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x1 = acc[nj][rt][j], x2 = acc[nj + 2][rt][j];
+          for (int h = 0; h < 2; ++h) {   // two outputs at a time: packed fp32 (gelu_fast2, common.h)
+            f32x2 x1 = {acc[nj][rt][2 * h], acc[nj][rt][2 * h + 1]}, x2 = {acc[nj + 2][rt][2 * h], acc[nj + 2][rt][2 * h + 1]};
             if constexpr (FOLD) {
-              x1 = rs * (x1 - mu * s1[nj][j]);
-              x2 = rs * (x2 - mu * s2[nj][j]);
+              x1 = pk_fma(splat2(-mu), f32x2{s1[nj][2 * h], s1[nj][2 * h + 1]}, x1) * rs;
+              x2 = pk_fma(splat2(-mu), f32x2{s2[nj][2 * h], s2[nj][2 * h + 1]}, x2) * rs;
             }
-            o[j] = Op<T>::to(gelu_fast(x1) * x2);
+            const f32x2 g = gelu_fast2(x1) * x2;
+            o[2 * h] = Op<T>::to(g[0]);
+            o[2 * h + 1] = Op<T>::to(g[1]);
           }
           put_pair(rt * 16 + l15, nj * 16 + 4 * q, o);
         }

@@ -468,6 +468,8 @@ def main() -> None:
     ap.add_argument("--model", choices=["base", "large"], default="base",
                     help="base = BASELINE configs[1] (the metric); large = ModernBERT-large geometry (configs[4] extractor), informational")
     args = ap.parse_args()
+    if os.environ.get("VRAG_BENCH_SKIP_LEGS"):   # A/B sessions (tools/ab_streams.sh): the headline and its roofline only
+        args.cpu_budget = 0.0
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` on its own: become the launcher the driver would have used (one rank per GPU)

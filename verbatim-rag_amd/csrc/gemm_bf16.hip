@@ -96,40 +96,37 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + rowp * 256 + (((2 * l7) ^ (rowp & 15)) << 4));
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + rowp * 256 + (((2 * l7 + 1) ^ (rowp & 15)) << 4));
       const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rowp << 2, __builtin_bit_cast(int, off[ps])));
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = a0[j];
-        v[4 + j] = a1[j];
-      }
+      // the additions and the statistics as packed fp32 (two columns per issue slot)
+      f32x2 v[4] = {{a0[0], a0[1]}, {a0[2], a0[3]}, {a1[0], a1[1]}, {a1[2], a1[3]}};
       if (in_split) {
         const V8 hi = __builtin_bit_cast(V8, hv[i][0]);
         const f16x8 lo = __builtin_bit_cast(f16x8, hv[i][1]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)hi[j] + (float)lo[j];
+        for (int j = 0; j < 4; ++j) v[j] += f32x2{(float)hi[2 * j], (float)hi[2 * j + 1]} + f32x2{(float)lo[2 * j], (float)lo[2 * j + 1]};
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] += hv[i][0][j];
-          v[4 + j] += hv[i][1][j];
+        for (int j = 0; j < 2; ++j) {
+          v[j] += f32x2{hv[i][0][2 * j], hv[i][0][2 * j + 1]};
+          v[2 + j] += f32x2{hv[i][1][2 * j], hv[i][1][2 * j + 1]};
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += o;
+      for (int j = 0; j < 4; ++j) v[j] += o;
       const size_t rb = row_base(hp, i);
       if (out_split) {
         V8 ho;
         f16x8 lw;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          ho[j] = Op<T>::to(v[j]);
-          lw[j] = (f16_t)(v[j] - (float)ho[j]);
+          ho[j] = Op<T>::to(v[j >> 1][j & 1]);
+          lw[j] = (f16_t)(v[j >> 1][j & 1] - (float)ho[j]);
         }
         store16_nt(p.resid_bf16 + rb + loff, __builtin_bit_cast(f32x4, ho));
         store16_nt(p.lo_out + rb + loff, __builtin_bit_cast(f32x4, lw));
         if (p.stats_part) {
-          float s1 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-          float s2 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+          const f32x2 t1 = (v[0] + v[1]) + (v[2] + v[3]);
+          const f32x2 t2 = pk_fma(v[3], v[3], pk_fma(v[2], v[2], pk_fma(v[1], v[1], v[0] * v[0])));
+          float s1 = t1[0] + t1[1], s2 = t2[0] + t2[1];
           s1 = row8_sum(s1);
           s2 = row8_sum(s2);
           if (l7 == 0) {
@@ -139,8 +136,8 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
           }
         }
       } else {
-        store16_nt(p.out_f32 + rb + loff, f32x4{v[0], v[1], v[2], v[3]});
-        store16_nt(p.out_f32 + rb + loff + 4, f32x4{v[4], v[5], v[6], v[7]});
+        store16_nt(p.out_f32 + rb + loff, f32x4{v[0][0], v[0][1], v[1][0], v[1][1]});
+        store16_nt(p.out_f32 + rb + loff + 4, f32x4{v[2][0], v[2][1], v[3][0], v[3][1]});
       }
     }
   };
@@ -508,19 +505,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
               const f32x4 c = cz[g & 1][i][nj], sv = sz[g & 1][i][nj];
               V4 o1, o2;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                float x1 = acc[nj][rt][j], x2 = acc[nj + 2][rt][j];
+              for (int h = 0; h < 2; ++h) {   // two features at a time as packed fp32 (see gelu_fast2, common.h)
+                const int j0 = 2 * h;
+                f32x2 x1 = {acc[nj][rt][j0], acc[nj][rt][j0 + 1]}, x2 = {acc[nj + 2][rt][j0], acc[nj + 2][rt][j0 + 1]};
                 if constexpr (FOLD) {
-                  x1 = rs * (x1 - mu * ls1[nj][j]);
-                  x2 = rs * (x2 - mu * ls2[nj][j]);
+                  x1 = pk_fma(splat2(-mu), f32x2{ls1[nj][j0], ls1[nj][j0 + 1]}, x1) * rs;
+                  x2 = pk_fma(splat2(-mu), f32x2{ls2[nj][j0], ls2[nj][j0 + 1]}, x2) * rs;
                 }
                 if constexpr (BIAS) {
-                  x1 += b1[nj][j];
-                  x2 += b2[nj][j];
+                  x1 += f32x2{b1[nj][j0], b1[nj][j0 + 1]};
+                  x2 += f32x2{b2[nj][j0], b2[nj][j0 + 1]};
                 }
+                const f32x2 c2 = {c[j0], c[j0 + 1]}, s2 = {sv[j0], sv[j0 + 1]};
                 // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
-                o1[j] = Op<T>::to((x1 * c[j] - x2 * sv[j]) * scale);
-                o2[j] = Op<T>::to((x2 * c[j] + x1 * sv[j]) * scale);
+                const f32x2 r1 = pk_fma(-x2, s2, x1 * c2) * scale, r2 = pk_fma(x1, s2, x2 * c2) * scale;
+                o1[j0] = Op<T>::to(r1[0]);
+                o1[j0 + 1] = Op<T>::to(r1[1]);
+                o2[j0] = Op<T>::to(r2[0]);
+                o2[j0 + 1] = Op<T>::to(r2[1]);
               }
               put_bf16(rt * 16 + l15, dd, o1, 128);
               put_bf16(rt * 16 + l15, dd + 32, o2, 128);
@@ -564,11 +566,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           for (int rt = 0; rt < RT; ++rt) {
             V4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float v = acc[nj][rt][j];
-              if constexpr (FOLD) v = rs4[rt][j] * (v - mu4[rt][j] * sn_);
+            for (int h = 0; h < 2; ++h) {   // packed fp32, two tokens at a time
+              const int j0 = 2 * h;
+              f32x2 v = {acc[nj][rt][j0], acc[nj][rt][j0 + 1]};
+              if constexpr (FOLD) v = pk_fma(f32x2{-mu4[rt][j0], -mu4[rt][j0 + 1]}, splat2(sn_), v) * f32x2{rs4[rt][j0], rs4[rt][j0 + 1]};
               if constexpr (BIAS) v += bv_;
-              o[j] = Op<T>::to(v);
+              o[j0] = Op<T>::to(v[0]);
+              o[j0 + 1] = Op<T>::to(v[1]);
             }
             put_bf16(nj * 16 + l15, rt * 16 + 4 * q, o, RB);
           }

@@ -218,10 +218,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
           r4 = *reinterpret_cast<const f32x4*>(l_rs + rt * 16 + 4 * g);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = r4[r] * (acc[8 + db][rt][r] - m4[r] * lsv);
-          // keys past the end are masked to probability 0: their V must be a finite number for 0 * v to stay 0
-          vv[a * 4 + r] = qrow0 + rt * 16 + 4 * g + r < S ? Op<T>::to(v) : (T)0.f;
+        for (int h = 0; h < 2; ++h) {   // packed fp32, two tokens at a time
+          const int r0 = 2 * h;
+          const f32x2 v = pk_fma(f32x2{-m4[r0], -m4[r0 + 1]}, splat2(lsv), f32x2{acc[8 + db][rt][r0], acc[8 + db][rt][r0 + 1]}) * f32x2{r4[r0], r4[r0 + 1]};
+#pragma unroll
+          for (int e = 0; e < 2; ++e)   // keys past the end are masked to probability 0: their V must be a finite number for 0 * v to stay 0
+            vv[a * 4 + r0 + e] = qrow0 + rt * 16 + 4 * g + r0 + e < S ? Op<T>::to(v[e]) : (T)0.f;
         }
       }
       const int c = wave * 8 + tp * 4 + g;   // 16-byte chunk of the row: keys 64 w + 32 tp .. + 31, slot order (see top)
@@ -245,24 +247,31 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         l1 = *reinterpret_cast<const f32x4*>(l_ls + ls_off + dd);
         l2 = *reinterpret_cast<const f32x4*>(l_ls + ls_off + 32 + dd);
       }
+      // two columns at a time as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 on the accumulators' own register pairs; round 4):
+      // this epilogue is VALU-bound, and every operation of it is FMA-class -- same operations, same order as the scalar form
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x1 = acc[a0 + np][rt][j], x2 = acc[a0 + 2 + np][rt][j];
+      for (int h = 0; h < 2; ++h) {
+        const int j0 = 2 * h;
+        f32x2 x1 = {acc[a0 + np][rt][j0], acc[a0 + np][rt][j0 + 1]}, x2 = {acc[a0 + 2 + np][rt][j0], acc[a0 + 2 + np][rt][j0 + 1]};
         if constexpr (FOLD) {
-          x1 = rs * (x1 - mu * l1[j]);
-          x2 = rs * (x2 - mu * l2[j]);
+          x1 = pk_fma(splat2(-mu), f32x2{l1[j0], l1[j0 + 1]}, x1) * rs;
+          x2 = pk_fma(splat2(-mu), f32x2{l2[j0], l2[j0 + 1]}, x2) * rs;
         }
-        const float c = ca[j] * cb[j] - sa[j] * sb[j], sn = sa[j] * cb[j] + ca[j] * sb[j];   // cos / sin of (16 b + i) f
+        const f32x2 ca2 = {ca[j0], ca[j0 + 1]}, sa2 = {sa[j0], sa[j0 + 1]}, cb2 = {cb[j0], cb[j0 + 1]}, sb2 = {sb[j0], sb[j0 + 1]};
+        const f32x2 c = pk_fma(-sa2, sb2, ca2 * cb2), sn = pk_fma(ca2, sb2, sa2 * cb2);   // cos / sin of (16 b + i) f
         // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)  (TF:188-219)
-        const float o1 = (x1 * c - x2 * sn) * scale, o2 = (x2 * c + x1 * sn) * scale;
+        const f32x2 o1 = pk_fma(-x2, sn, x1 * c) * scale, o2 = pk_fma(x1, sn, x2 * c) * scale;
         // rows past the end of the sequence are masked (keys) or never stored (queries); only the fp16 conversion cares,
         // because it reports values it has to clamp
-        if constexpr (!std::is_same<T, bf16_t>::value) {
-          out[0][np * 4 + j] = live ? Op<T>::to(o1) : (T)0.f;
-          out[1][np * 4 + j] = live ? Op<T>::to(o2) : (T)0.f;
-        } else {
-          out[0][np * 4 + j] = Op<T>::to(o1);
-          out[1][np * 4 + j] = Op<T>::to(o2);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if constexpr (!std::is_same<T, bf16_t>::value) {
+            out[0][np * 4 + j0 + e] = live ? Op<T>::to(o1[e]) : (T)0.f;
+            out[1][np * 4 + j0 + e] = live ? Op<T>::to(o2[e]) : (T)0.f;
+          } else {
+            out[0][np * 4 + j0 + e] = Op<T>::to(o1[e]);
+            out[1][np * 4 + j0 + e] = Op<T>::to(o2[e]);
+          }
         }
       }
     }

@@ -25,6 +25,13 @@ def test_encoder_suite_through_the_fused_kernel():
     _run(["tests/test_encoder_gpu.py", "tests/test_heads_gpu.py"], 2)
 
 
+def test_fuzzed_batches_through_the_fused_kernel():
+    """Round 4: wave-slot packing -- a workgroup holds a group of consecutive sequences, each on ceil(S / 64) of its eight waves.
+    The randomised batch compositions of test_fuzz_gpu.py (1 .. 512 tokens, up to 23 sequences, random micro-batch cuts) give
+    groups of every shape: many one-wave sequences in one workgroup, a sequence ending a group, a 512-token one alone."""
+    _run(["tests/test_fuzz_gpu.py"], 2)
+
+
 def test_headline_batch_through_the_two_kernel_path():
     """The other direction: the 256 x 512 batch with the fused kernel switched off (what sequences above 512 tokens get)."""
     _run(["tests/test_full_shapes_gpu.py::test_configs1_batch_256x512_sample_vs_oracle"], 0)

@@ -199,6 +199,7 @@ struct MicroBatch {
   int seq0 = 0, seq1 = 0;   // sequences of the micro-batch
   int max_len = 0;          // longest of them
   int tokens = 0;           // their lengths summed
+  int grp0 = 0, grp1 = 0;   // work items of the fused QKV + attention kernel (groups of sequences, qkv_attn.h); empty = not packed
 };
 
 struct ProfRec {
@@ -262,6 +263,7 @@ struct vrag_encoder {
   int *d_ids = nullptr, *d_pos = nullptr, *d_tokseq = nullptr;
   int *d_packed = nullptr, *d_seq_meta = nullptr;   // the batch as handed over: ids back to back; [3][max_seqs] first row / first id / length
   int* h_seq_meta = nullptr;
+  int4 *d_groups = nullptr, *h_groups = nullptr;   // [max_seqs * 8] wave descriptors of the fused kernel's groups
   float* h = nullptr;
   bf16_t *a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr, *act = nullptr;
   float* f32tmp = nullptr;  // [cap_rows, H] final hidden / head dense output
@@ -471,10 +473,12 @@ int check_ready(vrag_encoder* e) {
 // Does this micro-batch take the fused Wqkv + RoPE + attention kernel (qkv_attn.hip)?  One rule for the schedule and for the
 // HIP-graph cache key: a graph captured on one path must never be replayed for a batch that takes the other.
 static bool fused_attention_for(const vrag_encoder* e, const MicroBatch& mb) {
-  if (!e->fused_qkv_attn || mb.max_len > kFusedMaxSeq) return false;
+  if (!e->fused_qkv_attn || mb.max_len > kFusedMaxSeq || mb.grp1 <= mb.grp0) return false;
   if (e->fused_qkv_attn == 2) return true;
   const int M = mb.row1 - mb.row0;
-  return !gemm_consumer_finalizes(M) && (int64_t)mb.tokens >= (int64_t)kFusedMinMeanLen * (mb.seq1 - mb.seq0);
+  // a workgroup costs what a full 512-token one costs: the kernel pays when its groups are FULL enough (tokens per 512-token
+  // workgroup; kFusedMinFill, measured: bench.py ragged_leg with VRAG_FUSED_QKV_ATTN = 0 / 2)
+  return !gemm_consumer_finalizes(M) && (int64_t)mb.tokens * 100 >= (int64_t)kFusedMinFillPct * kFusedMaxSeq * (mb.grp1 - mb.grp0);
 }
 
 int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
@@ -560,9 +564,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         f.rope_sin = global ? e->sin_g : e->sin_l;
         f.rope_rows = c.max_seq_len;
         f.o = e->o;
-        f.seq_row = e->d_seq_meta + mb.seq0;
-        f.seq_len = e->d_seq_meta + 2 * c.max_seqs + mb.seq0;
-        f.n_seqs = mb.seq1 - mb.seq0;
+        f.groups = e->d_groups + (size_t)mb.grp0 * 8;
+        f.n_groups = mb.grp1 - mb.grp0;
         f.H = H;
         f.nh = c.num_heads;
         f.Tp = Tp;
@@ -946,6 +949,7 @@ int init_workspace(vrag_encoder* e) {
   e->d_lblk_q0 = e->d_blk_start + 5 * e->cap_blocks;
   TRY(dev_alloc(e, &e->d_packed, (size_t)cfg->max_tokens));
   TRY(dev_alloc(e, &e->d_seq_meta, (size_t)3 * cfg->max_seqs));
+  TRY(dev_alloc(e, &e->d_groups, (size_t)8 * cfg->max_seqs));
   TRY(dev_alloc(e, &e->d_rng_start, cfg->max_ranges));
   TRY(dev_alloc(e, &e->d_rng_end, cfg->max_ranges));
   TRY(dev_alloc(e, &e->d_rng_out, (size_t)cfg->max_ranges * H));
@@ -957,6 +961,7 @@ int init_workspace(vrag_encoder* e) {
   e->h_lblk_len = e->h_blk_start + 4 * e->cap_blocks;
   e->h_lblk_q0 = e->h_blk_start + 5 * e->cap_blocks;
   TRY(host_alloc(e, &e->h_seq_meta, (size_t)3 * cfg->max_seqs));
+  TRY(host_alloc(e, &e->h_groups, (size_t)8 * cfg->max_seqs));
   TRY(host_alloc(e, &e->h_rng_start, cfg->max_ranges));
   TRY(host_alloc(e, &e->h_rng_end, cfg->max_ranges));
   // pad ids everywhere so never-loaded rows embed a valid token
@@ -1546,6 +1551,16 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   // rows up to max(rows, previous rows) get pad ids so stale tokens of an older batch vanish
   const int fill_to = std::min(e->cap_rows, std::max(rows, prev_rows));
   e->mbs.push_back({mb_row0, rows, mb_blk0, nblk, mb_lblk0, nlblk, mb_seq0, n_seqs, mb_max_len, mb_tokens});
+  // Work items of the fused QKV + attention kernel: per micro-batch that could take it (every sequence <= 512 tokens, rows above
+  // the launch-bound threshold), groups of consecutive sequences packed onto the eight 64-token waves of a workgroup.
+  int n_groups = 0;
+  for (auto& mb : e->mbs) {
+    mb.grp0 = mb.grp1 = n_groups;
+    if (e->arch == 1 || !e->fused_qkv_attn || mb.max_len > kFusedMaxSeq) continue;
+    if (e->fused_qkv_attn != 2 && gemm_consumer_finalizes(mb.row1 - mb.row0)) continue;
+    n_groups += fused_pack_groups(seq_row, seq_ln, mb.seq0, mb.seq1, e->h_groups + (size_t)n_groups * 8);
+    mb.grp1 = n_groups;
+  }
   e->n_seqs = n_seqs;
   e->n_tokens = (int)total;
   e->rows = rows;
@@ -1555,6 +1570,7 @@ int vrag_encoder_load_batch(vrag_encoder* e, const int32_t* ids, const int32_t* 
   e->types_loaded = false;   // segment ids belong to one batch
   HIP_TRY(hipMemcpyAsync(e->d_packed, e->h_ids, (size_t)total * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->d_seq_meta, e->h_seq_meta, (size_t)3 * c.max_seqs * sizeof(int), hipMemcpyHostToDevice, st));
+  if (n_groups > 0) HIP_TRY(hipMemcpyAsync(e->d_groups, e->h_groups, (size_t)n_groups * 8 * sizeof(int4), hipMemcpyHostToDevice, st));
   // one upload for the six descriptor arrays: from the first used entry of the first to the last used entry of the last
   HIP_TRY(hipMemcpyAsync(e->d_blk_start, e->h_blk_start, ((size_t)5 * e->cap_blocks + nlblk) * sizeof(int), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(pack_layout_kernel, dim3((fill_to + 255) / 256), dim3(256), 0, st, e->d_packed, e->d_seq_meta,
@@ -1578,7 +1594,7 @@ static int run_layers_maybe_graphed(vrag_encoder* e, int n_layers, hipStream_t s
   // The key holds everything that selects kernels or launch geometry: row count, attention block counts, sequences, and the
   // attention path (it depends on the longest sequence and the mean length, which the other fields do not determine).
   const std::array<int, 7> key = {e->rows, mb.blk1 - mb.blk0, mb.lblk1 - mb.lblk0, n_layers, e->types_loaded ? 1 : 0, mb.seq1 - mb.seq0,
-                                  e->arch != 1 && fused_attention_for(e, mb) ? 1 : 0};
+                                  e->arch != 1 && fused_attention_for(e, mb) ? 1 + (mb.grp1 - mb.grp0) : 0};   // + the fused kernel's grid
   // Bound the whole map (instantiated or not): query traffic has many geometries, most of them seen once.  The least recently
   // used entry goes first, whatever it holds.
   while (e->graphs.size() >= kGraphCacheMax && e->graphs.find(key) == e->graphs.end()) {
@@ -2128,7 +2144,7 @@ int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, 
   if (e == hipSuccess) e = hipMalloc((void**)&rstd, Tp * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&lns, ((size_t)3 * H + 64) * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&cs, (size_t)kFusedMaxSeq * 32 * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_row, n_seqs * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_row, (size_t)n_seqs * 8 * sizeof(int4));   // the groups' wave descriptors
   if (e == hipSuccess) e = hipMalloc((void**)&d_len, n_seqs * 4);
   if (e != hipSuccess) {
     cleanup();
@@ -2150,9 +2166,10 @@ int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, 
     (void)hipMemcpy(lns, f.data(), (size_t)3 * H * 4, hipMemcpyHostToDevice);
     std::fill(f.begin(), f.end(), 0.7071f);
     (void)hipMemcpy(cs, f.data(), (size_t)kFusedMaxSeq * 32 * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_row, row.data(), n_seqs * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_len, len.data(), n_seqs * 4, hipMemcpyHostToDevice);
   }
+  std::vector<int4> groups((size_t)n_seqs * 8);
+  const int n_groups = fused_pack_groups(row.data(), len.data(), 0, n_seqs, groups.data());
+  (void)hipMemcpy(d_row, groups.data(), (size_t)n_groups * 8 * sizeof(int4), hipMemcpyHostToDevice);
   QkvAttnParams f{};
   f.x = (const bf16_t*)x;
   f.w = (const bf16_t*)w;
@@ -2163,9 +2180,8 @@ int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, 
   f.rope_sin = cs;
   f.rope_rows = kFusedMaxSeq;
   f.o = (bf16_t*)o;
-  f.seq_row = d_row;
-  f.seq_len = d_len;
-  f.n_seqs = n_seqs;
+  f.groups = reinterpret_cast<const int4*>(d_row);
+  f.n_groups = n_groups;
   f.H = H;
   f.nh = nh;
   f.Tp = (int)Tp;

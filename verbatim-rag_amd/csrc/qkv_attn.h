@@ -5,7 +5,7 @@
 namespace vrag {
 
 constexpr int kFusedMaxSeq = 512;   // tokens one workgroup holds: 8 waves x 64 rows
-constexpr int kFusedMinMeanLen = 288;   // mean sequence length of a micro-batch from which the kernel beats the two-kernel path (profiles/r03_fused_by_sequence_length.txt)
+constexpr int kFusedMinFillPct = 72;   // tokens per 512-token workgroup (%) from which the kernel beats the two-kernel path: a workgroup costs what a full one costs
 
 struct QkvAttnParams {
   const bf16_t* x;         // [Tp, H] the Wqkv GEMM's A operand rows (op16(h - c) under the LayerNorm fold, else LN(h))
@@ -17,9 +17,11 @@ struct QkvAttnParams {
   const float* rope_sin;
   int rope_rows;           // positions the rotary tables hold (>= the longest sequence)
   bf16_t* o;               // [Tp, H] attention output (the Wo GEMM's A operand)
-  const int* seq_row;      // [n_seqs] first packed row of every sequence
-  const int* seq_len;      // [n_seqs] tokens (<= kFusedMaxSeq)
-  int n_seqs;
+  // Work items: GROUPS of consecutive sequences, each sequence on ceil(S / 64) consecutive waves of the group's workgroup
+  // (fused_pack_groups below).  Per wave: x = packed row of the wave's first token, y = its sequence's length (0 = unused wave),
+  // z = the first wave of its sequence, w unused.
+  const int4* groups;      // [n_groups][8]
+  int n_groups;
   int H, nh, Tp;
   int window;              // banded layers: keep |i - j| <= window
   int op_dtype;
@@ -28,6 +30,11 @@ struct QkvAttnParams {
 };
 
 hipError_t launch_qkv_attention(const QkvAttnParams& p, bool local, hipStream_t stream);
+
+// Host: packs sequences seq0 .. seq1 - 1 (first rows `seq_row`, lengths `seq_len` <= kFusedMaxSeq) into groups, first fit over
+// CONSECUTIVE sequences (a group's rows are then one contiguous stretch of the packed buffer: one XCD's L2 serves its heads).
+// Writes 8 descriptors per group to `out` (room for 8 * (seq1 - seq0) of them) and returns the number of groups.
+int fused_pack_groups(const int* seq_row, const int* seq_len, int seq0, int seq1, int4* out);
 
 // out[(h * 3 + part) * 64 + d][:] = w[part * H + h * 64 + d][:]  (and the same for the optional row-sum / bias vectors)
 hipError_t permute_qkv_heads(const bf16_t* w, const float* s, int H, int nh, bf16_t* w_out, float* s_out, hipStream_t stream);

@@ -22,8 +22,12 @@
 //      DMA, no barriers, waves run free; softmax in exp2 units with a lazily moved reference that rides into the S^T MFMAs
 //      as their C operand, row sums from an all-ones MFMA (the arithmetic of attn2_fwd_kernel, attention.hip).
 //   4. O rows are staged through LDS and stored as whole 128-byte head rows.
-// Sequences longer than 512 tokens, BERT-family encoders, launch-bound batches and batches of short sequences (mean length
-// below kFusedMinMeanLen: a 512-token workgroup per sequence wastes its idle waves) keep the two-kernel path.
+// Round 4, wave-slot packing: a workgroup holds a GROUP of consecutive sequences, each on ceil(S / 64) consecutive waves (per-wave
+// descriptors: first row, sequence length, first wave of the sequence); K / V^T rows stay indexed by workgroup slot, positions,
+// masks and the key-tile walk are relative to the sequence.  A workgroup costs what a full one costs, so the schedule takes the
+// kernel when the groups are full enough (kFusedMinFillPct of 512 tokens per workgroup; GpuModelSpanExtractor orders a sub-batch's
+// pairs so that they are: packing.wave_slot_order).
+// Sequences longer than 512 tokens, BERT-family encoders, launch-bound batches and poorly filled batches keep the two-kernel path.
 #include "qkv_attn.h"
 
 #include <cstdlib>
@@ -60,11 +64,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   // workgroup b runs on XCD b % 8: the heads of one sequence are dealt to ONE XCD back to back, so its token rows are
   // fetched from HBM once and re-read from that XCD's L2 by the other heads
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int seq = (slot / nh) * 8 + xcd, head = slot % nh;
-  if (seq >= p.n_seqs) return;
-  const int t0 = p.seq_row[seq], S = p.seq_len[seq];
-  const int qrow0 = wave * 64;           // first token of this wave inside the sequence
-  const bool active = qrow0 < S;         // wave-uniform: a wave past the end of a short sequence only helps with the weight DMA
+  const int grp = (slot / nh) * 8 + xcd, head = slot % nh;
+  if (grp >= p.n_groups) return;
+  // Wave-slot packing (round 4): the workgroup holds a GROUP of consecutive sequences, each on ceil(S / 64) consecutive waves.
+  // Per wave: the packed row of its first token, its sequence's length and the first wave (= 64-key LDS slot) of its sequence.
+  // K / V^T rows stay indexed by workgroup slot (wave * 64 + row); positions, masks and the key-tile walk are relative to the
+  // sequence.  A 512-token sequence is the group of one: row0 = first row + 64 w, kbase = 0.
+  const int4 wd = p.groups[grp * 8 + wave];
+  const int wrow0 = uniform(wd.x), S = uniform(wd.y), kbase = uniform(wd.z);
+  const int srow0 = wave * 64;                 // first K / V^T row (LDS slot position) of this wave
+  const int qrow0 = (wave - kbase) * 64;       // first token of this wave inside its sequence
+  const bool active = qrow0 < S;               // wave-uniform (S = 0: an unused wave): such a wave only helps with the weight DMA
   const T* X = reinterpret_cast<const T*>(p.x);
   const T* Wh = reinterpret_cast<const T*>(p.w) + (size_t)head * 192 * H;
 
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     const int row = wave * 24 + i * 8 + (lane >> 3);
     voffW[i] = (unsigned)(row * H + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u;
   }
-  const char* const Xw = reinterpret_cast<const char*>(X + (size_t)(t0 + qrow0) * H);   // this wave's first token row (uniform)
+  const char* const Xw = reinterpret_cast<const char*>(X + (size_t)wrow0 * H);   // this wave's first token row (uniform)
   const char* const Wb = reinterpret_cast<const char*>(Wh);
   char* const xbuf = smem + QA_XOFF + wave * 8192;
   // one DMA instruction of the next stage: weight rows (i < 3, 8 rows each) or this wave's token rows (i < 8)
@@ -110,10 +120,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   // loop and attention.  Rotary rows by angle addition: pos = 16 b + i, cos(pos f) = cos(16 b f) cos(i f) - sin(16 b f) sin(i f):
   // table rows 16 b (b < 32) and rows 0 .. 15 are all a 512-token sequence needs (12 KiB instead of 128).
   if (!(p.debug_flags & 4)) {
-    if (FOLD && wave < 2) {
-      const float* src = wave == 0 ? p.ln_mu : p.ln_rstd;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) glds16(src + min(t0 + i * 256 + lane * 4, Tp - 4), smem + (wave == 0 ? QA_MU : QA_RS) + i * 1024);
+    if (FOLD && lane < 16) {   // every wave brings the statistics of ITS 64 rows (16 lanes x 4 floats each)
+      glds16(p.ln_mu + min(wrow0 + lane * 4, Tp - 4), smem + QA_MU + srow0 * 4);
+      glds16(p.ln_rstd + min(wrow0 + lane * 4, Tp - 4), smem + QA_RS + srow0 * 4);
     }
     if (FOLD && wave == 2) glds16(p.ln_s + head * 192 + lane * 4, smem + QA_LS);
     if (wave == 2 || wave == 3) {   // rows 0 .. 15 (8 rows of 128 bytes per instruction)
@@ -198,8 +207,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   if (p.debug_flags & 16) return;
 
   // ---------------------------------------------------------------- 2. epilogue: fold, RoPE, K / V^T -> LDS, Q -> registers
-  const float* l_mu = reinterpret_cast<const float*>(smem + QA_MU) + qrow0;
-  const float* l_rs = reinterpret_cast<const float*>(smem + QA_RS) + qrow0;
+  const float* l_mu = reinterpret_cast<const float*>(smem + QA_MU) + srow0;
+  const float* l_rs = reinterpret_cast<const float*>(smem + QA_RS) + srow0;
   const float* l_ls = reinterpret_cast<const float*>(smem + QA_LS);
   // ---- V^T third (un-swapped accumulators: lane = feature d, registers = tokens)
 #pragma unroll
@@ -237,8 +246,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 #pragma unroll
     for (int np = 0; np < 2; ++np) {
       const int dd = np * 16 + 4 * g;
-      const f32x4 ca = *reinterpret_cast<const f32x4*>(smem + QA_CA + ((4 * wave + rt) * 32 + dd) * 4);
-      const f32x4 sa = *reinterpret_cast<const f32x4*>(smem + QA_SA + ((4 * wave + rt) * 32 + dd) * 4);
+      const f32x4 ca = *reinterpret_cast<const f32x4*>(smem + QA_CA + (((qrow0 >> 4) + rt) * 32 + dd) * 4);
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(smem + QA_SA + (((qrow0 >> 4) + rt) * 32 + dd) * 4);
       const int bsw = l15 * 128 + ((((dd >> 2) ^ ((l15 >> 1) & 7))) << 4);
       const f32x4 cb = *reinterpret_cast<const f32x4*>(smem + QA_CB + bsw);
       const f32x4 sb = *reinterpret_cast<const f32x4*>(smem + QA_SB + bsw);
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   for (int rt = 0; rt < 4; ++rt) {
     V8 kf[2];
     rope_rows(4, rt, 64, 1.0f, kf);
-    const int row = qrow0 + rt * 16 + l15;
+    const int row = srow0 + rt * 16 + l15;   // LDS slot position
 #pragma unroll
     for (int s = 0; s < 2; ++s) *reinterpret_cast<V8*>(smem + row * 128 + (((4 * s + g) ^ ((row >> 1) & 7)) << 4)) = kf[s];
   }
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          const char* krow = smem + (kt * 64 + kb * 16 + l15) * 128;
+          const char* krow = smem + ((kbase + kt) * 64 + kb * 16 + l15) * 128;   // key tile kt of THIS sequence = LDS slot kbase + kt
           const V8 k0 = *reinterpret_cast<const V8*>(krow + ((g ^ ksw) << 4));
           const V8 k1 = *reinterpret_cast<const V8*>(krow + (((4 + g) ^ ksw) << 4));
 #pragma unroll
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         for (int c = 0; c < 4; ++c) lo[c] = Op<T>::mfma16(ones, pf[c][t2], lo[c]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const V8 vf = *reinterpret_cast<const V8*>(smem + QA_V_OFF + (dt * 16 + l15) * 1024 + (((kt * 8 + t2 * 4 + g) ^ l15) << 4));
+          const V8 vf = *reinterpret_cast<const V8*>(smem + QA_V_OFF + (dt * 16 + l15) * 1024 + ((((kbase + kt) * 8 + t2 * 4 + g) ^ l15) << 4));
 #pragma unroll
           for (int c = 0; c < 4; ++c) ot[c][dt] = Op<T>::mfma16(vf, pf[c][t2], ot[c][dt]);
         }
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), c16 = lane & 7;
       const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((c16 ^ (row & 7)) << 4));
-      if (qrow0 + row < S && !(p.debug_flags & 8)) store16_nt(reinterpret_cast<T*>(p.o) + (size_t)(t0 + qrow0 + row) * H + head * 64 + c16 * 8, v);
+      if (qrow0 + row < S && !(p.debug_flags & 8)) store16_nt(reinterpret_cast<T*>(p.o) + (size_t)(wrow0 + row) * H + head * 64 + c16 * 8, v);
     }
   }
 }
@@ -480,13 +489,13 @@ static hipError_t launch_t(const QkvAttnParams& p, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr = true;
   }
-  const int grid = ((p.n_seqs + 7) / 8) * 8 * p.nh;
+  const int grid = ((p.n_groups + 7) / 8) * 8 * p.nh;
   hipLaunchKernelGGL((qkv_attn_kernel<LOCAL, FOLD, T>), dim3(grid), dim3(512), QA_SMEM, stream, p);
   return hipGetLastError();
 }
 
 hipError_t launch_qkv_attention(const QkvAttnParams& p, bool local, hipStream_t stream) {
-  if (p.n_seqs <= 0) return hipSuccess;
+  if (p.n_groups <= 0) return hipSuccess;
   if (p.H % 64 != 0 || p.H != p.nh * 64 || (size_t)p.Tp * p.H >= (size_t)1 << 31) return hipErrorInvalidValue;
   const bool fold = p.ln_mu != nullptr;
   if (p.op_dtype == kOpF16) {
@@ -509,6 +518,21 @@ __global__ void permute_qkv_heads_kernel(const bf16_t* __restrict__ w, const flo
 hipError_t permute_qkv_heads(const bf16_t* w, const float* s, int H, int nh, bf16_t* w_out, float* s_out, hipStream_t stream) {
   hipLaunchKernelGGL(permute_qkv_heads_kernel, dim3(3 * H), dim3(256), 0, stream, w, s, H, nh, w_out, s_out);
   return hipGetLastError();
+}
+
+int fused_pack_groups(const int* seq_row, const int* seq_len, int seq0, int seq1, int4* out) {
+  int n = 0, used = 8;   // waves taken in the current group (8 = none open)
+  for (int s = seq0; s < seq1; ++s) {
+    const int need = (seq_len[s] + 63) / 64;
+    if (used + need > 8) {   // open a new group
+      for (int w = 0; w < 8; ++w) out[n * 8 + w] = int4{0, 0, 0, 0};
+      ++n;
+      used = 0;
+    }
+    for (int j = 0; j < need; ++j) out[(n - 1) * 8 + used + j] = int4{seq_row[s] + 64 * j, seq_len[s], used, 0};
+    used += need;
+  }
+  return n;
 }
 
 unsigned qkv_attn_f16_saturated(bool reset) { return f16_sat_take(reset); }

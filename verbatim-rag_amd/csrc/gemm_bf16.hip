@@ -637,26 +637,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // NS = LDS stages.  2: the throughput configuration (one stage in flight, plain barriers).  4: the
 // small-batch configuration -- with a handful of tiles the K loop is a chain of memory round trips, and three
 // stages in flight (counted vmcnt, raw barriers) cut that chain to a third.
-template <int EPI, int BM, int BN, int WM, int WN, int NS = 2, typename T = bf16_t>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
+// HW = K-split waves (round 4, launch-bound residual GEMMs; WM = WN = 1): waves beyond the first that compute the SAME 64 x 64
+// tile over OTHER K-steps.  At this size a launch is a chain of latencies, and the chain is the single wave's own K-step (fragment
+// reads -> MFMAs, ~0.55 us, whatever the ring depth: profiles/r04_small_gemm_probes.txt): with HW = 3 the ring is eight stages
+// deep, a super-step holds four landed K-steps, wave w computes K-step 4 j + w of super-step j, and the four partial tiles meet
+// in LDS in a fixed order (wave 0 adds waves 1, 2, 3) before wave 0 runs the epilogue.  Every wave takes a quarter of the DMA.
+template <int EPI, int BM, int BN, int WM, int WN, int NS = 2, typename T = bf16_t, int HW = 0>
+__global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
-  static_assert(NS >= 2 && NS <= 4, "LDS stages");
+  static_assert(NS >= 2 && NS <= 8, "LDS stages");
+  constexpr int NWAVE = WM * WN + HW;       // waves that share the operand DMA
   constexpr int ROWB = BK * 2;                // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;            // tile rows filled by one LDS-DMA instruction (64 lanes x 16 bytes)
   constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
   constexpr int KS = BK / 32;                 // MFMA k-substeps per stage
   constexpr int RT = BM / WM / 16;            // 16-row accumulator tiles per wave
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int A_INSTR = BM / RPI / (WM * WN); // LDS-DMA instructions per wave per stage
-  constexpr int W_INSTR = BN / RPI / (WM * WN);
-  static_assert(A_INSTR * RPI * WM * WN == BM && W_INSTR * RPI * WM * WN == BN, "tile rows must split over the waves");
+  constexpr int A_INSTR = BM / RPI / NWAVE; // LDS-DMA instructions per wave per stage
+  constexpr int W_INSTR = BN / RPI / NWAVE;
+  static_assert(A_INSTR * RPI * NWAVE == BM && W_INSTR * RPI * NWAVE == BN, "tile rows must split over the waves");
+  static_assert((NS - 1) * (A_INSTR + W_INSTR) <= 63, "a wave's vmcnt counts at most 63 DMA instructions in flight");
   static_assert(NS * STAGE_BYTES >= WM * WN * 16384 || EPI == EPI_NONE, "the epilogues stage 16 KiB per wave through the operand ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  static_assert(HW == 0 || (WM == 1 && WN == 1 && NS == 2 * (HW + 1)), "K-split waves: one tile, a ring of two super-steps");
+  const int wm = HW > 0 ? 0 : wave / WN, wn = HW > 0 ? 0 : wave % WN;
   const int q = lane >> 4, l15 = lane & 15;
   constexpr int WROWS = BM / WM;              // rows of the A tile owned by one wave
 
@@ -725,7 +733,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
     constexpr bool SWAPPED = decltype(swapped_tag)::value;
     constexpr int NDMA = A_INSTR + W_INSTR;   // LDS-DMA instructions per wave per stage
     auto wait_allow = [&](int stages_in_flight) {   // this wave's DMA is retired except the newest `stages_in_flight` stages
-      if (NS > 2 && stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+      if constexpr (NS > 4) {
+        switch (stages_in_flight) {
+          case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NDMA) : "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NDMA) : "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMA) : "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory"); break;
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      } else if (NS > 2 && stages_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
       else if (NS > 2 && stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -737,16 +755,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
         asm volatile("" ::: "memory");
       }
     };
-#pragma unroll
-    for (int i = 0; i < NS - 1; ++i)
-      if (i < KT) stage(i, i);
-    wait_allow(min(NS - 1, KT) - 1);
-    step_barrier();
-    int buf = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-      const int nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;   // the slot read in step kt-1: every wave passed the barrier since
-      const bool do_stage = nxt < KT;
-      if (do_stage) stage(nxt, nbuf);   // right after the barrier (issuing half of the waves' share a substep later: no difference, r2s)
+    // one K-step's MFMAs on LDS slot `buf`
+    auto compute = [&](int buf) {
       const char* sA = smem + buf * STAGE_BYTES + (wm * WROWS) * ROWB;
       const char* sW = smem + buf * STAGE_BYTES + A_BYTES + (wn * 64) * ROWB;
       // MFMA order: the KS k-substeps of one accumulator tile back to back (a dependent pair), row tile by row tile -- measured
@@ -757,16 +767,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          wf[s][i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
-        }
+        for (int i = 0; i < 4; ++i) wf[s][i] = *reinterpret_cast<const V8*>(sW + i * 16 * ROWB + fo[s]);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         V8 af[KS] = {};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          af[s] = *reinterpret_cast<const V8*>(sA + rt * 16 * ROWB + fo[s]);
-        }
+        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const V8*>(sA + rt * 16 * ROWB + fo[s]);
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
@@ -777,6 +783,59 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
               acc[nj][rt] = Op<T>::mfma16(af[s], wf[s][nj], acc[nj][rt]);
           }
       }
+    };
+    if constexpr (HW > 0) {
+      // K-split: super-step j = K-steps G j .. G j + G - 1, all landed before its barrier; wave w computes K-step G j + w.
+      constexpr int G = HW + 1;
+      int issued = min(NS - 1, KT);
+#pragma unroll
+      for (int i = 0; i < NS - 1; ++i)
+        if (i < KT) stage(i, i);
+      for (int first = 0; first < KT; first += G) {
+        const int last = min(KT, first + G) - 1;
+        wait_allow(issued - 1 - last);   // this wave's share of K-steps first .. last has landed; later ones stay in flight
+        step_barrier();                  // ... and every other wave's
+        if (first + wave <= last) compute((first + wave) % NS);
+        step_barrier();                  // all reads of this super-step's slots are done: they are refilled now
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+          if (issued < KT) {
+            stage(issued, issued % NS);
+            ++issued;
+          }
+      }
+      // the partial tiles meet in LDS (the ring is free): waves 1 .. HW store theirs lane-linear, wave 0 adds them in wave order
+      if (wave > 0) {
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            *reinterpret_cast<f32x4*>(smem + (wave - 1) * (RT * 4096) + ((nj * RT + rt) * 64 + lane) * 16) = acc[nj][rt];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < HW; ++w)
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[nj][rt] += *reinterpret_cast<const f32x4*>(smem + w * (RT * 4096) + ((nj * RT + rt) * 64 + lane) * 16);
+      }
+      __syncthreads();   // wave 0's epilogue stages through the same bytes
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+      if (i < KT) stage(i, i);
+    wait_allow(min(NS - 1, KT) - 1);
+    step_barrier();
+    int buf = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      const int nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;   // the slot read in step kt-1: every wave passed the barrier since
+      const bool do_stage = nxt < KT;
+      if (do_stage) stage(nxt, nbuf);   // right after the barrier (issuing half of the waves' share a substep later: no difference, r2s)
+      compute(buf);
       wait_allow(max(0, min(NS - 2, KT - 2 - kt)));   // step kt+1 has landed (this wave's share)
       step_barrier();
       buf = buf + 1 == NS ? 0 : buf + 1;
@@ -785,7 +844,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(const GemmPa
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  gemm_epilogue<EPI, RT, WROWS, T, (NS == 4 && BM == 128 && BN == 128)>(p, acc, smem, wave, lane, mw, nw, v_block);
+  if (HW == 0 || wave == 0) gemm_epilogue<EPI, RT, WROWS, T, (NS == 4 && BM == 128 && BN == 128)>(p, acc, smem, wave, lane, mw, nw, v_block);
   __syncthreads();  // staging area is reused as operand slots by the next tile
   }  // tile loop
 }
@@ -797,19 +856,19 @@ int gemm_small_m_threshold(int set_to) {
 }
 
 // One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
-template <int EPI, int BM, int BN, int WM, int WN, int NS, typename T>
+template <int EPI, int BM, int BN, int WM, int WN, int NS, typename T, int HW = 0>
 static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
   constexpr int SMEM = NS * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T, HW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   p.n_tiles = nbm * nbn;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T>), dim3(std::min(nbm * nbn, grid_cap)), dim3(WM * WN * 64), SMEM,
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T, HW>), dim3(std::min(nbm * nbn, grid_cap)), dim3((WM * WN + HW) * 64), SMEM,
                      stream, p);
   return hipGetLastError();
 }
@@ -824,7 +883,12 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
       // brings in (32 KiB per step: 1.2 us measured, profiles/r03_latency_kernel_stats.txt), not by its 0.25 us of MFMAs:
       // 64 x 64 tiles (one wave each, 16 KiB per step) spread the same bytes over four times the CUs
       // (extract_spans(question, 5 chunks) 1.83 -> 1.74 ms, profiles/r03_small_residual_tiles_ab.txt).
-      if ((int64_t)((p.M + 127) / 128) * (p.N / 128) <= 128) return launch_cfg<EPI, 64, 64, 1, 1, 4, T>(p, 1024, stream);
+      if ((int64_t)((p.M + 127) / 128) * (p.N / 128) <= 128) {
+        // at most one 64 x 64 tile per CU: four waves split K over an eight-stage ring (see the kernel): 12.4 -> 9.8 us at K = 768,
+        // 15.6 -> 11.5 us at K = 1152, extract_spans(question, 5 chunks) 1.68 -> 1.59 ms (profiles/r04_small_gemm_probes.txt)
+        if ((int64_t)((p.M + 63) / 64) * (p.N / 64) <= 256) return launch_cfg<EPI, 64, 64, 1, 1, 8, T, 3>(p, 1024, stream);
+        return launch_cfg<EPI, 64, 64, 1, 1, 4, T>(p, 1024, stream);
+      }
     }
     return launch_cfg<EPI, 128, 128, 2, 2, 4, T>(p, 256, stream);
   }

@@ -637,11 +637,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // NS = LDS stages.  2: the throughput configuration (one stage in flight, plain barriers).  4: the
 // small-batch configuration -- with a handful of tiles the K loop is a chain of memory round trips, and three
 // stages in flight (counted vmcnt, raw barriers) cut that chain to a third.
-// HW = K-split waves (round 4, launch-bound residual GEMMs; WM = WN = 1): waves beyond the first that compute the SAME 64 x 64
-// tile over OTHER K-steps.  At this size a launch is a chain of latencies, and the chain is the single wave's own K-step (fragment
-// reads -> MFMAs, ~0.55 us, whatever the ring depth: profiles/r04_small_gemm_probes.txt): with HW = 3 the ring is eight stages
-// deep, a super-step holds four landed K-steps, wave w computes K-step 4 j + w of super-step j, and the four partial tiles meet
-// in LDS in a fixed order (wave 0 adds waves 1, 2, 3) before wave 0 runs the epilogue.  Every wave takes a quarter of the DMA.
+// HW = K-split waves (round 4, the launch-bound configurations): HW / (WM x WN) further GROUPS of WM x WN waves that compute the
+// SAME tile over OTHER K-steps.  At this size a launch is a chain of latencies, and the chain is a wave's own K-step (fragment
+// reads -> MFMAs, ~0.55 us, whatever the ring depth: profiles/r04_small_gemm_probes.txt).  With KG groups the ring holds 2 KG
+// stages, a super-step holds KG landed K-steps, group g computes K-step KG j + g of super-step j, and the groups' partial tiles
+// meet in LDS in group order (group 0 adds groups 1, 2, ...) before group 0 runs the epilogue.  Every wave takes its share of the
+// DMA.  64 x 64 tiles: four single-wave groups on an eight-stage ring; 128 x 128 tiles: two groups of 2 x 2 waves on four stages.
 template <int EPI, int BM, int BN, int WM, int WN, int NS = 2, typename T = bf16_t, int HW = 0>
 __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
@@ -663,8 +664,10 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
-  static_assert(HW == 0 || (WM == 1 && WN == 1 && NS == 2 * (HW + 1)), "K-split waves: one tile, a ring of two super-steps");
-  const int wm = HW > 0 ? 0 : wave / WN, wn = HW > 0 ? 0 : wave % WN;
+  constexpr int KG = 1 + HW / (WM * WN);     // K-groups
+  static_assert(HW % (WM * WN) == 0 && (HW == 0 || NS == 2 * KG), "K-split: whole groups of waves, a ring of two super-steps");
+  const int kg = wave / (WM * WN), wl = wave % (WM * WN);   // K-group of this wave, its place in the group
+  const int wm = wl / WN, wn = wl % WN;
   const int q = lane >> 4, l15 = lane & 15;
   constexpr int WROWS = BM / WM;              // rows of the A tile owned by one wave
 
@@ -786,7 +789,7 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
     };
     if constexpr (HW > 0) {
       // K-split: super-step j = K-steps G j .. G j + G - 1, all landed before its barrier; wave w computes K-step G j + w.
-      constexpr int G = HW + 1;
+      constexpr int G = KG;
       int issued = min(NS - 1, KT);
 #pragma unroll
       for (int i = 0; i < NS - 1; ++i)
@@ -795,7 +798,7 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
         const int last = min(KT, first + G) - 1;
         wait_allow(issued - 1 - last);   // this wave's share of K-steps first .. last has landed; later ones stay in flight
         step_barrier();                  // ... and every other wave's
-        if (first + wave <= last) compute((first + wave) % NS);
+        if (first + kg <= last) compute((first + kg) % NS);
         step_barrier();                  // all reads of this super-step's slots are done: they are refilled now
 #pragma unroll
         for (int i = 0; i < G; ++i)
@@ -804,25 +807,27 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
             ++issued;
           }
       }
-      // the partial tiles meet in LDS (the ring is free): waves 1 .. HW store theirs lane-linear, wave 0 adds them in wave order
-      if (wave > 0) {
+      // the partial tiles meet in LDS (the ring is free): the waves of groups 1 .. store theirs lane-linear, the wave of group 0 in
+      // the same place of the tile adds them in group order
+      constexpr int PART = RT * 4096;   // bytes of one wave's accumulators
+      if (kg > 0) {
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            *reinterpret_cast<f32x4*>(smem + (wave - 1) * (RT * 4096) + ((nj * RT + rt) * 64 + lane) * 16) = acc[nj][rt];
+            *reinterpret_cast<f32x4*>(smem + ((kg - 1) * (WM * WN) + wl) * PART + ((nj * RT + rt) * 64 + lane) * 16) = acc[nj][rt];
       }
       __syncthreads();
-      if (wave == 0) {
+      if (kg == 0) {
 #pragma unroll
-        for (int w = 0; w < HW; ++w)
+        for (int g = 0; g < KG - 1; ++g)
 #pragma unroll
           for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
-              acc[nj][rt] += *reinterpret_cast<const f32x4*>(smem + w * (RT * 4096) + ((nj * RT + rt) * 64 + lane) * 16);
+              acc[nj][rt] += *reinterpret_cast<const f32x4*>(smem + (g * (WM * WN) + wl) * PART + ((nj * RT + rt) * 64 + lane) * 16);
       }
-      __syncthreads();   // wave 0's epilogue stages through the same bytes
+      __syncthreads();   // group 0's epilogue stages through the same bytes
       return;
     }
 #pragma unroll
@@ -844,7 +849,8 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  if (HW == 0 || wave == 0) gemm_epilogue<EPI, RT, WROWS, T, (NS == 4 && BM == 128 && BN == 128)>(p, acc, smem, wave, lane, mw, nw, v_block);
+  if (kg == 0) gemm_epilogue<EPI, RT, WROWS, T, (BM == 128 && BN == 128 && (NS == 4 || HW > 0))>(p, acc, smem, wave, lane, mw, nw, v_block);
+  else if constexpr (EPI == EPI_GEGLU) __syncthreads();   // the GeGLU epilogue's pair-staging barrier is a workgroup barrier
   __syncthreads();  // staging area is reused as operand slots by the next tile
   }  // tile loop
 }
@@ -890,6 +896,9 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
         return launch_cfg<EPI, 64, 64, 1, 1, 4, T>(p, 1024, stream);
       }
     }
+    // (two K-groups of 2 x 2 waves for these 128 x 128 tiles measured SLOWER: extract_spans(question, 5 chunks) 1.71 vs 1.56 ms,
+    //  profiles/r04_small_gemm_probes.txt -- eight waves per CU, a 64 KiB reduction and twice the barriers cost more than the
+    //  halved K-step chain returns; the template keeps the general form)
     return launch_cfg<EPI, 128, 128, 2, 2, 4, T>(p, 256, stream);
   }
   if (p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0))

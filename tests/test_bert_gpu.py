@@ -103,11 +103,14 @@ def test_base_width_hidden_pool_and_splade_vs_oracle(base_width):
         sr = O.splade_pool(B.mlm_logits(cfg, W, ref))
         assert np.abs(rows[i] - sr).max() < 4e-2
         o += len(s)
-    # micro-batching (2048-token micro-batches on two streams) must not change a sequence's rows
+    # micro-batching (2048-token micro-batches on two streams) must not change a sequence's rows beyond rounding: the lone 512-token
+    # sequence takes the launch-bound residual GEMMs with K split over four waves (round 4), the batch's micro-batches the one-wave
+    # form -- another fp32 summation order, which 16-bit operand rounding carries to ~2e-3 after twelve layers (the oracle bound above
+    # is 4e-2).  Bit-identity holds between launches of the same configuration (test_extractor_gpu.py, the graph test).
     eng.load_batch([seqs[0]])
     eng.run()
     alone = eng.read_hidden(final_norm=False)
-    assert np.array_equal(alone, got[:512])
+    assert np.array_equal(alone, got[:512]) or float(np.abs(alone - got[:512]).max()) < 1e-2
 
 
 def test_providers_on_bert_engine(base_width):
@@ -199,7 +202,7 @@ def test_cross_encoder_pairs_vs_transformers_golden():
             assert np.abs(logits[i] - z[f"logits{i}"]).max() < 5e-3, (logits[i], z[f"logits{i}"])
             o += len(s)
         alone = eng.pair_logits([seqs[1]], [types[1]])
-        assert np.array_equal(alone[0], logits[1])
+        assert np.array_equal(alone[0], logits[1]) or float(np.abs(alone[0] - logits[1]).max()) < 1e-3   # same configuration -> same bits; else rounding
         # without segment ids every token gets type 0: a different (and wrong for pairs) result, not a crash
         eng.load_batch([seqs[1]])
         eng.run()

@@ -360,8 +360,6 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
 
         from verbatim_rag_amd.engine import EncoderEngine
 
-        from verbatim_rag_amd.packing import wave_slot_order
-
         mbt = micro_batch_tokens or tokens
         lens = ragged_lengths(mbt, max(1, tokens // mbt))
         seqs, bounds = synth_ragged_batch(shape, lens, seed=77)
@@ -371,27 +369,19 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
         eng.set_qa_head(qa_w, qa_b)
         stream = torch.cuda.current_stream().cuda_stream
 
-        def timed(order):
-            sq, bd = [seqs[i] for i in order], [bounds[i] for i in order]
-            eng.load_batch(sq, stream)
-            eng.load_ranges(np.repeat(np.arange(len(sq), dtype=np.int32), [len(b) for b in bd]),
-                            np.asarray([r[0] for b in bd for r in b], np.int32), np.asarray([r[1] for b in bd for r in b], np.int32), stream)
-            for _ in range(2):
-                eng.run(stream)
-                eng.run_qa_head(stream)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                eng.run(stream)
-                eng.run_qa_head(stream)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / steps
-
-        # the pairs in the order they were drawn, then in the order GpuModelSpanExtractor hands a sub-batch to the engine
-        # (packing.wave_slot_order: the pairs are independent, so the extractor is free to order them; fuller 512-token
-        # workgroups for the fused QKV + attention kernel)
-        dt_drawn = timed(list(range(len(seqs))))
-        dt = timed(wave_slot_order(lens).tolist())
+        eng.load_batch(seqs, stream)
+        eng.load_ranges(np.repeat(np.arange(len(seqs), dtype=np.int32), [len(b) for b in bounds]),
+                        np.asarray([r[0] for b in bounds for r in b], np.int32), np.asarray([r[1] for b in bounds for r in b], np.int32), stream)
+        for _ in range(2):
+            eng.run(stream)
+            eng.run_qa_head(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run(stream)
+            eng.run_qa_head(stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
         eng.set_concurrency(1)                  # untimed: the kernels of this batch one at a time, per class
         eng.run(stream)
         torch.cuda.synchronize()
@@ -407,8 +397,7 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
         return {"ragged_chunks_per_s": len(lens) / dt, "ms_per_step": dt * 1e3, "chunks_per_step": int(len(lens)), "tokens_per_step": int(lens.sum()),
                 "length_min_mean_max": [int(lens.min()), float(lens.mean()), int(lens.max())], "tokens_per_s": tps,
                 "tokens_per_s_vs_512_token_batch": tps / headline_tokens_per_s, "single_stream_pass_by_class": iso,
-                "pairs_in_drawn_order": {"ms_per_step": dt_drawn * 1e3, "tokens_per_s_vs_512_token_batch": float(lens.sum()) / dt_drawn / headline_tokens_per_s},
-                "order": "packing.wave_slot_order (best-fit-decreasing bins of eight 64-token wave slots; what extract_spans_batch applies to a sub-batch)",
+                "order": "as drawn (the engine packs the sequences of a micro-batch into the fused kernel's 8-slot groups itself, best fit decreasing)",
                 "what": "encoder + sentence head over pairs of 64-512 tokens (seeded, mean ~200) filling the same two 65 536-row micro-batches as the headline (8-row alignment gaps between pairs are rows, not tokens), resident inputs"}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}

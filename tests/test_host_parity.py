@@ -250,29 +250,3 @@ def test_filter_expression_subset():
         with pytest.raises(ValueError):
             parse_filter(bad)
 
-
-def test_wave_slot_order_is_a_permutation_that_fills_the_groups():
-    """packing.wave_slot_order: a permutation; consecutive first-fit over the ordered lengths (what the fused kernel's group packer
-    does, csrc/qkv_attn.hip fused_pack_groups) needs no more 8-slot groups than a best-fit-decreasing packing, and far fewer than
-    the same packer over the lengths as they come."""
-    import numpy as np
-
-    from verbatim_rag_amd.packing import wave_slot_order
-
-    def groups(lens):
-        used, n = 8, 0
-        for need in ((np.asarray(lens) + 63) // 64).tolist():
-            if used + need > 8:
-                n, used = n + 1, 0
-            used += need
-        return n
-
-    rng = np.random.default_rng(3)
-    for trial in range(5):
-        lens = np.clip(64 + rng.gamma(2.0, 68.0, size=int(rng.integers(1, 700))), 1, 512).astype(np.int64)
-        order = wave_slot_order(lens)
-        assert sorted(order.tolist()) == list(range(len(lens)))
-        slots = int(((lens + 63) // 64).sum())
-        assert groups(lens[order]) <= groups(lens)
-        assert groups(lens[order]) <= int(np.ceil(slots / 8 * 1.02)) + 1          # within 2 % (+1) of the slot lower bound
-    assert wave_slot_order([]).tolist() == [] and wave_slot_order([700, 64, 64]).tolist()[0] == 0   # an over-long sequence stays in front

@@ -32,8 +32,8 @@ struct QkvAttnParams {
 hipError_t launch_qkv_attention(const QkvAttnParams& p, bool local, hipStream_t stream);
 
 // Host: packs sequences seq0 .. seq1 - 1 (first rows `seq_row`, lengths `seq_len` <= kFusedMaxSeq) into groups, first fit over
-// CONSECUTIVE sequences (a group's rows are then one contiguous stretch of the packed buffer: one XCD's L2 serves its heads).
-// Writes 8 descriptors per group to `out` (room for 8 * (seq1 - seq0) of them) and returns the number of groups.
+// consecutive sequences -- the simple form the diagnostics use; the engine's packer (capi.hip) is best fit decreasing over the
+// whole micro-batch.  Writes 8 descriptors per group to `out` (room for 8 * (seq1 - seq0) of them), returns the number of groups.
 int fused_pack_groups(const int* seq_row, const int* seq_len, int seq0, int seq1, int4* out);
 
 // out[(h * 3 + part) * 64 + d][:] = w[part * H + h * 64 + d][:]  (and the same for the optional row-sum / bias vectors)

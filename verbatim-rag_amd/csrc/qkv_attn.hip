@@ -25,8 +25,9 @@
 // Round 4, wave-slot packing: a workgroup holds a GROUP of consecutive sequences, each on ceil(S / 64) consecutive waves (per-wave
 // descriptors: first row, sequence length, first wave of the sequence); K / V^T rows stay indexed by workgroup slot, positions,
 // masks and the key-tile walk are relative to the sequence.  A workgroup costs what a full one costs, so the schedule takes the
-// kernel when the groups are full enough (kFusedMinFillPct of 512 tokens per workgroup; GpuModelSpanExtractor orders a sub-batch's
-// pairs so that they are: packing.wave_slot_order).
+// kernel when the groups are full enough (kFusedMinFillPct of 512 tokens per workgroup).  A wave's descriptor carries its own first
+// row, so the sequences of a group need not be neighbours in the packed buffer: the engine packs a micro-batch's sequences best fit
+// decreasing (capi.hip), whatever order they arrived in.
 // Sequences longer than 512 tokens, BERT-family encoders, launch-bound batches and poorly filled batches keep the two-kernel path.
 #include "qkv_attn.h"
 

@@ -31,7 +31,6 @@ from .packing import (
     split_into_sentences,
     split_into_sentences_batch,
     valid_boundaries,
-    wave_slot_order,
 )
 
 logger = logging.getLogger(__name__)
@@ -466,10 +465,6 @@ class GpuModelSpanExtractor(SpanExtractor):
     def _run_sub_batch(self, batch, out, which: int = 0) -> None:
         """One workspace-sized batch: device logits, softmax, strict `>` threshold (extractors.py:272-275)."""
         engine = self.engines[which]
-        if len(batch) >= 64:
-            # throughput-sized sub-batch: hand the pairs over in wave-slot packing order (fuller workgroups for the fused
-            # QKV + attention kernel; the pairs are independent and results are stored by (query, text), so order is free)
-            batch = [batch[i] for i in wave_slot_order([len(b[3]) for b in batch]).tolist()]
         with self._locks[which]:
             try:
                 counts = np.asarray([len(b[4]) for b in batch], np.int64)

@@ -191,38 +191,3 @@ def valid_boundaries(boundaries: Sequence[Tuple[int, int]], seq_len: int) -> Lis
         out.append((s, e))
     return out
 
-
-def wave_slot_order(lengths, slot: int = 64, slots_per_group: int = 8):
-    """Order in which a throughput-sized batch of (question, chunk) pairs is handed to the engine: the fused QKV + attention
-    kernel (csrc/qkv_attn.hip) gives every sequence ceil(len / 64) of a workgroup's eight 64-token waves and packs CONSECUTIVE
-    sequences into a workgroup, and a workgroup costs the same however full it is -- so the pairs are emitted bin by bin of a
-    best-fit-decreasing packing into 8-slot bins (pairs of one bin consecutive, fullest-first inside).  The pairs are
-    independent (the reference extracts them one by one: verbatim_core/extractors.py:233-268), so any order gives the same
-    result per pair.  Returns the permutation (indices into `lengths`); sequences longer than a group keep their place in
-    front (they take the packed path anyway)."""
-    import numpy as np
-
-    lengths = np.asarray(lengths, np.int64)
-    need = (lengths + slot - 1) // slot
-    order = np.argsort(-need, kind="stable")
-    long_ones = [int(i) for i in order if need[i] > slots_per_group]
-    bins = []                                    # [remaining, [indices]]
-    by_remaining = [[] for _ in range(slots_per_group + 1)]   # open bins by remaining slots
-    for i in order:
-        n = int(need[i])
-        if n > slots_per_group:
-            continue
-        if n <= 0:
-            n = 1
-        b = None
-        for r in range(n, slots_per_group + 1):  # best fit: the open bin with the least room that still takes it
-            if by_remaining[r]:
-                b = by_remaining[r].pop()
-                break
-        if b is None:
-            b = len(bins)
-            bins.append([slots_per_group, []])
-        bins[b][1].append(int(i))
-        bins[b][0] -= n
-        by_remaining[bins[b][0]].append(b)
-    return np.asarray(long_ones + [i for _rem, members in bins for i in members], np.int64)

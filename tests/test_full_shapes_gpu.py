@@ -60,6 +60,45 @@ def test_configs1_batch_256x512_sample_vs_oracle():
     assert worst < 1e-3, worst
 
 
+def test_ragged_throughput_batch_sample_vs_oracle():
+    """BASELINE configs[1]'s model on the pair lengths real chunkers produce: 330 pairs of 1 .. 512 tokens (odd
+    lengths included, mean ~200) in one 65 536-row micro-batch.  By the default rule this batch takes the fused QKV + attention
+    kernel with WAVE-SLOT PACKING (several sequences per 512-token workgroup, groups packed best fit decreasing across the
+    micro-batch: neighbours in a workgroup are not neighbours in the packed buffer); a sample of pairs -- the shortest, the
+    longest, lengths around the 64-token slot edges -- is held to the oracle's 1e-3, and each equals itself extracted alone (the
+    two-kernel path) to rounding."""
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+    from verbatim_rag_amd.weights import random_init, random_qa_head
+
+    shape = ModernBertShape.base()
+    w = random_init(shape, seed=1234)
+    qa_w, qa_b = random_qa_head(shape)
+    rng = np.random.default_rng(77)
+    lens = np.clip(64 + rng.gamma(2.0, 68.0, size=330), 40, 512).astype(int).tolist()
+    lens[:8] = [1, 63, 64, 65, 128, 129, 511, 512]
+    seqs, bounds = [], []
+    for L in lens:
+        ids = rng.integers(1000, 50000, size=L)
+        ids[0] = shape.cls_token_id
+        seqs.append(ids.astype(np.int32))
+        step = max(1, L // 6)
+        bounds.append([(a, min(L - 1, a + step - 1)) for a in range(0, L, step)][:8])
+    eng = EncoderEngine(shape, w, max_tokens=sum(lens) + 8 * len(lens), max_seqs=len(lens), max_seq_len=512,
+                        max_ranges=sum(len(b) for b in bounds), micro_batch_tokens=65536)
+    eng.set_qa_head(qa_w, qa_b)
+    assert sum(lens) > 40000                      # throughput-sized: above the launch-bound threshold
+    got = eng.qa_logits(seqs, bounds)
+    cfg = _oracle_cfg(shape)
+    worst = 0.0
+    for i in (0, 1, 2, 3, 5, 6, 7, 100, 329):
+        ref = O.qa_sentence_logits(O.encoder_forward(cfg, w, seqs[i]), bounds[i], qa_w, qa_b)
+        worst = max(worst, float(np.abs(got[i] - ref).max()))
+        alone = eng.qa_logits([seqs[i]], [bounds[i]])[0]
+        assert np.abs(alone - got[i]).max() < 5e-4, f"pair {i} ({lens[i]} tokens): batch result differs from the pair alone"
+    eng.close()
+    assert worst < 1e-3, worst
+
+
 def test_modernbert_large_full_depth_vs_oracle():
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
     from verbatim_rag_amd.weights import random_init, random_qa_head

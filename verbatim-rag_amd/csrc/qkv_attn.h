@@ -5,7 +5,7 @@
 namespace vrag {
 
 constexpr int kFusedMaxSeq = 512;   // tokens one workgroup holds: 8 waves x 64 rows
-constexpr int kFusedMinFillPct = 72;   // tokens per 512-token workgroup (%) from which the kernel beats the two-kernel path: a workgroup costs what a full one costs
+constexpr int kFusedMinFillPct = 60;   // tokens per 512-token workgroup (%) from which the kernel beats the two-kernel path (a workgroup costs what a full one costs; measured: profiles/r04_fused_by_sequence_length.txt -- it still wins at 62.5 %, break-even ~58 %)
 
 struct QkvAttnParams {
   const bf16_t* x;         // [Tp, H] the Wqkv GEMM's A operand rows (op16(h - c) under the LayerNorm fold, else LN(h))

@@ -37,7 +37,7 @@ extern "C" {
 #define VRAG_ERR_CAPACITY (-3)/* batch does not fit the workspace the handle was created with */
 #define VRAG_ERR_NO_DEVICE (-4)
 
-#define VRAG_ABI_VERSION 5
+#define VRAG_ABI_VERSION 6
 
 /* MFMA operand type of an encoder handle.  bf16: fp32's exponent range (safe for any checkpoint), 8 significant bits --
  * sentence logits within 3e-4 of the fp32 reference.  fp16: 11 significant bits at the same matrix-core rate, values
@@ -158,6 +158,13 @@ int vrag_encoder_set_mlm_head(vrag_encoder* enc, const float* dense_w /*[H,H]*/,
 int vrag_encoder_set_mlm_head_ex(vrag_encoder* enc, const float* dense_w /*[H,H]*/, const float* dense_b /*[H]*/,
                                  const float* norm_w /*[H]*/, const float* norm_b /*[H]*/,
                                  const float* decoder_w /*[V,H] or NULL*/, const float* decoder_b /*[V]*/);
+
+/* Operand precision of the MLM / SPLADE head GEMMs, to be chosen BEFORE vrag_encoder_set_mlm_head*: split_operands != 0
+ * (the default) carries activations and weights as (value, remainder) pairs of the operand type -- the dense layer as
+ * three accumulating GEMMs, the decoder as one GEMM over K = 3H -- so that every SPLADE weight max_s log1p(relu(logit))
+ * stays within 2e-3 of the fp32 arithmetic of SparseEncoder.encode (embedding_providers.py:127-166; nothing averages
+ * operand rounding away under a max); 0 = plain 16-bit operands: a third of the decoder work, weights within ~1e-2. */
+int vrag_encoder_set_head_precision(vrag_encoder* enc, int32_t split_operands);
 
 /* Sentence-pair inputs (cross-encoder reranking: sentence-transformers CrossEncoder over
  * BertForSequenceClassification, verbatim_rag/rerankers.py:109-134).  BERT-family handles only.
@@ -330,6 +337,28 @@ int vrag_sparse_index_search_device(vrag_sparse_index* ix, const int64_t* q_indp
 int vrag_topk_merge(const float* scores, const int64_t* ids, int32_t n_lists, int32_t nq, int32_t k_in, int32_t k_out,
                     int64_t score_list_stride, int64_t id_list_stride, float* out_scores, int64_t* out_ids,
                     int32_t on_device, int32_t device, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The exchange step of sharded retrieval: one process per GPU, the corpus row-sharded, every rank answers the
+ * (replicated) query batch on its own shard with vrag_*_index_search_device and contributes its packed lists
+ *     payload = [ global ids  int64 x nq*k_in | scores fp32 x nq*k_in | pad to 8 bytes ]       (device memory)
+ * to ONE RCCL all-gather over xGMI; every rank then merges the world's lists on its GPU.  RCCL is bound at run time (the
+ * copy already mapped into the process -- e.g. torch's -- else the system librccl.so.1; $VRAG_RCCL_LIB overrides).
+ * The host framework only has to carry the unique id from rank 0 to the other ranks (torch.distributed broadcast, MPI, a
+ * file): vrag_comm_get_unique_id on rank 0, vrag_comm_create (collective: every rank calls it) everywhere.
+ * Calls on one communicator must be issued in the same order on every rank (RCCL's rule). */
+#define VRAG_COMM_ID_BYTES 128
+typedef struct vrag_comm vrag_comm;
+int vrag_comm_get_unique_id(uint8_t* id /*[VRAG_COMM_ID_BYTES]*/);
+int vrag_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device, vrag_comm** out);
+void vrag_comm_destroy(vrag_comm* comm);
+int vrag_comm_info(vrag_comm* comm, int32_t* rank, int32_t* world, int32_t* rccl_version /* any may be NULL */);
+/* ncclAllGather of nbytes per rank, enqueued on `stream` (NULL = the legacy default stream); recv holds world * nbytes. */
+int vrag_comm_allgather(vrag_comm* comm, const void* send /*device*/, void* recv /*device*/, int64_t nbytes, void* stream);
+/* The whole exchange: all-gather of `payload` into `gathered` (device scratch of world * payload bytes) + vrag_topk_merge in
+ * place, both enqueued on `stream`; out_* are device [nq, k_out], identical on every rank.  No synchronisation. */
+int vrag_topk_allgather_merge(vrag_comm* comm, const void* payload, void* gathered, int32_t nq, int32_t k_in, int32_t k_out,
+                              float* out_scores /*device*/, int64_t* out_ids /*device*/, void* stream);
 
 /* Sentence boundaries of a batch of chunk texts (the GPU-side sentence split): for every document the parts of
  *   re.split(r"(?<=[.!?])\s+", text), each stripped of surrounding white space, empty parts dropped

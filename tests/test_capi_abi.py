@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.vrag_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.vrag_abi_version() == _lib.ABI_VERSION == 6
     assert lib.vrag_device_count() >= 0
     assert isinstance(_lib.last_error(), str)
 

@@ -4,7 +4,7 @@
   * configs[2]: a 10^6-document / ~1.28 * 10^8-nnz SELL-64 shard, 1 000 queries, k = 5 -- the 8-queries-per-pass kernel
     and the single-query kernel, ids AND scores equal to the oracle;
   * configs[3] (one GPU's slice of the 10^7-row index): 1.25 * 10^6 x 768 rows, fp32 (bit-exact on arbitrary data) and
-    bf16 (bit-exact on bf16-representable grid data), 1 / 32 / 256 queries;
+    bf16 (bit-exact on bf16-representable grid data), 1 / 32 / 256 (bf16: / 4 096) queries;
   * both through the PUBLIC ingest path -- `GpuVectorStore.add_vectors` (milvus_base.py:90-127) -> `query_batch` /
     `query` (milvus_base.py:189-313) on a 10^6-chunk hybrid store: dense, sparse, hybrid (RRF), filtered, after a
     delete and after an append (dense append + sparse tail segment);
@@ -90,7 +90,10 @@ def test_configs3_dense_shard_1_25m_rows(dtype):
 
     gen = S.dense_rows if dtype == "f32" else S.dense_grid
     X = gen(N_DENSE, DIM, seed=31)
-    Q = gen(256, DIM, seed=32)
+    # bf16 rows: up to 4 096 queries -- batches of >= 64 take the tiled search (the shard read once per batch: rows x queries
+    # on the encoder's GEMM kernel with the candidate-filter epilogue, csrc/topk.hip "dense, tiled batched search")
+    nqs = (1, 32, 256) if dtype == "f32" else (1, 32, 256, 4096)
+    Q = gen(nqs[-1], DIM, seed=32)
     sh = DenseShard(DIM, N_DENSE, dtype)
     t0 = time.perf_counter()
     sh.add(X)
@@ -98,9 +101,9 @@ def test_configs3_dense_shard_1_25m_rows(dtype):
     k = 10
     t0 = time.perf_counter()
     rs, ri = T.dense_topk(X, Q, k, blocked=True)
-    _note(f"dense_{dtype}_256_queries_oracle_s", time.perf_counter() - t0)
+    _note(f"dense_{dtype}_{nqs[-1]}_queries_oracle_s", time.perf_counter() - t0)
     try:
-        for nq in (1, 32, 256):
+        for nq in nqs:
             t0 = time.perf_counter()
             s, i = sh.search(Q[:nq], k)
             _note(f"dense_{dtype}_{nq}_queries_search_s", time.perf_counter() - t0)

@@ -46,6 +46,26 @@ def _worker(port, q):
         stream = torch.cuda.current_stream().cuda_stream
         sh.search_device(Q, 10, scores_ptr, ids_ptr, row_map=table.data_ptr(), n_map=len(X), stream=stream)
         ms, mi = comm.allgather_merge_device(payload, len(Q), 10, 10)
+        out["exchange_backend"] = comm.exchange_backend       # RCCL behind the C ABI (vrag_comm_create / vrag_topk_allgather_merge)
+        # the same payload through torch's communicator (VRAG_COMM=torch) gives the same lists
+        os.environ["VRAG_COMM"] = "torch"
+        comm_t = ShardComm(device=0)
+        os.environ.pop("VRAG_COMM")
+        mst, mit = comm_t.allgather_merge_device(payload, len(Q), 10, 10)
+        out["torch_comm_equals_library_comm"] = bool(comm_t.exchange_backend == "torch.distributed" and np.array_equal(ms, mst)
+                                                     and np.array_equal(mi, mit))
+        # raw all-gather entry point + communicator info
+        from verbatim_rag_amd import _lib as L
+        import ctypes as CT
+
+        rk, wd, ver = CT.c_int32(-1), CT.c_int32(-1), CT.c_int32(0)
+        L.check("info", L.load().vrag_comm_info(comm._vcomm, CT.byref(rk), CT.byref(wd), CT.byref(ver)))
+        src = torch.arange(1000, dtype=torch.uint8, device="cuda")
+        dst = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+        L.check("ag", L.load().vrag_comm_allgather(comm._vcomm, CT.c_void_p(src.data_ptr()), CT.c_void_p(dst.data_ptr()), 1000,
+                                                    CT.c_void_p(stream)))
+        torch.cuda.synchronize()
+        out["raw_allgather"] = bool((rk.value, wd.value) == (0, 1) and ver.value > 0 and torch.equal(src, dst))
         rs, ri = T.dense_topk(X, Q, 10)
         out["dense_device_exchange"] = bool(np.array_equal(mi, hi + 1000) and np.array_equal(ms, hs) and np.array_equal(hi, ri)
                                             and np.array_equal(hs, rs))
@@ -127,6 +147,7 @@ def test_rccl_world1_exchange_and_store():
     p.join(120)
     assert isinstance(out, dict), out
     assert out.pop("backend") == ("nccl", True)
+    assert out.pop("exchange_backend") == "vrag_comm"
     assert out.pop("store_distributed_flag") == (True, 1)
     bad = {k: v for k, v in out.items() if v is not True}
     assert not bad, bad

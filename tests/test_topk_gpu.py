@@ -438,3 +438,75 @@ def test_dense_edges_dim_limits_and_capacity():
     s, i = sh.search(_dyadic(rng, (2, 64)), 3)
     sh.close()
     assert (i == -1).all() and np.isneginf(s).all()
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 64, 10), (300_000, 384, 300, 5), (5_000, 128, 100, 16), (200_000, 1024, 257, 64),
+                                         (4_096, 64, 64, 1), (4_353, 256, 65, 7), (1_100_000, 64, 500, 33)])
+def test_dense_topk_tiled_batched_search_exact(n, dim, nq, k):
+    """>= 64 queries over >= 4 096 bf16 rows: the shard is read once per batch -- rows x queries on the encoder's GEMM
+    kernel, EPI_TOPK epilogue, staged thresholds (csrc/topk.hip).  Dyadic-grid data: ids and scores equal the oracle bit
+    for bit, ties (duplicated rows and queries, a small value range) included; row counts around the stage boundaries
+    256 / 4 096 / 65 536 / 1 048 576 and query counts off the 256-column tile."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(n + nq)
+    X, Q = _dyadic(rng, (n, dim), lim=8 if dim <= 128 else 64), _dyadic(rng, (nq, dim))
+    X[n // 2] = X[n // 3]
+    X[n - 1] = X[0]
+    Q[1] = Q[0]
+    sh = DenseShard(dim, n, "bf16")
+    sh.add(X)
+    s, i = sh.search(Q, k)
+    s2, i2 = sh.search(Q[:63], k)          # the 32-queries-per-pass route on the same shard
+    sh.close()
+    rs, ri = T.dense_topk(X, Q, k, blocked=n * nq > 5_000_000)
+    assert np.array_equal(i, ri), (n, dim, nq, k)
+    assert np.array_equal(s, rs), (n, dim, nq, k)
+    assert np.array_equal(i2, ri[:63]) and np.array_equal(s2, rs[:63])
+
+
+def test_dense_topk_tiled_fp32_queries_ride_as_column_pairs():
+    """Queries that are not bf16 numbers: (value, remainder) column pairs in the tiled search too -- the ranking equals the
+    fp32-query oracle's up to fp32 summation noise, exactly like the 16-queries-per-pass route."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((90_000, 768)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = X[:150] + 0.05 * rng.standard_normal((150, 768)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    assert (Q.view(np.uint32) & 0xFFFF).any()
+    rows = T.bf16_round(X)
+    sh = DenseShard(768, len(X), "bf16")
+    sh.add(X)
+    sb, ib = sh.search(Q, 10)
+    sh.close()
+    rs, ri = T.dense_topk(rows, Q, 10, blocked=True)
+    _assert_same_ranking(sb, ib, rs, ri, rows, Q)
+    assert (ib[:, 0] == np.arange(150)).all()
+
+
+def test_dense_topk_tiled_candidate_overflow_is_rescued():
+    """Rows sorted by similarity to a query: every row of a stage beats the threshold the stage started with, the
+    query's candidate buffer (2 048 slots) overflows, and the rescue pass re-answers that query from the whole shard.
+    Query 0 scores row r as x0 + x1 / 256 with (x0, x1) ascending in r -- 16 641 distinct, strictly increasing scores;
+    query 1 sees them descending; the other queries are ordinary."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(77)
+    n, dim, nq, k = 16_641, 128, 70, 10
+    X = _dyadic(rng, (n, dim), lim=4)
+    r = np.arange(n)
+    X[:, 0] = ((r // 129) - 64) / 64.0
+    X[:, 1] = ((r % 129) - 64) / 64.0
+    Q = _dyadic(rng, (nq, dim))
+    Q[0] = 0
+    Q[0, 0], Q[0, 1] = 1.0, 1.0 / 256
+    Q[1] = -Q[0]
+    sh = DenseShard(dim, n, "bf16")
+    sh.add(X)
+    s, i = sh.search(Q, k)
+    sh.close()
+    rs, ri = T.dense_topk(X, Q, k)
+    assert np.array_equal(i[0], np.arange(n - 1, n - 1 - k, -1)) and np.array_equal(i[1], np.arange(k))
+    assert np.array_equal(i, ri) and np.array_equal(s, rs)

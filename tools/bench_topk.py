@@ -34,19 +34,24 @@ def dense(n=1_250_000, dim=768, k=10):
     for _ in range(n // chunk):
         sh.add((rng.integers(-64, 65, size=(chunk, dim)) / 64.0).astype(np.float32))
     out = []
-    for nq, exact in ((1, True), (4, True), (32, True), (256, True), (256, False)):
+    tiled_off = os.environ.get("VRAG_TOPK_NO_TILED") is not None
+    for nq, exact in ((1, True), (4, True), (32, True), (64, True), (256, True), (256, False), (1024, True), (10240, True)):
         if exact:   # bf16-exact queries: 32 per matrix-core pass
             q = (rng.integers(-64, 65, size=(nq, dim)) / 64.0).astype(np.float32)
         else:       # generic fp32 queries: (bf16, remainder) column pairs, 16 per pass
             q = rng.standard_normal((nq, dim)).astype(np.float32)
         sh.search(q, k)
-        dt = timeit(lambda: sh.run_resident(nq, k), 10)
+        dt = timeit(lambda: sh.run_resident(nq, k), 10 if nq <= 1024 else 3)
+        tiled = nq >= 64 and not tiled_off     # csrc/topk.hip dense_use_tiled: the shard is read once per batch
         per_pass = 1 if nq == 1 else (4 if nq < 3 else (32 if exact else 16))
-        passes = (nq + per_pass - 1) // per_pass
+        passes = 1 if tiled else (nq + per_pass - 1) // per_pass
         bytes_ = n * dim * 2 * passes          # one pass streams the shard once, whatever the number of queries in it
+        flops = 2.0 * n * dim * nq * (1 if exact else 2)
         out.append({"kind": "dense_bf16", "rows": n, "dim": dim, "nq": nq, "k": k, "fp32_queries_split": not exact,
+                    "route": "tiled_gemm_epilogue" if tiled else "query_passes",
                     "ms": dt * 1e3, "queries_per_s": nq / dt, "algorithmic_GBps": bytes_ / dt / 1e9,
-                    "frac_of_8TBps": bytes_ / dt / HBM_PEAK, "bytes_per_pass": n * dim * 2, "passes": passes})
+                    "frac_of_8TBps": bytes_ / dt / HBM_PEAK, "bytes_per_pass": n * dim * 2, "passes": passes,
+                    "TFLOPs": flops / dt / 1e12, "frac_of_2p5_PFLOPs": flops / dt / 2.5e15})
     sh.close()
     return out
 

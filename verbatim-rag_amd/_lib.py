@@ -11,7 +11,7 @@ _LOCK = threading.Lock()
 _LIB = None
 
 VRAG_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 PROF_CLASSES = (
     "embed", "layernorm", "gemm_qkv", "attn_global", "attn_local",
     "gemm_wo", "gemm_wi", "gemm_wo_mlp", "head", "qkv_attn_global", "qkv_attn_local",
@@ -82,6 +82,7 @@ SIGNATURES = {
     "vrag_encoder_set_token_head": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int32]),
     "vrag_encoder_set_mlm_head": (C.c_int, [_H, _FP, _FP, _FP, _FP]),
     "vrag_encoder_set_mlm_head_ex": (C.c_int, [_H, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "vrag_encoder_set_head_precision": (C.c_int, [_H, C.c_int32]),
     "vrag_encoder_set_token_types": (C.c_int, [_H, _FP, C.c_int32]),
     "vrag_encoder_load_token_types": (C.c_int, [_H, _IP, C.c_void_p]),
     "vrag_encoder_set_pair_head": (C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int32]),
@@ -132,6 +133,13 @@ SIGNATURES = {
     "vrag_sparse_index_stats": (C.c_int, [_H, _LP, _LP, _LP]),
     "vrag_sparse_index_search": (C.c_int, [_H, _LP, _IP, _FP, C.c_int32, C.c_int32, _FP, _LP, C.c_void_p]),
     "vrag_sparse_index_run_resident": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p]),
+    "vrag_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "vrag_comm_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_H)]),
+    "vrag_comm_destroy": (None, [_H]),
+    "vrag_comm_info": (C.c_int, [_H, _IP, _IP, _IP]),
+    "vrag_comm_allgather": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vrag_topk_allgather_merge": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "vrag_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
 }

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 # VRAG_BUILD_VARIANT=<tag> (tuning experiments only): objects under build_<tag>/, library libvrag_amd_<tag>.so -- load it with VRAG_AMD_LIB
 VARIANT = os.environ.get("VRAG_BUILD_VARIANT", "")
 LIB_PATH = os.path.join(HERE, f"libvrag_amd_{VARIANT}.so" if VARIANT else "libvrag_amd.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "qkv_attn.hip", "norm_heads.hip", "topk.hip", "text.hip", "capi.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "qkv_attn.hip", "norm_heads.hip", "topk.hip", "text.hip", "comm.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 FLAGS += os.environ.get("VRAG_HIPCC_FLAGS", "").split()  # tuning experiments only
 
@@ -53,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or any(_newer(o, LIB_PATH) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB_PATH]   # -ldl: comm.hip binds RCCL at run time
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

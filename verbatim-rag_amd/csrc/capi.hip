@@ -85,6 +85,28 @@ static void launch_cvt_rows(int op_dtype, dim3 grid, hipStream_t st, const float
                        col_scale, row_sum, dst_lo);
 }
 
+// fp32 matrix rows [rows_src, cols] -> [rows_dst, 3 cols] operand image [hi | hi | lo] (zero rows beyond rows_src): the
+// weight side of a K = 3 cols split-operand GEMM whose A operand is [xhi | xlo | xhi] (norm_heads.hip layernorm_kernel,
+// split3): sum = xhi.Whi + xlo.Whi + xhi.Wlo, the three products of (xhi + xlo).(Whi + Wlo) above fp32 resolution.
+template <typename T>
+__global__ void cvt_split3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst_, int rows_dst, int rows_src, int cols) {
+  T* dst = reinterpret_cast<T*>(dst_);
+  const int r = blockIdx.x;
+  if (r >= rows_dst) return;
+  T* row = dst + (size_t)r * 3 * cols;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float v = r < rows_src ? src[(size_t)r * cols + c] : 0.f;
+    const T hi = Op<T>::to(v);
+    row[c] = hi;
+    row[cols + c] = hi;
+    row[2 * cols + c] = Op<T>::to(v - (float)hi);
+  }
+}
+static void launch_cvt_split3(int op_dtype, hipStream_t st, const float* src, bf16_t* dst, int rows_dst, int rows_src, int cols) {
+  if (op_dtype == kOpF16) hipLaunchKernelGGL(cvt_split3_kernel<f16_t>, dim3(rows_dst), dim3(256), 0, st, src, dst, rows_dst, rows_src, cols);
+  else hipLaunchKernelGGL(cvt_split3_kernel<bf16_t>, dim3(rows_dst), dim3(256), 0, st, src, dst, rows_dst, rows_src, cols);
+}
+
 // Row statistics from the per-segment partial sums left by the residual GEMM epilogue.  The sums are over (h - c)
 // with c = shift[r] (the row's previous mean; null = 0):  d = mean(h - c),  var = E[(h-c)^2] - d^2  -- no
 // cancellation however large |mean(h)| is --, mu_rel[r] = d (what the consumer GEMM's fold subtracts from its
@@ -257,6 +279,10 @@ struct vrag_encoder {
   bf16_t *mlm_dense = nullptr, *mlm_dec = nullptr;
   float *mlm_norm = nullptr, *mlm_bias = nullptr;
   int vpad = 0;
+  // split-operand MLM head (vrag_encoder_set_head_precision, the default): dense weight remainder, the decoder as a
+  // [vpad, 3H] image [Whi | Whi | Wlo] and the [cap_rows, 3H] operand image [xhi | xlo | xhi] its K = 3H GEMM reads
+  bool mlm_split = true;
+  bf16_t *mlm_dense_lo = nullptr, *mlm_dec3 = nullptr, *splade_a3 = nullptr;
 
   // workspace
   int cap_rows = 0;
@@ -1356,11 +1382,31 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* e, const float* dense_w, const fl
   float* stage = nullptr;
   int rc = dev_alloc(e, &stage, stage_elems, false);
   if (rc) return rc;
-  if ((rc = upload_bf16(e, &e->mlm_dense, dense_w, H, H, H, 0, stage, stage_elems))) return rc;
+  if ((rc = upload_bf16(e, &e->mlm_dense, dense_w, H, H, H, 0, stage, stage_elems, nullptr, nullptr,
+                        e->mlm_split ? &e->mlm_dense_lo : nullptr)))
+    return rc;
   if ((rc = upload_f32(e, &e->mlm_norm, norm_w, H))) return rc;
   if (dense_b && (rc = upload_f32(e, &e->mlm_dense_b, dense_b, H))) return rc;
   if (norm_b && (rc = upload_f32(e, &e->mlm_norm_b, norm_b, H))) return rc;
-  if (decoder_w) {
+  if (e->mlm_split) {
+    // decoder as [Whi | Whi | Wlo] rows of 3H operand values; host weights stream through the staging buffer in row chunks
+    if ((rc = dev_alloc(e, &e->mlm_dec3, (size_t)vpad * 3 * H, false))) return rc;
+    if ((rc = dev_alloc(e, &e->splade_a3, (size_t)e->cap_rows * 3 * H, true))) return rc;
+    if (decoder_w) {
+      const int chunk = (int)std::max<size_t>(1, stage_elems / H);
+      for (int r0 = 0; r0 < vpad; r0 += chunk) {
+        const int nr_dst = std::min(chunk, vpad - r0), nr_src = std::max(0, std::min(chunk, V - r0));
+        if (nr_src > 0) HIP_TRY(hipMemcpy(stage, decoder_w + (size_t)r0 * H, (size_t)nr_src * H * sizeof(float), hipMemcpyHostToDevice));
+        launch_cvt_split3(e->op_dtype, 0, stage, e->mlm_dec3 + (size_t)r0 * 3 * H, nr_dst, nr_src, H);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+      }
+    } else {   // tied decoder: the device-resident fp32 embedding table
+      launch_cvt_split3(e->op_dtype, 0, e->tok_emb, e->mlm_dec3, vpad, V, H);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+    }
+  } else if (decoder_w) {
     if ((rc = upload_bf16(e, &e->mlm_dec, decoder_w, V, H, vpad, 0, stage, stage_elems))) return rc;
   } else {
     // tied decoder: convert the device-resident fp32 embedding table
@@ -1373,6 +1419,14 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* e, const float* dense_w, const fl
   if (decoder_b) HIP_TRY(hipMemcpy(e->mlm_bias, decoder_b, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
   if ((rc = dev_alloc(e, &e->d_splade, (size_t)e->cfg.max_seqs * vpad))) return rc;
   e->vpad = vpad;
+  return VRAG_OK;
+}
+
+int vrag_encoder_set_head_precision(vrag_encoder* e, int32_t split_operands) {
+  ARG_CHECK(e, "null handle");
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  ARG_CHECK(e->mlm_dec == nullptr && e->mlm_dec3 == nullptr, "set the head precision before the MLM head (vrag_encoder_set_mlm_head*)");
+  e->mlm_split = split_operands != 0;
   return VRAG_OK;
 }
 
@@ -1836,41 +1890,70 @@ int vrag_encoder_run_splade(vrag_encoder* e, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> lk(e->mu);
-  ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set (vrag_encoder_set_mlm_head)");
+  ARG_CHECK(e->mlm_dec != nullptr || e->mlm_dec3 != nullptr, "mlm head not set (vrag_encoder_set_mlm_head)");
   ARG_CHECK(e->ran, "encoder has not run on this batch");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
   const int H = e->cfg.hidden_size;
   ProfScope ps(e, VRAG_PROF_HEAD, st);
-  if (e->arch == 1) {  // post-LN stream: no final LayerNorm, just the bf16 operand copy
-    launch_cvt_rows(e->op_dtype, dim3(e->rows), st, e->h, e->a, e->rows, e->rows, H, 0, (const float*)nullptr, (float*)nullptr);
+  const bool split = e->mlm_dec3 != nullptr;
+  // Split operands (default): every SPLADE weight is a max over tokens of log1p(relu(logit)) -- nothing averages the
+  // operand rounding of the two head GEMMs away (1e-2 on a weight with plain bf16 operands, and these rows feed a sparse
+  // index whose top-k is held to bit-exactness).  x = xhi + xlo and W = Whi + Wlo in the operand type; the dense layer
+  // runs as three accumulating GEMMs like the token head's, the decoder as ONE GEMM over K = 3H on the operand images
+  // [xhi | xlo | xhi] x [Whi | Whi | Wlo] with the SPLADE epilogue on the sum (lo.lo is below fp32 resolution).
+  bf16_t* x_lo = split ? e->o : nullptr;   // the attention output buffer is free once the layers have run
+  if (e->arch == 1) {  // post-LN stream: no final LayerNorm, just the operand copy
+    launch_cvt_rows(e->op_dtype, dim3(e->rows), st, e->h, e->a, e->rows, e->rows, H, 0, (const float*)nullptr, (float*)nullptr, x_lo);
     HIP_TRY(hipGetLastError());
   } else {
-    HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, nullptr, nullptr, e->op_dtype));
+    HIP_TRY(launch_layernorm(e->h, e->final_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, nullptr, nullptr, e->op_dtype, x_lo));
   }
-  GemmParams g{};
-  g.op_dtype = e->op_dtype;
-  g.A = e->a;
-  g.W = e->mlm_dense;
-  g.M = e->rows;
-  g.N = H;
-  g.K = H;
-  g.out_f32 = e->f32tmp;
-  g.bias = e->mlm_dense_b;
-  HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
-  HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, e->mlm_norm_b, nullptr,
-                           e->op_dtype));
   HIP_TRY(hipMemsetAsync(e->d_splade, 0, (size_t)e->n_seqs * e->vpad * sizeof(unsigned), st));
   GemmParams d{};
   d.op_dtype = e->op_dtype;
-  d.A = e->a;
-  d.W = e->mlm_dec;
   d.M = e->rows;
   d.N = e->vpad;
-  d.K = H;
   d.bias = e->mlm_bias;
   d.tok_seq = e->d_tokseq;
   d.splade_rows = e->d_splade;
+  if (split) {
+    HIP_TRY(hipMemsetAsync(e->f32tmp, 0, (size_t)e->rows * H * sizeof(float), st));
+    const bf16_t* parts[3][2] = {{e->a, e->mlm_dense}, {x_lo, e->mlm_dense}, {e->a, e->mlm_dense_lo}};
+    for (int i = 0; i < 3; ++i) {
+      GemmParams g{};
+      g.op_dtype = e->op_dtype;
+      g.A = parts[i][0];
+      g.W = parts[i][1];
+      g.M = e->rows;
+      g.N = H;
+      g.K = H;
+      g.out_f32 = e->f32tmp;
+      g.bias = i == 0 ? e->mlm_dense_b : nullptr;   // BERT-family heads: the bias rides in with the first partial product
+      HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
+    }
+    HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->splade_a3, nullptr, st, e->mlm_norm_b, nullptr,
+                             e->op_dtype, nullptr, /*gelu_first=*/1, /*split3=*/1));
+    d.A = e->splade_a3;
+    d.W = e->mlm_dec3;
+    d.K = 3 * H;
+  } else {
+    GemmParams g{};
+    g.op_dtype = e->op_dtype;
+    g.A = e->a;
+    g.W = e->mlm_dense;
+    g.M = e->rows;
+    g.N = H;
+    g.K = H;
+    g.out_f32 = e->f32tmp;
+    g.bias = e->mlm_dense_b;
+    HIP_TRY(launch_gemm(EPI_F32_GELU, g, st));
+    HIP_TRY(launch_layernorm(e->f32tmp, e->mlm_norm, e->cfg.norm_eps, H, e->rows, e->a, nullptr, st, e->mlm_norm_b, nullptr,
+                             e->op_dtype));
+    d.A = e->a;
+    d.W = e->mlm_dec;
+    d.K = H;
+  }
   HIP_TRY(launch_gemm(EPI_SPLADE, d, st));
   return VRAG_OK;
 }

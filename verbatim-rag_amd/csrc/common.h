@@ -180,6 +180,21 @@ static inline unsigned f16_sat_take(bool reset) {
   return v;
 }
 
+// Top-k candidate keys (csrc/topk.hip; also built by the EPI_TOPK epilogue of csrc/gemm_bf16.hip): one u64
+//   [ orderable(score) : 32 | 0xFFFFFFFF - local_row : 32 ]      (max key == best hit under (score desc, id asc))
+typedef unsigned long long u64;
+__device__ __forceinline__ unsigned orderable(float s) {
+  const unsigned b = __builtin_bit_cast(unsigned, s);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float unorderable(unsigned k) {
+  const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ u64 make_key(float s, unsigned row) {
+  return ((u64)orderable(s) << 32) | (u64)(0xFFFFFFFFu - row);
+}
+
 // 16-byte global -> LDS DMA. LDS destination = wave-uniform `lds` + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -14,6 +14,7 @@ enum GemmEpi {
   EPI_QKV_ROPE = 5,  // RoPE(q,k) in fp32, q *= d^-1/2, write Q,K [T,nh,64] and V^T [nh,64,T]
   EPI_SPLADE = 6,    // rows[seq(m)][n] = max(rows, log1p(relu(acc+bias)))  via ordered-uint atomicMax
   EPI_NONE = 7,      // diagnostics: main loop only (accumulators kept alive, nothing stored)
+  EPI_TOPK = 8,      // batched dense search: A = corpus rows, W = queries; scores above the query's entry threshold become candidate keys
   EPI_COUNT
 };
 
@@ -67,6 +68,17 @@ struct GemmParams {
   // launch costs as much as the kernel (a query's handful of chunks).
   const float* stats_in;  // [Mpad, K/64, 2] or null (then ln_mu / ln_rstd were written by ln_stats_finalize_kernel)
   float fin_eps;          // LayerNorm eps of that finalisation
+  // EPI_TOPK (csrc/topk.hip, the tiled batched dense search): output column n is query n (topk_pairs: queries ride as
+  // (bf16 value, bf16 remainder) column pairs 2q, 2q + 1 and the score is the pair's sum); row m is corpus row topk_row_base + m.
+  // A score enters query q's candidate list when its key (score, row) is above topk_thr_key[q]; topk_thr_score[q] is that
+  // key's score (-inf while the list is short), the cheap pre-filter every accumulator is compared with.
+  // topk_direct: first stage, every row is a candidate -- slot = m, no counter traffic.
+  const float* topk_thr_score;      // [n queries]
+  const unsigned long long* topk_thr_key;
+  unsigned* topk_cnt;               // [n queries] candidates appended so far (may exceed topk_cap: the overflow is detected by the selection kernel)
+  unsigned long long* topk_buf;     // [n queries][topk_cap]
+  int topk_cap, topk_nq, topk_pairs, topk_direct;
+  unsigned topk_row_base;
   int op_dtype;           // kOpBf16 (0) or kOpF16 (1): what A, W and every 16-bit output hold (pointers stay typed bf16_t*)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid
   int act_gelu;           // EPI_BF16: apply GELU(erf) after the bias

@@ -630,6 +630,62 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       done_below = cur + 1;
     }
+  } else if constexpr (EPI == EPI_TOPK) {
+    // Lane = corpus row (per row tile rt), registers = 4 consecutive query columns per column tile nj.  After the first
+    // rows of a shard almost nothing passes the entry threshold: the common case is 128 compares per lane and one branch.
+    f32x4 thr[4];
+    if (p.topk_pairs) {
+      // columns (2j, 2j + 1) = (value, remainder) of query (n >> 1): both columns of a pair hold the pair's threshold
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        const int qa = (nw + nj * 16 + 4 * q) >> 1;
+        const float t0 = qa < p.topk_nq ? p.topk_thr_score[qa] : INFINITY, t1 = qa + 1 < p.topk_nq ? p.topk_thr_score[qa + 1] : INFINITY;
+        thr[nj] = f32x4{t0, t0, t1, t1};
+      }
+    } else {
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        const int n = nw + nj * 16 + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) thr[nj][r] = n + r < p.topk_nq ? p.topk_thr_score[n + r] : INFINITY;
+      }
+    }
+    bool any = false;
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if (p.topk_pairs) {
+          any |= (acc[nj][rt][0] + acc[nj][rt][1] >= thr[nj][0]) | (acc[nj][rt][2] + acc[nj][rt][3] >= thr[nj][2]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) any |= (acc[nj][rt][r] >= thr[nj][r]);
+        }
+      }
+    if (any) {
+      auto offer = [&](float score, int query, int row) {
+        if (row >= p.M || query >= p.topk_nq) return;   // padding rows of the last tile hold whatever the allocation does
+        const unsigned long long key = make_key(score, p.topk_row_base + (unsigned)row);
+        if (key <= p.topk_thr_key[query]) return;
+        const unsigned slot = p.topk_direct ? (unsigned)row : atomicAdd(p.topk_cnt + query, 1u);
+        if (slot < (unsigned)p.topk_cap) p.topk_buf[(size_t)query * p.topk_cap + slot] = key;
+      };
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = mw + rt * 16 + l15, n = nw + nj * 16 + 4 * q;
+          if (p.topk_pairs) {
+            const float s0 = acc[nj][rt][0] + acc[nj][rt][1], s1 = acc[nj][rt][2] + acc[nj][rt][3];
+            if (s0 >= thr[nj][0]) offer(s0, n >> 1, row);
+            if (s1 >= thr[nj][2]) offer(s1, (n >> 1) + 1, row);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (acc[nj][rt][r] >= thr[nj][r]) offer(acc[nj][rt][r], n + r, row);
+          }
+        }
+    }
   }
 }
 
@@ -917,6 +973,7 @@ static hipError_t launch_typed(GemmEpi epi, const GemmParams& p, hipStream_t str
     case EPI_QKV_ROPE: return launch_t<EPI_QKV_ROPE, T>(p, stream);
     case EPI_SPLADE: return launch_t<EPI_SPLADE, T>(p, stream);
     case EPI_NONE: return launch_t<EPI_NONE, T>(p, stream);
+    case EPI_TOPK: return launch_t<EPI_TOPK, T>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -937,7 +994,8 @@ const char* gemm_kernel_name(GemmEpi epi) {
   static const char* names[] = {"gemm_bf16_kernel<EPI_F32>",      "gemm_bf16_kernel<EPI_BF16>",
                                 "gemm_bf16_kernel<EPI_F32_GELU>", "gemm_bf16_kernel<EPI_RESIDUAL>",
                                 "gemm_bf16_kernel<EPI_GEGLU>",     "gemm_bf16_kernel<EPI_QKV_ROPE>",
-                                "gemm_bf16_kernel<EPI_SPLADE>",    "gemm_bf16_kernel<EPI_NONE>"};
+                                "gemm_bf16_kernel<EPI_SPLADE>",    "gemm_bf16_kernel<EPI_NONE>",
+                                "gemm_bf16_kernel<EPI_TOPK>"};
   return epi >= 0 && epi < EPI_COUNT ? names[epi] : "?";
 }
 

@@ -17,10 +17,13 @@ hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float
 // out = LN(h) * w (+ bias); writes bf16 and/or fp32 (either pointer may be null; out_f32 may be h itself).
 // w == nullptr: no gain (it is folded into the consumer GEMM's weight); row_mean != nullptr: also mean(h[row]).
 // op_dtype: what out_bf16 holds (kOpBf16 / kOpF16); out_lo != nullptr: also the remainder  x - float(out_bf16)  in the
-// same type (the split-operand head GEMM multiplies both parts).
+// same type (the split-operand head GEMM multiplies both parts).  gelu_first: h is a raw dense output, gelu_erf is applied
+// before the normalisation.  split3: out_bf16 is a [rows, 3H] image [hi | lo | hi] (out_lo must be null): the A operand of a
+// K = 3H split-operand GEMM.
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows,
                             bf16_t* out_bf16, float* out_f32, hipStream_t stream, const float* bias = nullptr,
-                            float* row_mean = nullptr, int op_dtype = kOpBf16, bf16_t* out_lo = nullptr);
+                            float* row_mean = nullptr, int op_dtype = kOpBf16, bf16_t* out_lo = nullptr, int gelu_first = 0,
+                            int split3 = 0);
 
 // For each range r: v = mean_{t in [start[r], end[r]]} LN(h[t]) * lnw   (inclusive token range; lnw == nullptr:
 // no LayerNorm, v = mean of h -- post-LN encoders)

@@ -96,16 +96,27 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
 }
 
 // `of` may alias `h` (in place): a row is fully in registers before anything is written.
+// gelu_first: h holds a raw dense output and the activation is applied here (split-operand heads accumulate their three
+// partial GEMMs before the non-linearity).  split3: ob is a [rows, 3H] operand image  [hi | lo | hi]  of the normalised row
+// (hi = T(x), lo = T(x - hi)) -- the A operand of a K = 3H GEMM against a [Whi | Whi | Wlo] weight, i.e. the three
+// significant products of (hi + lo) . (Whi + Wlo) summed in ONE fp32 accumulation (SPLADE decoder, capi.hip run_splade).
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const float* __restrict__ w,
                                                          float eps, int H, int rows, bf16_t* __restrict__ ob,
                                                          float* of, const float* __restrict__ bias,
-                                                         float* __restrict__ row_mean, bf16_t* __restrict__ ob_lo) {
+                                                         float* __restrict__ row_mean, bf16_t* __restrict__ ob_lo,
+                                                         int gelu_first, int split3) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 x[MAXV], wv[MAXV];
   load_row(h + (size_t)row * H, H, lane, x);
+  if (gelu_first) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[i][j] = gelu_erf(x[i][j]);
+  }
   if (w) {
     load_row(w, H, lane, wv);
   } else {   // gain already folded into the consumer's weight
@@ -115,6 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const fl
   float mean = 0.f;
   ln_row(x, wv, H, lane, eps, bias, &mean);
   if (row_mean && lane == 0) row_mean[row] = mean;
+  const size_t ld = split3 ? (size_t)3 * H : (size_t)H;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane * 4 + 256 * i;
@@ -127,8 +139,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* h, const fl
           o[j] = Op<T>::to(x[i][j]);
           lo[j] = Op<T>::to(x[i][j] - (float)o[j]);   // remainder: x = o + lo to twice the operand precision
         }
-        *reinterpret_cast<typename Op<T>::v4*>(ob + (size_t)row * H + c) = o;
-        if (ob_lo) *reinterpret_cast<typename Op<T>::v4*>(ob_lo + (size_t)row * H + c) = lo;
+        *reinterpret_cast<typename Op<T>::v4*>(ob + (size_t)row * ld + c) = o;
+        if (split3) {
+          *reinterpret_cast<typename Op<T>::v4*>(ob + (size_t)row * ld + H + c) = lo;
+          *reinterpret_cast<typename Op<T>::v4*>(ob + (size_t)row * ld + 2 * H + c) = o;
+        } else if (ob_lo) {
+          *reinterpret_cast<typename Op<T>::v4*>(ob_lo + (size_t)row * H + c) = lo;
+        }
       }
     }
   }
@@ -297,13 +314,16 @@ hipError_t launch_embed_ln(const int* ids, const float* E, const float* w, float
 }
 
 hipError_t launch_layernorm(const float* h, const float* w, float eps, int H, int rows, bf16_t* ob, float* of,
-                            hipStream_t stream, const float* bias, float* row_mean, int op_dtype, bf16_t* ob_lo) {
+                            hipStream_t stream, const float* bias, float* row_mean, int op_dtype, bf16_t* ob_lo, int gelu_first,
+                            int split3) {
   if (rows <= 0) return hipSuccess;
-  if (H > MAXV * 256 || (H & 3)) return hipErrorInvalidValue;
+  if (H > MAXV * 256 || (H & 3) || (split3 && (!ob || ob_lo))) return hipErrorInvalidValue;
   if (op_dtype == kOpF16)
-    hipLaunchKernelGGL(layernorm_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean, ob_lo);
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean, ob_lo,
+                       gelu_first, split3);
   else
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean, ob_lo);
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, h, w, eps, H, rows, ob, of, bias, row_mean, ob_lo,
+                       gelu_first, split3);
   return hipGetLastError();
 }
 

@@ -27,29 +27,12 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_bf16.h"
 
 namespace vrag {
 void set_error(const char* fmt, ...);
 
-typedef unsigned long long u64;
-
-__device__ __forceinline__ unsigned orderable(float s) {
-  const unsigned b = __builtin_bit_cast(unsigned, s);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__host__ __device__ inline float unorderable(unsigned k) {
-  const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  float f;
-#if defined(__HIP_DEVICE_COMPILE__)
-  f = __builtin_bit_cast(float, b);
-#else
-  memcpy(&f, &b, 4);
-#endif
-  return f;
-}
-__device__ __forceinline__ u64 make_key(float s, unsigned row) {
-  return ((u64)orderable(s) << 32) | (u64)(0xFFFFFFFFu - row);
-}
+// u64 / orderable / unorderable / make_key: common.h (the tiled batched search builds the same keys in a GEMM epilogue)
 
 // Paged search (k > KMAX): page p+1 only admits keys strictly below the last key of page p; keys are unique per
 // (score, row), so the pages are disjoint and their concatenation is the exact top-(pages * KMAX).
@@ -1075,6 +1058,132 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
   return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------ dense, tiled batched search
+// Q >= 64 queries over bf16 rows (SURVEY 8d "Dense top-k, Q-query batch": MFMA-bound once the batch is large, the shard's
+// bytes read ONCE per batch): the scores are a GEMM  rows [N, dim] x queries [Q, dim]^T  on the encoder's own kernel
+// (csrc/gemm_bf16.hip, 256 x 256 tiles) with the EPI_TOPK epilogue -- nothing is stored but the (score, row) keys above each
+// query's entry threshold, appended to a per-query candidate buffer.  The passes of 32 queries above re-stream the shard
+// Q / 32 times (256 queries over 1.25 M x 768 rows: 8 passes; 10 240 queries: 320).
+// The shard is walked in stages of geometrically growing row ranges [0, 256), [256, 4096), [4096, 65536), ...: after each stage
+// one workgroup per query sorts that query's candidates, keeps the best k and publishes the k-th key as the next stage's
+// threshold.  With rows in random order a stage that multiplies the rows seen by 16 admits ~15 k candidates per query
+// (k ln 16 if the threshold moved inside the stage; it does not); the buffer holds 2048.  A query whose buffer overflows
+// (rows sorted by similarity to it) is flagged and re-answered by dense_tiled_rescue_kernel, which walks the shard for that
+// query alone -- exactness never depends on the order of the rows.
+constexpr int TCAP = 2048;        // candidate slots per query and stage
+constexpr int TSTAGE0 = 256;      // rows of the first stage (every row is a candidate: one key per row, no counters)
+constexpr int TRATIO = 16;        // growth of the rows seen per stage
+
+// fp32 queries -> the GEMM's W operand [n_cols_pad, dim] bf16.  pairs: rows (2q, 2q + 1) = (bf16(q), bf16(q - bf16(q)));
+// rows beyond the queries are zero.
+__global__ void tiled_queries_kernel(const float* __restrict__ q, int nq, int dim, int pairs, int n_cols_pad, bf16_t* __restrict__ w) {
+  const int r = blockIdx.x;
+  if (r >= n_cols_pad) return;
+  const int qi = pairs ? r >> 1 : r;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float v = qi < nq ? q[(size_t)qi * dim + c] : 0.f;
+    if (pairs && (r & 1)) v -= (float)(bf16_t)v;
+    w[(size_t)r * dim + c] = (bf16_t)v;
+  }
+}
+
+// One workgroup per query: the candidates of the stage just finished (cnt[q] keys, the first `carry` of them the best k of
+// the earlier stages) -> sorted, best k kept in place, k-th key published as the next entry threshold; last stage: the
+// list goes to out[q][0..k).  A counter beyond the capacity marks the query for the rescue pass.
+__global__ __launch_bounds__(256) void tiled_select_kernel(u64* __restrict__ buf, unsigned* __restrict__ cnt, int cap, int k,
+                                                            u64* __restrict__ thr_key, float* __restrict__ thr_score,
+                                                            u64* __restrict__ out, unsigned* __restrict__ ovf, int direct_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* sk = reinterpret_cast<u64*>(smem);
+  const int q = blockIdx.x, tid = threadIdx.x;
+  u64* mine = buf + (size_t)q * cap;
+  const unsigned raw = direct_n > 0 ? (unsigned)direct_n : cnt[q];
+  if (raw > (unsigned)cap && tid == 0) ovf[q] = 1u;
+  const int n = (int)min(raw, (unsigned)cap);
+  int P = 2;
+  while (P < n) P <<= 1;
+  for (int i = tid; i < P; i += 256) sk[i] = i < n ? mine[i] : 0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (P >> 1); i += 256) {
+        const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const u64 a = sk[lo], b = sk[hi];
+        if ((a < b) == desc) {
+          sk[lo] = b;
+          sk[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < k; i += 256) {
+    const u64 v = i < P ? sk[i] : 0ull;
+    mine[i] = v;
+    if (out) out[(size_t)q * k + i] = v;
+  }
+  if (tid == 0) {
+    const bool full = n >= k;
+    cnt[q] = (unsigned)min(n, k);
+    thr_key[q] = full ? sk[k - 1] : 0ull;
+    thr_score[q] = full ? unorderable((unsigned)(sk[k - 1] >> 32)) : -INFINITY;
+  }
+}
+
+// Queries whose candidate buffer overflowed: one workgroup per query walks the whole shard (16 rows in flight, one per
+// 16-lane group, fp32 query in LDS) and rewrites out[q].  Launched with one workgroup per query after every tiled search;
+// all of them leave at once unless a flag is set.
+__global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
+                                                                  const float* __restrict__ queries, int k,
+                                                                  const unsigned* __restrict__ ovf, u64* __restrict__ out) {
+  const int q = blockIdx.x;
+  if (!ovf[q]) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);
+  u64* lists = reinterpret_cast<u64*>(smem + (size_t)dim * sizeof(float));   // [16 groups][k]
+  const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
+  for (int i = tid; i < dim; i += 256) sq[i] = queries[(size_t)q * dim + i];
+  for (int i = tid; i < 16 * k; i += 256) lists[i] = 0ull;
+  __syncthreads();
+  u64* mylist = lists + (size_t)grp * k;
+  for (long long r = grp; r < n_rows; r += 16) {
+    const bf16_t* row = rows + (size_t)r * dim;
+    float acc = 0.f;
+    for (int c = gl * 8; c < dim; c += 128) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf((float)v[j], sq[c + j], acc);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (gl == 0) insert_key(mylist, k, make_key(acc, (unsigned)r));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int head[16];
+    for (int g = 0; g < 16; ++g) head[g] = 0;
+    for (int i = 0; i < k; ++i) {
+      u64 best = 0ull;
+      int bg = -1;
+      for (int g = 0; g < 16; ++g)
+        if (head[g] < k) {
+          const u64 v = lists[(size_t)g * k + head[g]];
+          if (v > best) {
+            best = v;
+            bg = g;
+          }
+        }
+      out[(size_t)q * k + i] = best;
+      if (bg >= 0) ++head[bg];
+    }
+  }
+}
+
+static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size) {
+  static const bool off = getenv("VRAG_TOPK_NO_TILED") != nullptr;   // A/B against the 32-query passes
+  return !off && dtype == 0 && dim % 64 == 0 && nq >= 64 && k <= KMAX && size >= 4096;
+}
+
 // ------------------------------------------------------------------------------------ sparse
 template <bool LDSQ>
 __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short* __restrict__ cols,
@@ -1481,6 +1590,12 @@ struct vrag_dense_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;   // d_bound: per-query page bound (k > KMAX)
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
+  // tiled batched search (nq >= 64 over bf16 rows): W operand of the score GEMM, candidate buffers, thresholds, flags
+  bf16_t* d_tw = nullptr;
+  u64 *d_tbuf = nullptr, *d_tthr = nullptr;
+  float* d_tthrs = nullptr;
+  unsigned* d_tcnt = nullptr;   // [nq] counters followed by [nq] overflow flags
+  size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0;
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
   hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
@@ -1572,6 +1687,72 @@ int paged_search(int nq, int k, u64** d_bound, size_t* d_bound_elems, const u64*
   return VRAG_OK;
 }
 
+__global__ void tiled_init_kernel(int nq, u64* __restrict__ thr_key, float* __restrict__ thr_score, unsigned* __restrict__ cnt_ovf) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  thr_key[q] = 0ull;
+  thr_score[q] = -INFINITY;
+  cnt_ovf[q] = 0u;
+  cnt_ovf[nq + q] = 0u;
+}
+
+// The tiled batched search on the resident queries (ix->d_q, fp32): leaves the [nq, k] keys in ix->d_out.  Kernels only.
+int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st) {
+  const int dim = ix->dim, pairs = ix->resident_split;
+  const int n_cols = pairs ? 2 * nq : nq;
+  const int n_pad = (n_cols + 255) / 256 * 256;
+  int rc;
+  if ((rc = grow(&ix->d_tw, &ix->d_tw_elems, (size_t)n_pad * dim))) return rc;
+  if ((rc = grow(&ix->d_tbuf, &ix->d_tbuf_elems, (size_t)nq * TCAP))) return rc;
+  if ((rc = grow(&ix->d_tthr, &ix->d_tthr_elems, (size_t)nq))) return rc;
+  if ((rc = grow(&ix->d_tthrs, &ix->d_tthrs_elems, (size_t)nq))) return rc;
+  if ((rc = grow(&ix->d_tcnt, &ix->d_tcnt_elems, (size_t)2 * nq))) return rc;
+  unsigned* ovf = ix->d_tcnt + nq;
+  hipLaunchKernelGGL(tiled_queries_kernel, dim3(n_pad), dim3(256), 0, st, ix->d_q, nq, dim, pairs, n_pad, ix->d_tw);
+  hipLaunchKernelGGL(tiled_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nq, ix->d_tthr, ix->d_tthrs, ix->d_tcnt);
+  HIP_TRY(hipGetLastError());
+  // stage 0 writes slot = row: a NaN score leaves its slot untouched, so the slots start as "no key"
+  HIP_TRY(hipMemset2DAsync(ix->d_tbuf, (size_t)TCAP * sizeof(u64), 0, (size_t)TSTAGE0 * sizeof(u64), (size_t)nq, st));
+  const long long n = (long long)ix->size;
+  static bool attr = false;
+  if (!attr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiled_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TCAP * (int)sizeof(u64)));
+    attr = true;
+  }
+  long long lo = 0, hi = std::min<long long>(n, TSTAGE0);
+  for (int stage = 0; lo < n; ++stage) {
+    GemmParams g{};
+    g.op_dtype = kOpBf16;
+    g.A = reinterpret_cast<const bf16_t*>(ix->rows) + (size_t)lo * dim;
+    g.W = ix->d_tw;
+    g.M = (int)(hi - lo);
+    g.N = n_pad;
+    g.K = dim;
+    g.topk_thr_score = ix->d_tthrs;
+    g.topk_thr_key = ix->d_tthr;
+    g.topk_cnt = ix->d_tcnt;
+    g.topk_buf = ix->d_tbuf;
+    g.topk_cap = TCAP;
+    g.topk_nq = nq;
+    g.topk_pairs = pairs;
+    g.topk_direct = stage == 0;
+    g.topk_row_base = (unsigned)lo;
+    HIP_TRY(launch_gemm(EPI_TOPK, g, st));
+    const bool last = hi >= n;
+    hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
+                       ix->d_tthr, ix->d_tthrs, last ? ix->d_out : (u64*)nullptr, ovf, stage == 0 ? (int)(hi - lo) : 0);
+    HIP_TRY(hipGetLastError());
+    lo = hi;
+    hi = std::min<long long>(n, hi * TRATIO);
+  }
+  const size_t lds = (size_t)dim * sizeof(float) + (size_t)16 * k * sizeof(u64);
+  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(ix->rows), n, dim,
+                     ix->d_q, k, ovf, ix->d_out);
+  HIP_TRY(hipGetLastError());
+  return VRAG_OK;
+}
+
 // One device pass (k <= KMAX) of a dense search: uploads the queries, runs phase 1 + the per-query merge and leaves the
 // [nq, k] keys in ix->d_out.  Returns once the query upload has been consumed (the caller's buffer may be reused); the
 // kernels are only enqueued.  Caller holds ix->mu and has set the device.
@@ -1604,6 +1785,8 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   HIP_TRY(hipEventSynchronize(ix->upload_done));
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
+  } else if (dense_use_tiled(ix->dtype, ix->dim, nq, k, (long long)ix->size)) {
+    if ((rc = dense_tiled_search(ix, nq, k, st))) return rc;
   } else {
     HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
                              ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
@@ -1634,7 +1817,8 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
   ix->device = device;
   ix->capacity = capacity;
   const size_t esz = dtype == 0 ? 2 : 4;
-  hipError_t e = hipMalloc(&ix->rows, (size_t)capacity * dim * esz);
+  // + two 256-row tiles: the tiled batched search reads whole GEMM tiles behind the last row (results of rows >= size are dropped)
+  hipError_t e = hipMalloc(&ix->rows, ((size_t)capacity + 512) * dim * esz);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
   ix->stage_rows = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)dim * 4));
   if (e == hipSuccess) {
@@ -1661,6 +1845,8 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
+  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt})
+    if (p) (void)hipFree(p);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -1766,6 +1952,10 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   ARG_CHECK(ix->d_q && ix->d_q_elems >= (size_t)nq * ix->dim && ix->size > 0, "call vrag_dense_index_search once first");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
+  if (dense_use_tiled(ix->dtype, ix->dim, nq, k, (long long)ix->size)) {
+    ARG_CHECK(ix->d_out_elems >= (size_t)nq * k, "scratch too small");
+    return dense_tiled_search(ix, nq, k, st);
+  }
   const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
   ARG_CHECK(ix->d_cand_elems >= (size_t)n_wg * nq * k && ix->d_out_elems >= (size_t)nq * k + nq, "scratch too small");
   HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,

@@ -12,6 +12,7 @@ The reference has no distributed code at all; this is new, not a tr
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -81,6 +82,50 @@ class ShardComm:
         self.backend = dist.get_backend(group)
         self.device = device
         self._merge = merge
+        self._vcomm = None          # vrag_comm handle: the library's own RCCL communicator (include/vrag_amd.h)
+        if self.backend == "nccl" and merge is None and os.environ.get("VRAG_COMM", "") != "torch":
+            self._vcomm = self._create_library_comm(dist, group)
+
+    def _create_library_comm(self, dist, group):
+        """The exchange runs behind the C ABI (`vrag_topk_allgather_merge`: ncclAllGather + merge on one stream); torch's
+        process group only carries the 128-byte unique id from the group's rank 0 to the others."""
+        import torch
+
+        from . import _lib
+
+        lib = _lib.load()
+        dev = torch.device("cuda", self.device)
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check("vrag_comm_get_unique_id", lib.vrag_comm_get_unique_id(buf))
+            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(ident, src=src, group=group)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        h = C.c_void_p()
+        _lib.check("vrag_comm_create", lib.vrag_comm_create(raw, self.rank, self.world, self.device, C.byref(h)))
+        return h
+
+    @property
+    def exchange_backend(self) -> str:
+        """Who runs the data-path collective: "vrag_comm" (RCCL behind the C ABI), "torch.distributed" or "host"."""
+        if self._vcomm is not None:
+            return "vrag_comm"
+        return "torch.distributed" if self.on_gpu else "host"
+
+    def close(self) -> None:
+        if getattr(self, "_vcomm", None) is not None:
+            from . import _lib
+
+            _lib.load().vrag_comm_destroy(self._vcomm)
+            self._vcomm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def on_gpu(self) -> bool:
@@ -139,11 +184,16 @@ class ShardComm:
         n = Q * kk
         nbytes = self.payload_bytes(n)
         flat = torch.empty(self.world * nbytes, dtype=torch.uint8, device=payload.device)
-        dist.all_gather_into_tensor(flat, payload, group=self.group)    # THE collective of the retrieval path
         d_out_s = torch.empty((Q, k), dtype=torch.float32, device=payload.device)
         d_out_i = torch.empty((Q, k), dtype=torch.int64, device=payload.device)
         base = flat.data_ptr()
         stream = torch.cuda.current_stream(payload.device).cuda_stream
+        if self._vcomm is not None:      # THE collective of the retrieval path, behind the C ABI: ncclAllGather + merge on `stream`
+            _lib.check("vrag_topk_allgather_merge", lib.vrag_topk_allgather_merge(
+                self._vcomm, C.c_void_p(payload.data_ptr()), C.c_void_p(base), Q, kk, k, C.c_void_p(d_out_s.data_ptr()),
+                C.c_void_p(d_out_i.data_ptr()), C.c_void_p(stream)))
+            return d_out_s.cpu().numpy(), d_out_i.cpu().numpy()
+        dist.all_gather_into_tensor(flat, payload, group=self.group)    # VRAG_COMM=torch: the same exchange on torch's communicator
         _lib.check("vrag_topk_merge", lib.vrag_topk_merge(
             C.c_void_p(base + n * 8), C.c_void_p(base), self.world, Q, kk, k, nbytes, nbytes,
             C.c_void_p(d_out_s.data_ptr()), C.c_void_p(d_out_i.data_ptr()), 1, self.device, C.c_void_p(stream)))

@@ -207,7 +207,14 @@ class EncoderEngine:
                    self._lib.vrag_encoder_set_token_head(self._h, _fp(d), _fp(n), _fp(w), _fp(b), w.shape[0]))
         self.token_labels = int(w.shape[0])
 
-    def set_mlm_head(self, dense_w, norm_w, decoder_b, decoder_w=None) -> None:
+    def _set_head_precision(self, split_operands: bool) -> None:
+        _lib.check("vrag_encoder_set_head_precision",
+                   self._lib.vrag_encoder_set_head_precision(self._h, 1 if split_operands else 0))
+
+    def set_mlm_head(self, dense_w, norm_w, decoder_b, decoder_w=None, split_operands: bool = True) -> None:
+        """`split_operands` (default): both head GEMMs carry (value, remainder) operand pairs, SPLADE weights within 2e-3 of
+        the fp32 reference; False = plain 16-bit operands, 3x less decoder work, weights within ~1e-2."""
+        self._set_head_precision(split_operands)
         d, n = _f32(dense_w), _f32(norm_w)
         b = _f32(decoder_b) if decoder_b is not None else None
         dw = _f32(decoder_w) if decoder_w is not None else None
@@ -447,7 +454,8 @@ class BertEncoderEngine(EncoderEngine):
             self.set_mlm_head_ex(weights["mlm.dense.w"], weights["mlm.dense.b"], weights["mlm.ln.w"], weights["mlm.ln.b"],
                                  weights.get("mlm.dec.b"), weights.get("mlm.dec.w"))
 
-    def set_mlm_head_ex(self, dense_w, dense_b, norm_w, norm_b, decoder_b, decoder_w=None) -> None:
+    def set_mlm_head_ex(self, dense_w, dense_b, norm_w, norm_b, decoder_b, decoder_w=None, split_operands: bool = True) -> None:
+        self._set_head_precision(split_operands)
         opt = lambda a: _f32(a) if a is not None else None  # noqa: E731
         d, db, n, nb, b, dw = _f32(dense_w), opt(dense_b), _f32(norm_w), opt(norm_b), opt(decoder_b), opt(decoder_w)
         p = lambda a: _fp(a) if a is not None else None  # noqa: E731

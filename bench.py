@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -229,7 +230,7 @@ def power_limited_rate(shape, rows: int, device: int, value: float):
         from verbatim_rag_amd import _lib as L
 
         ms = C.c_float()
-        L.check("gemm", L.load().vrag_debug_gemm_ms(7, rows, 3 * shape.hidden_size, shape.hidden_size, 60, device, C.byref(ms)))
+        L.check_debug("gemm", L.load_debug().vrag_debug_gemm_ms(7, rows, 3 * shape.hidden_size, shape.hidden_size, 60, device, C.byref(ms)))
         plateau = 2.0 * rows * 3 * shape.hidden_size * shape.hidden_size / (ms.value * 1e-3) / 1e12
         return {"power_limited_mainloop_tflops": plateau, "model_frac_of_power_limited_rate": value * chunk_flops(shape) / 1e12 / plateau}
     except Exception as exc:
@@ -258,6 +259,23 @@ def api_leg(eng, shape, n_chunks: int, steps: int):
             chunks.append(" ".join(s.capitalize() for s in sents))
         ext = GpuModelSpanExtractor(engine=eng, tokenizer=tok, threshold=0.5)
         results = [types.SimpleNamespace(text=c) for c in chunks]
+        # the synthetic chunks run a few tokens over the 512-token budget: the packer drops their last sentence and says so
+        # per chunk and call (the reference's own warning text) -- thousands of lines that pushed the JSON line out of a
+        # `tail`; here the warning is counted instead and reported in the leg
+        import logging
+
+        class _Count(logging.Filter):
+            n = 0
+
+            def filter(self, record):
+                if "token budget" in record.getMessage():
+                    _Count.n += 1
+                    return False
+                return True
+
+        xlog = logging.getLogger("verbatim_rag_amd.extractors")
+        filt = _Count()
+        xlog.addFilter(filt)
         all_sents, samples = ext.pack_qa(question, chunks[:8])
         tokens = float(np.mean([len(smp.input_ids) for smp in samples if smp is not None]))
         out = ext.extract_spans_batch([question], [results])      # warm-up: fills the chunk cache (ingest-time work)
@@ -265,7 +283,9 @@ def api_leg(eng, shape, n_chunks: int, steps: int):
         for _ in range(steps):
             out = ext.extract_spans_batch([question], [results])
         dt = (time.perf_counter() - t0) / steps
+        xlog.removeFilter(filt)
         return {"api_chunks_per_s": n_chunks / dt, "ms_per_call": dt * 1e3, "chunks_per_call": n_chunks, "mean_tokens_per_pair": tokens,
+                "budget_warnings_suppressed": _Count.n,
                 "spans_returned": int(sum(len(v) for v in out[0].values())),
                 "what": "extract_spans_batch(1 question, 256 results): question tokenisation, ids from the chunk cache, H2D, "
                         "encoder + sentence head, read-back, threshold select"}
@@ -309,14 +329,28 @@ def token_head_f16_leg(shape, weights, seqs, micro_batch_tokens: int, device: in
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def ragged_lengths(rows_per_micro_batch: int, n_micro_batches: int, seed: int = 4242, lo: int = 64, hi: int = SEQ, mean: float = 200.0) -> np.ndarray:
+def ragged_lengths(rows_per_micro_batch: int, n_micro_batches: int, seed: int = 4242, lo: int = 64, hi: int = SEQ, mean: float = 200.0,
+                   aligned: bool = False) -> np.ndarray:
     """Seeded pair lengths in [lo, hi] with mean ~`mean` (what the reference's 512-CHARACTER chunker produces once the question
     is prepended: verbatim_rag/chunker_providers.py:531-572 cuts ~100-150-token windows; longer ones come from the markdown
-    chunkers) -- a shifted, clipped gamma.  The batch is formed the way a serving batcher fills the engine: pairs are drawn until
-    a micro-batch's packed rows (tokens + the 8-row alignment gap after every pair) are full, the last pair of a micro-batch
-    taking exactly the rows that are left -- so every micro-batch is a whole number of GEMM tile rounds, like the headline batch."""
+    chunkers) -- a shifted, clipped gamma.
+    aligned=False (the reported figure): ANY length, drawn until the batch's packed rows (tokens + the 8-row alignment gap a
+    pair of unaligned length leaves) would pass the budget of the headline batch -- the engine's equal-size micro-batch cuts and
+    tile-round remainders are whatever they come out as, like a real chunker's output.
+    aligned=True (best case, reported beside it): lengths are multiples of 8 (no alignment gaps) and the last pair of every
+    micro-batch takes exactly the rows that are left, so every micro-batch is a whole number of GEMM tile rounds."""
     rng = np.random.default_rng(seed)
     out = []
+    if not aligned:
+        budget, rows = rows_per_micro_batch * n_micro_batches, 0
+        while True:
+            n = int(np.clip(lo + rng.gamma(2.0, (mean - lo) / 2.0), lo, hi))
+            packed = (n + 7) // 8 * 8
+            if rows + packed > budget:
+                break
+            out.append(n)
+            rows += packed
+        return np.asarray(out, np.int32)
     for _ in range(n_micro_batches):
         rows = 0
         while True:
@@ -351,7 +385,8 @@ def synth_ragged_batch(shape, lens, seed: int):
     return seqs, bounds
 
 
-def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int, device: int, steps: int, headline_tokens_per_s: float):
+def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int, device: int, steps: int, headline_tokens_per_s: float,
+               aligned: bool = False):
     """The headline step on the pair lengths real chunkers produce: the same packed rows per step (131 072,
     two full micro-batches) as pairs of 64-512 tokens, mean ~200, inputs resident, encoder + sentence head.  Reported beside the
     headline as chunks/s and as tokens/s (real tokens, alignment gaps not counted) relative to the 512-token batch.  Never raises."""
@@ -361,7 +396,7 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
         from verbatim_rag_amd.engine import EncoderEngine
 
         mbt = micro_batch_tokens or tokens
-        lens = ragged_lengths(mbt, max(1, tokens // mbt))
+        lens = ragged_lengths(mbt, max(1, tokens // mbt), aligned=aligned)
         seqs, bounds = synth_ragged_batch(shape, lens, seed=77)
         n_rng = sum(len(b) for b in bounds)
         eng = EncoderEngine(shape, weights, max_tokens=int(lens.sum()) + 8 * len(lens), max_seqs=len(lens), max_seq_len=SEQ,
@@ -398,7 +433,9 @@ def ragged_leg(shape, weights, qa_w, qa_b, tokens: int, micro_batch_tokens: int,
                 "length_min_mean_max": [int(lens.min()), float(lens.mean()), int(lens.max())], "tokens_per_s": tps,
                 "tokens_per_s_vs_512_token_batch": tps / headline_tokens_per_s, "single_stream_pass_by_class": iso,
                 "order": "as drawn (the engine packs the sequences of a micro-batch into the fused kernel's 8-slot groups itself, best fit decreasing)",
-                "what": "encoder + sentence head over pairs of 64-512 tokens (seeded, mean ~200) filling the same two 65 536-row micro-batches as the headline (8-row alignment gaps between pairs are rows, not tokens), resident inputs"}
+                "lengths": "multiples of 8, every micro-batch filled to a whole number of tile rounds (best case)" if aligned else
+                           "unconstrained (alignment gaps and tile-round remainders as they fall)",
+                "what": "encoder + sentence head over pairs of 64-512 tokens (seeded, mean ~200) within the packed-row budget of the headline batch (8-row alignment gaps between pairs are rows, not tokens), resident inputs"}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -413,47 +450,79 @@ def _grid_rows(n: int, dim: int, seed: int) -> np.ndarray:
     return out
 
 
-def sharded_retrieval_leg(rank: int, world: int, device: int, rows_per_rank: int = 1_250_000, dim: int = 768, nq: int = 64,
-                          k: int = 10, reps: int = 5):
-    """The exchange step of the path on N > 1 ranks at BASELINE configs[3]'s per-GPU size (10^7 x 768 rows over 8 GPUs =
-    1.25 * 10^6 per rank; north_star: "RCCL all-gather of per-shard top-k for the final merge"): every rank searches its
-    own fp32 row shard on its GPU, the `[Q, k]` lists stay in HBM (`vrag_dense_index_search_device`), ONE
-    all_gather_into_tensor carries them, `vrag_topk_merge` merges them on every GPU.  Outside the timed region of the
-    headline metric; returns a small report on rank 0 (never raises)."""
-    try:
-        import torch.distributed as dist
+def sharded_retrieval_leg(rank: int, world: int, device: int, backend: str, rows_per_rank: int = 1_250_000, dim: int = 768,
+                          nq: int = 1024, k: int = 10, reps: int = 5):
+    """Second TIMED leg of an N > 1 run: the exchange step of the path at BASELINE configs[3]'s per-GPU size (10^7 x 768 bf16
+    rows over 8 GPUs = 1.25 * 10^6 per rank; north_star: "RCCL all-gather of per-shard top-k for the final merge").  Every
+    rank holds its own row shard (generated ON its GPU: dyadic-grid rows from a seeded device generator, handed to the index
+    with vrag_dense_index_add_device -- no host RNG, no upload), answers the replicated batch of `nq` queries on it (tiled
+    batched search, lists left in HBM by vrag_dense_index_search_device), ONE all-gather carries the `[nq, k]` lists
+    (vrag_topk_allgather_merge: ncclAllGather + merge behind the C ABI on RCCL groups), every GPU merges.  Timed like the
+    headline: barrier + synchronize on both sides, `reps` exchanges, MAX over ranks.  Returns a report on every rank (rank 0
+    prints it); a failure is reported on stderr AND in the line, never as a crash."""
+    import torch
+    import torch.distributed as dist
 
+    report = {"rows_per_rank": None}
+    try:
         from verbatim_rag_amd.distributed import ShardedTopK, merge_topk
         from verbatim_rag_amd.vector_stores import DenseShard
 
         rows_per_rank = int(os.environ.get("VRAG_BENCH_SHARD_ROWS", rows_per_rank))
-        X = _grid_rows(rows_per_rank, dim, 77 + rank)
-        Q = _grid_rows(nq, dim, 5)
-        shard = DenseShard(dim, rows_per_rank, "f32", device)
-        shard.add(X)
-        del X
+        dev = torch.device("cuda", device)
+        shard = DenseShard(dim, rows_per_rank, "bf16", device)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(7700 + rank)
+        t_gen = time.perf_counter()
+        for a in range(0, rows_per_rank, 131072):       # 131 072-row slabs: 400 MB of fp32 staging at a time
+            b = min(rows_per_rank, a + 131072)
+            slab = torch.randint(-64, 65, (b - a, dim), generator=gen, device=dev, dtype=torch.int32).to(torch.float32) / 64.0
+            shard.add_device(slab.data_ptr(), b - a, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            del slab
+        t_gen = time.perf_counter() - t_gen
+        Q = _grid_rows(nq, dim, 5)                                                               # replicated queries: same on every rank
         topk = ShardedTopK(shard.search, shard_base=rank * rows_per_rank, device=device, shard=shard)
         s, i = topk.search(Q, k)                                                                 # warm-up + the checked result
+        torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
             topk.search(Q, k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
         dist.barrier()
-        dt = (time.perf_counter() - t0) / reps
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item()) / reps
         ls, li = shard.search(Q, k)                                                              # the host-side statement of the same lists
         gathered = [None] * world
         dist.all_gather_object(gathered, (ls, np.where(li >= 0, li + rank * rows_per_rank, -1)))
+        comm = topk._comm
         shard.close()
-        if rank != 0:
-            return None
         hs, hi = merge_topk(np.stack([g[0] for g in gathered]), np.stack([g[1] for g in gathered]).astype(np.int64), k)
-        return {"rows_total": rows_per_rank * world, "rows_per_rank": rows_per_rank, "dim": dim, "rows_dtype": "f32", "queries": nq, "k": k,
-                "queries_per_s": nq / dt, "ms_per_batch": dt * 1e3,
-                "collective": f"one all_gather_into_tensor of {nq * k * 12} B per rank ({dist.get_backend()}), merge on every GPU",
-                "lists_device_resident": bool(topk._comm is not None and topk._comm.on_gpu),
-                "merged_equals_host_merge_of_shard_lists": bool(np.array_equal(hi, i) and np.array_equal(hs, s))}
+        report = {"sharded_queries_per_s": nq / dt, "ms_per_batch": dt * 1e3, "rows_total": rows_per_rank * world,
+                  "rows_per_rank": rows_per_rank, "dim": dim, "rows_dtype": "bf16", "queries": nq, "k": k, "reps": reps,
+                  "shard_generated_on_gpu_s": t_gen,
+                  "collective": f"one all-gather of {nq * k * 12} B per rank, merge on every GPU",
+                  "exchange_backend": comm.exchange_backend if comm is not None else None,
+                  "process_group_backend": dist.get_backend(), "world_size_reported_by_backend": int(dist.get_world_size()),
+                  "lists_device_resident": bool(comm is not None and comm.on_gpu),
+                  "merged_equals_host_merge_of_shard_lists": bool(np.array_equal(hi, i) and np.array_equal(hs, s))}
     except Exception as exc:
-        return {"error": f"{type(exc).__name__}: {exc}"}
+        import traceback
+
+        print(f"bench.py: sharded retrieval leg FAILED on rank {rank}: {type(exc).__name__}: {exc}\n{traceback.format_exc()}",
+              file=sys.stderr, flush=True)
+        report = {"error": f"rank {rank}: {type(exc).__name__}: {exc}"}
+    try:   # one rank's failure must show in rank 0's line
+        every = [None] * world
+        dist.all_gather_object(every, report.get("error"))
+        errs = [e for e in every if e]
+        if errs:
+            report["error"] = "; ".join(errs)
+    except Exception:
+        pass
+    return report
 
 
 def main() -> None:
@@ -579,7 +648,7 @@ def main() -> None:
         iso = eng.read_profile(reset=True)
         eng.set_concurrency(2)
 
-    sharded = sharded_retrieval_leg(rank, world, local_rank) if world > 1 else None
+    sharded = sharded_retrieval_leg(rank, world, local_rank, backend) if world > 1 else None
 
     if rank == 0:
         total_chunks = world * n_chunks * args.steps
@@ -675,6 +744,11 @@ def main() -> None:
             if api and "api_chunks_per_s" in api:
                 api["fraction_of_resident_rate"] = api["api_chunks_per_s"] / value
             ragged = ragged_leg(shape, weights, qa_w, qa_b, n_chunks * SEQ, args.micro_batch_tokens, local_rank, max(3, args.steps), value * SEQ)
+            ragged_best = ragged_leg(shape, weights, qa_w, qa_b, n_chunks * SEQ, args.micro_batch_tokens, local_rank, 3, value * SEQ, aligned=True)
+            if ragged is not None and ragged_best is not None:
+                ragged["aligned_best_case"] = {k: ragged_best.get(k) for k in ("ragged_chunks_per_s", "tokens_per_s_vs_512_token_batch",
+                                                                                  "chunks_per_step", "tokens_per_step", "lengths", "error")
+                                               if k in ragged_best}
             tok16 = token_head_f16_leg(shape, weights, seqs, args.micro_batch_tokens, local_rank, steps=max(3, args.steps))
             recall = topk_recall_check()
             cpu, ref_logits = cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, args.cpu_budget)
@@ -693,14 +767,15 @@ def main() -> None:
             "config": {"workload": ("BASELINE configs[1]: ModernBERT-base span extractor, batch 256 chunks x 512 tok, single query, 16 sentences/chunk" if args.model == "base" else "ModernBERT-large geometry (BASELINE configs[4] extractor), batch 256 chunks x 512 tok, 16 sentences/chunk"),
                        "chunks_per_gpu_per_step": n_chunks, "seq_len": SEQ, "sentences_per_chunk": N_SENT,
                        "micro_batch_tokens": args.micro_batch_tokens, "parallelism": f"dp{world} (independent chunks, no collective)",
-                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), {args.operand_dtype} MFMA operands, fp32 accumulate/residual/LN/softmax"},
+                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), {args.operand_dtype} MFMA operands, fp32 accumulate / LayerNorm / softmax / heads; residual stream between sub-layers as two 16-bit planes (operand copy + fp16 remainder, 19+ significant bits)"},
             "sentence_classifications_per_s": value * N_SENT,
             "model_tflops": value * chunk_flops(shape) / 1e12,
             "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),
             "roofline": roof, "cpu_baseline": cpu, "parity_max_abs_err_vs_oracle": parity, "parity_max_rel_err": parity_rel,
             "parity_max_prob_err": parity_prob, "ragged_chunks_per_s": ragged.get("ragged_chunks_per_s") if ragged else None, "ragged_leg": ragged,
             "per_rank_ms_per_step": per_rank_ms, "world_size_reported_by_backend": backend_world,
-            "topk_recall_vs_cpu_ref": recall, "sharded_topk": sharded,
+            "topk_recall_vs_cpu_ref": recall,
+            "sharded_queries_per_s": sharded.get("sharded_queries_per_s") if sharded else None, "sharded_topk": sharded,
             "api_chunks_per_s": api.get("api_chunks_per_s") if api else None, "api_leg": api, "token_head_f16": tok16,
             "breakdown": breakdown,
         }

@@ -258,25 +258,11 @@ int vrag_encoder_set_concurrency(vrag_encoder* enc, int32_t n_streams);
 /* enabled: 0 = off, 1 = a HIP event pair around every launch, n > 1 = around every n-th launch of each class (the totals
  * vrag_encoder_read_profile returns are then the timed launches' mean x the launches issued). */
 int vrag_encoder_set_profiling(vrag_encoder* enc, int32_t enabled);
-/* Tuning / tests: GEMMs over at most `rows` token rows use the small-batch configuration (128x128 tiles, four LDS
- * stages in flight); 0 disables it.  Process-wide; returns the new threshold (default 8192). */
-int vrag_debug_set_gemm_small_m(int32_t rows);
-
-/* Diagnostics (kernel tuning): average ms of one GEMM instantiation (epilogue id as in
- * csrc/gemm_bf16.h, 7 = no epilogue) on synthetic [-1,1) operands. */
-int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t device, float* ms_out);
-/* Same for one attention launch: n_seqs sequences of S tokens (S a multiple of 8), hidden H = 64 * heads, local != 0 =
- * the banded kernel with |i - j| <= window. */
-int vrag_debug_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t device,
-                       float* ms_out);
-/* Same for the fused Wqkv + RoPE + attention kernel (csrc/qkv_attn.hip; S <= 512).  flags: 1 = no attention phase, 2 = no
- * main-loop MFMAs, 4 = no operand DMA (phase decomposition of the kernel's time). */
-int vrag_debug_qkv_attn_ms(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t iters, int32_t flags,
-                           int32_t device, float* ms_out);
-/* Unit-test hook of the attention kernels alone: host operands in the kernels' layouts (q, k: [T, H] bf16 / fp16 bits, q
- * pre-scaled by head_dim^-1/2 * log2 e; vt: [H, Tp], Tp = T rounded up to 256), o [T, H] out; T = n_seqs * S. */
-int vrag_debug_attn_run(int32_t local, int32_t n_seqs, int32_t S, int32_t H, int32_t window, int32_t f16, const uint16_t* q,
-                        const uint16_t* k, const uint16_t* vt, uint16_t* o, int32_t device);
+/* Launch-bound configuration: GEMMs over at most `rows` token rows (a query's handful of chunks) use 128x128 / 64x64 tiles with
+ * deeper LDS rings and a K split over waves instead of the 256x256 throughput tiles; 0 disables it, a negative value only
+ * reads.  Process-wide; returns the threshold in effect (default 8192).  The two configurations sum fp32 partial products in
+ * different orders, so tests pin one or the other through this call. */
+int vrag_set_small_batch_rows(int32_t rows);
 int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/,
                               int64_t* launches /*[VRAG_PROF_COUNT]*/, int32_t reset);
 
@@ -295,6 +281,9 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
 void vrag_dense_index_destroy(vrag_dense_index* ix);
 int64_t vrag_dense_index_size(vrag_dense_index* ix);
 int vrag_dense_index_add(vrag_dense_index* ix, const float* rows /*[n,dim] host fp32*/, int64_t n);
+/* The same from DEVICE memory (rows: fp32 [n, dim] on the index's device, e.g. vrag_encoder pooled embeddings that never
+ * visited the host): converted / copied on `stream` (NULL = the legacy default stream); returns when the rows are in place. */
+int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows /*[n,dim] device fp32*/, int64_t n, void* stream);
 int vrag_dense_index_search(vrag_dense_index* ix, const float* queries /*[nq,dim] host*/, int32_t nq, int32_t k,
                             float* scores /*[nq,k]*/, int64_t* ids /*[nq,k]*/, void* stream);
 /* Re-runs the kernels of the last search on the device-resident queries (no copies, no sync). */

@@ -110,7 +110,7 @@ def test_base_width_hidden_pool_and_splade_vs_oracle(base_width):
     eng.load_batch([seqs[0]])
     eng.run()
     alone = eng.read_hidden(final_norm=False)
-    assert np.array_equal(alone, got[:512]) or float(np.abs(alone - got[:512]).max()) < 1e-2
+    assert np.array_equal(alone, got[:512]) or float(np.abs(alone - got[:512]).max()) < 4e-3   # observed 2e-3 (r4)
 
 
 def test_providers_on_bert_engine(base_width):

@@ -27,6 +27,22 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_debug_harness_is_a_separate_library():
+    """include/vrag_amd_debug.h is exported by libvrag_amd_dbg.so only: a maintainer binding the product header gets no tuning
+    probes as API, and the product library carries none of their symbols."""
+    src = open(os.path.join(ROOT, "include", "vrag_amd_debug.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vrag_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(_lib.DEBUG_SIGNATURES) and all(n.startswith("vrag_debug_") for n in names)
+    prod = ctypes.CDLL(_lib.library_path())
+    dbg = ctypes.CDLL(_lib.debug_library_path())
+    for n in names:
+        assert not hasattr(prod, n), f"{n} leaked into the product library"
+        assert hasattr(dbg, n)
+    assert not [n for n in _declared() if n.startswith("vrag_debug_")]
+    _lib.load_debug()
+
+
 def test_abi_version_and_error_string():
     lib = _lib.load()
     assert lib.vrag_abi_version() == _lib.ABI_VERSION == 6

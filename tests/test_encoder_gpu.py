@@ -21,9 +21,9 @@ def gemm_config(request):
     from verbatim_rag_amd import _lib
 
     lib = _lib.load()
-    lib.vrag_debug_set_gemm_small_m(8192 if request.param.startswith("small") else 0)
+    lib.vrag_set_small_batch_rows(8192 if request.param.startswith("small") else 0)
     yield
-    lib.vrag_debug_set_gemm_small_m(8192)
+    lib.vrag_set_small_batch_rows(8192)
 
 
 def _engine(cfg, w, **kw):
@@ -319,7 +319,7 @@ def test_graph_cache_keeps_the_two_attention_paths_apart():
     rng = np.random.default_rng(6)
     qa_w, qa_b = rng.standard_normal((2, 128)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
     lib = _lib.load()
-    lib.vrag_debug_set_gemm_small_m(0)
+    lib.vrag_set_small_batch_rows(0)
 
     def engine(graphs):
         e = EncoderEngine(ModernBertShape(**TINY), w, max_tokens=8192, max_seqs=64, max_seq_len=1024, max_ranges=1024)
@@ -340,7 +340,7 @@ def test_graph_cache_keeps_the_two_attention_paths_apart():
                 assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, gi, lens)
         assert graphed.graph_stats()[0] > 0
     finally:
-        lib.vrag_debug_set_gemm_small_m(8192)
+        lib.vrag_set_small_batch_rows(8192)
         eager.close()
         graphed.close()
 

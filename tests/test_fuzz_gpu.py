@@ -29,7 +29,7 @@ def test_random_batches_vs_oracle(seed, dtype, logit_tol):
     mb = int(rng.choice([0, 300, 700, 2000]))
     shape = ModernBertShape(**{k: v for k, v in TINY.items()})
     lib = _lib.load()
-    lib.vrag_debug_set_gemm_small_m(int(rng.choice([0, 8192])))
+    lib.vrag_set_small_batch_rows(int(rng.choice([0, 8192])))
     eng = EncoderEngine(shape, w, max_tokens=6000, max_seqs=40, max_seq_len=512, max_ranges=400, micro_batch_tokens=mb,
                         operand_dtype=dtype)
     try:
@@ -59,4 +59,4 @@ def test_random_batches_vs_oracle(seed, dtype, logit_tol):
                 o += len(s)
     finally:
         eng.close()
-        lib.vrag_debug_set_gemm_small_m(8192)
+        lib.vrag_set_small_batch_rows(8192)

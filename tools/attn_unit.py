@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Attention kernels alone against a float64 softmax on the same bf16 operands (vrag_debug_attn_run): worst error per
 sequence length and mode, and -- for the banded mode -- the mean error by (row mod 32), which is where a masking or
-fragment-mapping slip shows.  VRAG_ATTN_V2=1 selects the second-generation kernel."""
+fragment-mapping slip shows."""
 import ctypes as C
 import os
 import sys
@@ -13,6 +13,8 @@ import verbatim_rag_amd  # noqa
 from verbatim_rag_amd import _lib
 
 lib = _lib.load()
+
+dbg = _lib.load_debug()   # harness library (include/vrag_amd_debug.h)
 
 
 def bf16_bits(x):
@@ -35,7 +37,7 @@ def run(local, n_seqs, S, H=128, W=64, seed=0, sharp=1.0):
     vt = np.zeros((H, Tp), np.uint16)
     vt[:, :T] = v.T
     o = np.zeros((T, H), np.uint16)
-    _lib.check("attn", lib.vrag_debug_attn_run(local, n_seqs, S, H, W, 0, q.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p),
+    _lib.check_debug("attn", dbg.vrag_debug_attn_run(local, n_seqs, S, H, W, 0, q.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p),
                                               vt.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), 0))
     got = from_bits(o).astype(np.float64)
     qf, kf, vf = from_bits(q).astype(np.float64), from_bits(k).astype(np.float64), from_bits(v).astype(np.float64)
@@ -54,7 +56,7 @@ def run(local, n_seqs, S, H=128, W=64, seed=0, sharp=1.0):
 
 
 if __name__ == "__main__":
-    tag = "v2" if os.environ.get("VRAG_ATTN_V2") else "v1"
+    tag = "attention"
     for local in (0, 1):
         for S in (64, 200, 512, 1000):
             for sharp in (1.0, 6.0):

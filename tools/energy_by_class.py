@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--only", default="", help="comma-separated substrings of class names to run")
     args = ap.parse_args()
     lib = _lib.load()
+    dbg = _lib.load_debug()   # harness library (include/vrag_amd_debug.h)
     hw = _hwmon()
     M, H, I, S = args.tokens, 768, 1152, 512
     classes = [   # name, kind, args, algorithmic FLOP per launch
@@ -107,15 +108,15 @@ def main():
             var = "VRAG_DEBUG_GEMM_PLAIN_RESID" if kind == "gemm_plain" else "VRAG_DEBUG_GEMM_SPLIT"
             os.environ[var] = "1"
             try:
-                _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
+                _lib.check_debug("gemm", dbg.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
             finally:
                 del os.environ[var]
         elif kind == "gemm":
-            _lib.check("gemm", lib.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
+            _lib.check_debug("gemm", dbg.vrag_debug_gemm_ms(a[0], a[1], a[2], a[3], iters, 0, C.byref(ms)))
         elif kind == "fused":
-            _lib.check("fused", lib.vrag_debug_qkv_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, 0, C.byref(ms)))
+            _lib.check_debug("fused", dbg.vrag_debug_qkv_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, 0, C.byref(ms)))
         else:
-            _lib.check("attn", lib.vrag_debug_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, C.byref(ms)))
+            _lib.check_debug("attn", dbg.vrag_debug_attn_ms(a[0], a[1], a[2], a[3], a[4], iters, 0, C.byref(ms)))
         return ms.value
 
     for name, kind, a, flop in classes:

@@ -15,15 +15,17 @@ from verbatim_rag_amd import _lib
 
 lib = _lib.load()
 
+dbg = _lib.load_debug()   # harness library (include/vrag_amd_debug.h)
+
 
 def run(name, epi, M, N, K, iters):
     ms = C.c_float()
-    _lib.check("gemm", lib.vrag_debug_gemm_ms(epi, M, N, K, iters, 0, C.byref(ms)))
+    _lib.check_debug("gemm", dbg.vrag_debug_gemm_ms(epi, M, N, K, iters, 0, C.byref(ms)))
     print(f"{name}  M={M} N={N} K={K} x{iters}: {ms.value*1e3:8.1f} us  {2.0*M*N*K/ms.value/1e9:8.1f} TFLOP/s", flush=True)
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "cal":
-    lib.vrag_debug_set_gemm_small_m(0)   # M = 4096 / 8192 would otherwise take the small-batch configuration
+    dbg.vrag_set_small_batch_rows(0)   # M = 4096 / 8192 would otherwise take the small-batch configuration
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     for n in (4096, 8192):
         run("none ", 7, n, n, n, iters)

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=5.0)
     args = ap.parse_args()
     lib = _lib.load()
+    dbg = _lib.load_debug()   # harness library (include/vrag_amd_debug.h)
     dev = torch.device("cuda", 0)
     n = 1 << 28                                            # 1 GiB of fp32 per buffer: far beyond the Infinity Cache
     src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
@@ -92,9 +93,9 @@ def main():
 
     def gemm_loop(seconds):
         ms = C.c_float()
-        _lib.check("gemm", lib.vrag_debug_gemm_ms(7, M, N, K, 50, 0, C.byref(ms)))
+        _lib.check_debug("gemm", dbg.vrag_debug_gemm_ms(7, M, N, K, 50, 0, C.byref(ms)))
         iters = max(100, int(seconds / (ms.value * 1e-3)))
-        _lib.check("gemm", lib.vrag_debug_gemm_ms(7, M, N, K, iters, 0, C.byref(ms)))
+        _lib.check_debug("gemm", dbg.vrag_debug_gemm_ms(7, M, N, K, iters, 0, C.byref(ms)))
         return {"gemm_tflops": 2.0 * M * N * K / (ms.value * 1e-3) / 1e12, "us_per_launch": ms.value * 1e3}
 
     def both(seconds):

@@ -11,12 +11,14 @@ import verbatim_rag_amd  # noqa: E402,F401
 from verbatim_rag_amd import _lib  # noqa: E402
 
 lib = _lib.load()
+
+dbg = _lib.load_debug()   # harness library (include/vrag_amd_debug.h)
 H, I = 768, 1152
 for epi, name, N, K in ((3, "resid", H, 64), (3, "resid", H, H), (3, "resid", H, I), (4, "geglu", 2 * I, H), (7, "none", H, H)):
     for rounds in (1, 2, 3, 6):
         M = 85 * 256 * rounds
         ms = C.c_float()
-        _lib.check("gemm", lib.vrag_debug_gemm_ms(epi, M, N, K, 300, 0, C.byref(ms)))
+        _lib.check_debug("gemm", dbg.vrag_debug_gemm_ms(epi, M, N, K, 300, 0, C.byref(ms)))
         ws = M * (H * 4 + H * 2 + K * 2) / 1e6 if epi == 3 else M * (K * 2 + N) / 1e6
         print(f"{name:6s} N={N:5d} K={K:5d} M={M:6d} ({rounds} rounds, working set {ws:6.0f} MB): {ms.value * 1e3:7.1f} us = "
               f"{ms.value * 1e3 / rounds:6.1f} us / round", flush=True)

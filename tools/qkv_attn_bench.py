@@ -9,26 +9,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from verbatim_rag_amd import _lib  # noqa: E402
 
 lib = _lib.load()
+
+dbg = _lib.load_debug()   # harness library (include/vrag_amd_debug.h)
 n_seqs, S, H = int(os.environ.get("NSEQ", 128)), int(os.environ.get("S", 512)), int(os.environ.get("H", 768))
 iters = int(os.environ.get("ITERS", 50))
 
 
 def fused(local, flags):
     ms = C.c_float()
-    rc = lib.vrag_debug_qkv_attn_ms(local, n_seqs, S, H, 64, iters, flags, 0, C.byref(ms))
+    rc = dbg.vrag_debug_qkv_attn_ms(local, n_seqs, S, H, 64, iters, flags, 0, C.byref(ms))
     assert rc == 0, lib.vrag_last_error()
     return ms.value * 1e3
 
 
 def gemm(epi, M, N, K):
     ms = C.c_float()
-    assert lib.vrag_debug_gemm_ms(epi, M, N, K, iters, 0, C.byref(ms)) == 0
+    assert dbg.vrag_debug_gemm_ms(epi, M, N, K, iters, 0, C.byref(ms)) == 0
     return ms.value * 1e3
 
 
 def attn(local):
     ms = C.c_float()
-    assert lib.vrag_debug_attn_ms(local, n_seqs, S, H, 64, iters, 0, C.byref(ms)) == 0
+    assert dbg.vrag_debug_attn_ms(local, n_seqs, S, H, 64, iters, 0, C.byref(ms)) == 0
     return ms.value * 1e3
 
 

@@ -108,16 +108,12 @@ SIGNATURES = {
     "vrag_encoder_set_concurrency": (C.c_int, [_H, C.c_int32]),
     "vrag_encoder_set_profiling": (C.c_int, [_H, C.c_int32]),
     "vrag_encoder_read_profile": (C.c_int, [_H, _FP, _LP, C.c_int32]),
-    "vrag_debug_set_gemm_small_m": (C.c_int, [C.c_int32]),
-    "vrag_debug_gemm_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
-    "vrag_debug_attn_run": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_int32]),
-    "vrag_debug_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
-    "vrag_debug_qkv_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "vrag_set_small_batch_rows": (C.c_int, [C.c_int32]),
     "vrag_dense_index_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_H)]),
     "vrag_dense_index_destroy": (None, [_H]),
     "vrag_dense_index_size": (C.c_int64, [_H]),
     "vrag_dense_index_add": (C.c_int, [_H, _FP, C.c_int64]),
+    "vrag_dense_index_add_device": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p]),
     "vrag_dense_index_search": (C.c_int, [_H, _FP, C.c_int32, C.c_int32, _FP, _LP, C.c_void_p]),
     "vrag_dense_index_run_resident": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_void_p]),
     "vrag_dense_index_search_device": (C.c_int, [_H, _FP, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -143,6 +139,17 @@ SIGNATURES = {
     "vrag_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
 }
+
+
+# include/vrag_amd_debug.h: the tuning / unit-test harness, exported by libvrag_amd_dbg.so only (load_debug()).
+DEBUG_SIGNATURES = {
+    "vrag_debug_gemm_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "vrag_debug_attn_run": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int32]),
+    "vrag_debug_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+    "vrag_debug_qkv_attn_ms": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _FP]),
+}
+_DBG = None
 
 
 def library_path() -> str:
@@ -196,6 +203,39 @@ def load() -> C.CDLL:
             raise ImportError(f"{path}: ABI version {lib.vrag_abi_version()} != {ABI_VERSION}")
         _LIB = lib
         return lib
+
+
+def debug_library_path() -> str:
+    return os.environ.get("VRAG_AMD_DEBUG_LIB", os.path.join(_HERE, "libvrag_amd_dbg.so"))
+
+
+def load_debug() -> C.CDLL:
+    """The harness library (include/vrag_amd_debug.h; tools/ and the attention unit test): the product sources plus the
+    synthetic-operand timing loops.  The product path never loads it."""
+    global _DBG
+    with _LOCK:
+        if _DBG is not None:
+            return _DBG
+        path = debug_library_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} not found: build it with `python __graft_entry__.py build`")
+        _preload_torch_hip_runtime()
+        lib = C.CDLL(path)
+        for name, (res, args) in DEBUG_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        lib.vrag_last_error.restype = C.c_char_p
+        lib.vrag_set_small_batch_rows.restype = C.c_int     # the harness library is a full build: its own copy of the threshold
+        lib.vrag_set_small_batch_rows.argtypes = [C.c_int32]
+        _DBG = lib
+        return lib
+
+
+def check_debug(fn: str, status: int) -> None:
+    if status != VRAG_OK:
+        msg = load_debug().vrag_last_error()
+        raise VragError(fn, status, msg.decode("utf-8", "replace") if msg else "")
 
 
 def last_error() -> str:

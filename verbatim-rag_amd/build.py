@@ -29,20 +29,29 @@ def _newer(src: str, dst: str) -> bool:
     return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+DEBUG_LIB_PATH = os.path.join(HERE, f"libvrag_amd_dbg_{VARIANT}.so" if VARIANT else "libvrag_amd_dbg.so")
+# Harness build (include/vrag_amd_debug.h): the product objects, except that the fused kernel keeps its phase-decomposition
+# branches (-DVRAG_DEBUG_API), plus the synthetic-operand timing loops / unit-test hook of debug_api.hip.
+DEBUG_ONLY = ["debug_api.hip"]
+DEBUG_RECOMPILED = ["qkv_attn.hip"]
+
+
+def build_library(force: bool = False, verbose: bool = False, debug: bool = True) -> str:
+    """Builds libvrag_amd.so (the product) and, with debug=True, libvrag_amd_dbg.so (the tuning / unit-test harness)."""
     hipcc = _hipcc()
     objdir = os.path.join(HERE, f"build_{VARIANT}" if VARIANT else "build")
     os.makedirs(objdir, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "vrag_amd.h"))
+    headers += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("vrag_amd.h", "vrag_amd_debug.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)
 
-    def compile_one(src: str) -> str:
+    def compile_one(job) -> str:
+        src, suffix, extra = job
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, src.replace(".hip", suffix + ".o"))
         if force or _newer(sp, obj) or os.path.getmtime(obj) < hdr_time:
-            cmd = [hipcc, *FLAGS, "-c", sp, "-o", obj]
+            cmd = [hipcc, *FLAGS, *extra, "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -50,13 +59,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(compile_one, srcs))
-    if force or any(_newer(o, LIB_PATH) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB_PATH]   # -ldl: comm.hip binds RCCL at run time
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    jobs = [(s, "", []) for s in srcs]
+    if debug:
+        jobs += [(s, "_dbg", ["-DVRAG_DEBUG_API"]) for s in DEBUG_RECOMPILED + DEBUG_ONLY]
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    prod = objs[: len(srcs)]
+
+    def link(inputs, out):
+        if force or any(_newer(o, out) for o in inputs):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *inputs, "-ldl", "-o", out]   # -ldl: comm.hip binds RCCL at run time
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+
+    link(prod, LIB_PATH)
+    if debug:
+        swapped = {os.path.join(objdir, s.replace(".hip", ".o")): os.path.join(objdir, s.replace(".hip", "_dbg.o")) for s in DEBUG_RECOMPILED}
+        dbg = [swapped.get(o, o) for o in prod] + [os.path.join(objdir, s.replace(".hip", "_dbg.o")) for s in DEBUG_ONLY]
+        link(dbg, DEBUG_LIB_PATH)
     return LIB_PATH
 
 

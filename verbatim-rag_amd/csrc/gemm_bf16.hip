@@ -119,7 +119,11 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           ho[j] = Op<T>::to(v[j >> 1][j & 1]);
-          lw[j] = (f16_t)(v[j >> 1][j & 1] - (float)ho[j]);
+          // fp16 operands: hi clamps at +-65504, so the remainder of an outlier beyond ~131 000 would overflow the fp16 low plane
+          // to inf and poison the stream -- clamp it too (and raise the saturation flag); bf16 hi never leaves a remainder
+          // above 2^-8 |v|, the plain conversion is exact enough there and costs nothing
+          if constexpr (std::is_same<T, f16_t>::value) lw[j] = Op<f16_t>::to(v[j >> 1][j & 1] - (float)ho[j]);
+          else lw[j] = (f16_t)(v[j >> 1][j & 1] - (float)ho[j]);
         }
         store16_nt(p.resid_bf16 + rb + loff, __builtin_bit_cast(f32x4, ho));
         store16_nt(p.lo_out + rb + loff, __builtin_bit_cast(f32x4, lw));

@@ -20,7 +20,7 @@
 //      from LDS: no global round trip between the main loop and attention.
 //   3. attention: every wave walks the 64-key tiles of its band (global: all of them) on the LDS-resident K / V^T -- no
 //      DMA, no barriers, waves run free; softmax in exp2 units with a lazily moved reference that rides into the S^T MFMAs
-//      as their C operand, row sums from an all-ones MFMA (the arithmetic of attn2_fwd_kernel, attention.hip).
+//      as their C operand, row sums from an all-ones MFMA (first built as a stand-alone second-generation attention kernel in round 3, since folded in here).
 //   4. O rows are staged through LDS and stored as whole 128-byte head rows.
 // Round 4, wave-slot packing: a workgroup holds a GROUP of consecutive sequences, each on ceil(S / 64) consecutive waves (per-wave
 // descriptors: first row, sequence length, first wave of the sequence); K / V^T rows stay indexed by workgroup slot, positions,
@@ -33,6 +33,14 @@
 
 #include <cstdlib>
 #include <type_traits>
+
+// Phase-decomposition probes of the fused kernel (vrag_debug_qkv_attn_ms, include/vrag_amd_debug.h): present in the harness build
+// only; the product build compiles every one of these branches out.
+#ifdef VRAG_DEBUG_API
+#define VRAG_DBG(bit) ((p.debug_flags & (bit)) != 0)
+#else
+#define VRAG_DBG(bit) false
+#endif
 
 namespace vrag {
 
@@ -104,13 +112,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   // The lane offset is re-read through an opaque asm at every use: otherwise the eleven 64-bit lane addresses are hoisted out
   // of the K loop as loop invariants -- 22 registers the loop does not have, i.e. spills and reloads in front of every DMA.
   auto dma_w = [&](int kt, int buf, int i) {
-    if (p.debug_flags & 4) return;
+    if (VRAG_DBG(4)) return;
     unsigned vo = voffW[i];
     asm volatile("" : "+v"(vo));
     glds16(Wb + kt * 128 + vo, smem + buf * QA_WB + (wave * 24 + i * 8) * 128);
   };
   auto dma_x = [&](int kt, int i) {
-    if (!active || (p.debug_flags & 4)) return;
+    if (!active || VRAG_DBG(4)) return;
     unsigned vo = voffX[i & 1];
     asm volatile("" : "+v"(vo));
     glds16(Xw + ((size_t)(i >> 1) * 16 * H + kt * 64) * 2 + vo, xbuf + i * 1024);
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   // NOW, behind the K / V^T area, and is read from LDS when the main loop is over: no global round trip sits between the main
   // loop and attention.  Rotary rows by angle addition: pos = 16 b + i, cos(pos f) = cos(16 b f) cos(i f) - sin(16 b f) sin(i f):
   // table rows 16 b (b < 32) and rows 0 .. 15 are all a 512-token sequence needs (12 KiB instead of 128).
-  if (!(p.debug_flags & 4)) {
+  if (!VRAG_DBG(4)) {
     if (FOLD && lane < 16) {   // every wave brings the statistics of ITS 64 rows (16 lanes x 4 floats each)
       glds16(p.ln_mu + min(wrow0 + lane * 4, Tp - 4), smem + QA_MU + srow0 * 4);
       glds16(p.ln_rstd + min(wrow0 + lane * 4, Tp - 4), smem + QA_RS + srow0 * 4);
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   int fo[2];   // fragment of a 16-row block: row l15, k-values 32 s + 8 g .. + 7
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) fo[s2] = l15 * 128 + ((((4 * s2 + g) ^ ((l15 >> 1) & 7))) << 4);
-  const bool mm = active && !(p.debug_flags & 2);
+  const bool mm = active && !VRAG_DBG(2);
 #pragma unroll
   for (int i = 0; i < 3; ++i) dma_w(0, 0, i);
 #pragma unroll
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     }
   }
   __syncthreads();   // every wave is past its last operand read: the ring becomes the K / V^T store
-  if (p.debug_flags & 16) return;
+  if (VRAG_DBG(16)) return;
 
   // ---------------------------------------------------------------- 2. epilogue: fold, RoPE, K / V^T -> LDS, Q -> registers
   const float* l_mu = reinterpret_cast<const float*>(smem + QA_MU) + srow0;
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   __syncthreads();   // K and V^T of the whole sequence are in LDS
 
   // ---------------------------------------------------------------- 3. attention over the LDS-resident keys
-  // The arithmetic of attn2_fwd_kernel (attention.hip): the running reference rides into S^T = K . Q^T as the MFMA's C operand,
+  // The running reference rides into S^T = K . Q^T as the MFMA's C operand,
   // so p = exp2(s) needs no subtraction; the reference moves (cross-lane maximum, rescale) only when a score exceeds it by
   // more than 2^8 or a row meets its first key -- a rare wave-uniform branch; row sums come from the matrix pipe (an all-ones
   // A operand against the very P fragments the P . V product uses).  Per score: half a v_max3, one v_exp, half a packed
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     kt_hi = min(S - 1, qrow0 + 63 + W) >> 6;
   }
   const int ksw = (l15 >> 1) & 7;
-  if (active && !(p.debug_flags & 1)) {
+  if (active && !VRAG_DBG(1)) {
     for (int kt = kt_lo; kt <= kt_hi; ++kt) {
       // 32-row group u against the 32-key half t2 of the tile: `cut` = some element of the 32 x 32 block is outside the band or
       // beyond the sequence (masked element by element; a block wholly outside is simply all -inf); `dead` = the whole 64-key
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + (lane >> 3), c16 = lane & 7;
       const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 128 + ((c16 ^ (row & 7)) << 4));
-      if (qrow0 + row < S && !(p.debug_flags & 8)) store16_nt(reinterpret_cast<T*>(p.o) + (size_t)(wrow0 + row) * H + head * 64 + c16 * 8, v);
+      if (qrow0 + row < S && !VRAG_DBG(8)) store16_nt(reinterpret_cast<T*>(p.o) + (size_t)(wrow0 + row) * H + head * 64 + c16 * 8, v);
     }
   }
 }

@@ -1882,6 +1882,27 @@ int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
   return VRAG_OK;
 }
 
+int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t n, void* stream) {
+  ARG_CHECK(ix && rows && n > 0, "bad arguments");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (ix->size + n > ix->capacity) {
+    set_error("dense index full: %lld + %lld > capacity %lld", (long long)ix->size, (long long)n, (long long)ix->capacity);
+    return VRAG_ERR_CAPACITY;
+  }
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t dim = ix->dim, off = (size_t)ix->size * dim, cnt = (size_t)n * dim;
+  if (ix->dtype == 1) {
+    HIP_TRY(hipMemcpyAsync(reinterpret_cast<float*>(ix->rows) + off, rows, cnt * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(cvt_f32_bf16_flat, dim3(2048), dim3(256), 0, st, rows, reinterpret_cast<bf16_t*>(ix->rows) + off, cnt);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(st));   // ingest is not the hot path: searches on any stream may follow at once
+  ix->size += n;
+  return VRAG_OK;
+}
+
 int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t nq, int32_t k, float* scores,
                             int64_t* ids, void* stream) {
   ARG_CHECK(ix && queries && scores && ids && nq > 0, "bad arguments");

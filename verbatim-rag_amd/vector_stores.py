@@ -239,6 +239,10 @@ class DenseShard:
             raise ValueError(f"rows must be [n, {self.dim}]")
         _lib.check("vrag_dense_index_add", self._lib.vrag_dense_index_add(self._h, rows.ctypes.data_as(_FP), rows.shape[0]))
 
+    def add_device(self, ptr: int, n: int, stream=None) -> None:
+        """Rows already in HBM (`ptr`: device address of fp32 `[n, dim]` on the shard's device): no host round trip."""
+        _lib.check("vrag_dense_index_add_device", self._lib.vrag_dense_index_add_device(self._h, C.c_void_p(int(ptr)), int(n), stream))
+
     def __len__(self) -> int:
         return int(self._lib.vrag_dense_index_size(self._h))
 

@@ -293,3 +293,137 @@ def test_configs4_slice_pipeline_with_the_large_extractor_equals_the_oracle_pipe
         assert g["answer"] == wnt["answer"]
         n_cited += len(g["structured_answer"]["citations"])
     assert n_cited > 0
+
+
+class _LookupProvider:
+    """Query-side stand-in for an embedding provider in the composed run below: question text -> a prepared vector (the
+    encoders behind the real providers are oracle-tested on their own: test_heads_gpu.py, test_bert_gpu.py,
+    test_splade_real_vocab_gpu.py; what is composed here is store + extractor + pipeline at configs[4]'s per-GPU size)."""
+
+    def __init__(self, table, dim):
+        self.table, self.dim = table, dim
+
+    def embed_text(self, text):
+        return self.table[text]
+
+    def embed_queries(self, texts):
+        return [self.table[t] for t in texts]
+
+    def embed_batch(self, texts):
+        return [self.table[t] for t in texts]
+
+    def get_dimension(self):
+        return self.dim
+
+
+def test_configs4_one_gpu_slice_composed_1_25m_hybrid_rows_large_extractor_1024_queries():
+    """BASELINE configs[4] as ONE GPU of the 8 sees it, composed: a 1.25 * 10^6-row hybrid store
+    (synthetic dense rows + SPLADE-shaped CSR rows, real multi-sentence chunk texts), 1 024 concurrent questions through
+    `StaticVerbatimPipeline.query_batch` -- batched hybrid retrieval (tiled dense search + batched sparse search + RRF),
+    top-5, the ModernBERT-large sentence classifier at full depth over the 5 120 (question, chunk) pairs, static template,
+    citations.  On a 16-question sample the responses (answers, highlights, citation offsets) must equal the same pipeline
+    with the extractor's logits replaced by the fp32 oracle's.  Wall times go to gpurun_out/full_size_timings.json."""
+    from tokenizers import Tokenizer
+
+    from oracle import modernbert_np as O
+    from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
+    from verbatim_rag_amd.extractors import GpuModelSpanExtractor, SpanExtractor, select_sentences
+    from verbatim_rag_amd.index import HotPathIndex
+    from verbatim_rag_amd.pipeline import StaticVerbatimPipeline
+    from verbatim_rag_amd.vector_stores import GpuVectorStore
+    from verbatim_rag_amd.weights import random_init, random_qa_head
+
+    n, nq, n_sample = N_DENSE, 1024, 16
+    tok = Tokenizer.from_file(os.path.join(G, "tokenizer.json"))
+    with open(os.path.join(G, "host_fixtures.json")) as f:
+        fx = json.load(f)
+    sents = [s for d in fx["config1"]["docs"] for s in d.replace("?", ".").split(". ") if len(s) > 12]
+    rng = np.random.default_rng(19)
+    pool = []
+    for i in range(512):                                   # 512 distinct chunk texts of 3 - 7 sentences, dealt over the rows
+        pick = rng.choice(len(sents), size=int(rng.integers(3, 8)), replace=False)
+        pool.append(" ".join(sents[j].rstrip(".") + (" number %d." % i if m == 0 else ".") for m, j in enumerate(pick)))
+    texts = [pool[(i * 2654435761) % 512] for i in range(n)]
+    t0 = time.perf_counter()
+    X = S.dense_rows(n, DIM, seed=51)
+    ip, ix, vv = S.sparse_corpus(n, VOCAB, seed=52)
+    store = GpuVectorStore(dense_dim=DIM, sparse_vocab=VOCAB)
+    store.add_vectors([f"c{i}" for i in range(n)], X, (ip, ix, vv), texts, texts,
+                      [{"title": f"Doc {i >> 6}", "source": f"s{i >> 6}.md", "document_id": f"d{i >> 6}"} for i in range(n)])
+    del X, ip, ix, vv
+    gc.collect()
+    _note("composed_store_build_1_25m_s", time.perf_counter() - t0)
+    Q = S.dense_rows(nq, DIM, seed=53)
+    dq, _csr = S.sparse_queries(nq, VOCAB, seed=54)
+    words = ["tower", "bridge", "museum", "river", "engineer", "harbour", "castle", "library"]
+    questions = [f"Where is the {words[i % 8]} number {i}?" for i in range(nq)]
+    index = HotPathIndex(store, dense_provider=_LookupProvider({q: Q[i].tolist() for i, q in enumerate(questions)}, DIM),
+                         sparse_provider=_LookupProvider({q: dq[i] for i, q in enumerate(questions)}, VOCAB))
+    base = ModernBertShape.large()
+    shape = ModernBertShape(**{**base.__dict__, "vocab_size": 512, "pad_token_id": 0, "cls_token_id": 1, "sep_token_id": 2})
+    w = random_init(shape, seed=404)
+    qa_w, qa_b = random_qa_head(shape)
+    eng = EncoderEngine(shape, w, max_tokens=262144, max_seqs=2048, max_seq_len=512, max_ranges=16384, micro_batch_tokens=65536)
+    eng.set_qa_head(qa_w, qa_b)
+    gpu_ext = GpuModelSpanExtractor(engine=eng, tokenizer=tok, threshold=0.5)
+    cfg = O.EncoderConfig(vocab_size=512, hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
+                          num_attention_heads=shape.num_attention_heads, intermediate_size=shape.intermediate_size,
+                          global_attn_every_n_layers=shape.global_attn_every_n_layers, local_attention=shape.local_attention,
+                          global_rope_theta=shape.global_rope_theta, local_rope_theta=shape.local_rope_theta,
+                          norm_eps=shape.norm_eps, pad_token_id=0, cls_token_id=1, sep_token_id=2)
+    cache = {}
+
+    def oracle_logits(question, text, smp):
+        key = (question, text)
+        if key not in cache:
+            hid = O.encoder_forward(cfg, w, np.asarray(smp.input_ids, np.int32))
+            cache[key] = O.qa_sentence_logits(hid, smp.sentence_boundaries, qa_w, qa_b)
+        return cache[key]
+
+    class OracleExtractor(SpanExtractor):
+        def extract_spans(self, question, search_results):
+            docs = [getattr(r, "text", "") for r in search_results]
+            all_sents, samples = gpu_ext.pack_qa(question, docs)
+            out = {}
+            for text, raw, smp in zip(docs, all_sents, samples):
+                out[text] = [] if smp is None else select_sentences(oracle_logits(question, text, smp), raw, gpu_ext.threshold)
+            return out
+
+    try:
+        pipe = StaticVerbatimPipeline(index, gpu_ext, k=5)
+        pipe.query_batch(questions[:64])                       # warm-up: store flush (SELL build, uploads), chunk cache
+        t0 = time.perf_counter()
+        got = pipe.query_batch(questions)
+        t_batch = time.perf_counter() - t0
+        _note("composed_1024_queries_query_batch_s", t_batch)
+        _note("composed_queries_per_s", nq / t_batch)
+        assert len(got) == nq and all(1 <= len(r.documents) <= 5 for r in got)
+        # oracle pass over the sample: probabilities first, then a threshold in the widest gap (the comparison is about
+        # arithmetic within 1e-3, not about a sentence that happens to sit on the threshold)
+        sample = list(range(0, nq, nq // n_sample))[:n_sample]
+        oracle_pipe = StaticVerbatimPipeline(index, OracleExtractor(), k=5)
+        t0 = time.perf_counter()
+        for i in sample:
+            oracle_pipe.query(questions[i])
+        _note("composed_oracle_16_queries_s", time.perf_counter() - t0)
+        probs = np.sort(np.concatenate([O.softmax_rows(lg)[:, 1] for lg in cache.values()]))
+        mid = probs[(probs > 0.3) & (probs < 0.7)]
+        assert len(mid) >= 2
+        g = int(np.argmax(np.diff(mid)))
+        gpu_ext.threshold = float((mid[g] + mid[g + 1]) / 2)
+        assert mid[g + 1] - mid[g] > 2e-3
+        got_s = pipe.query_batch([questions[i] for i in sample])
+        want = [oracle_pipe.query(questions[i]) for i in sample]
+        n_cited = 0
+        for a, b in zip(got_s, want):
+            a, b = a.model_dump(), b.model_dump()
+            assert [d["highlights"] for d in a["documents"]] == [d["highlights"] for d in b["documents"]]    # citation offsets
+            assert a["structured_answer"]["citations"] == b["structured_answer"]["citations"]
+            assert a["answer"] == b["answer"]
+            n_cited += len(a["structured_answer"]["citations"])
+        assert n_cited > 0
+    finally:
+        eng.close()
+        for shard, _b, _n in store._sparse_parts:
+            shard.close()
+        store._dense.close()

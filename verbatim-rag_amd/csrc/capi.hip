@@ -1966,7 +1966,7 @@ int vrag_encoder_read_splade(vrag_encoder* e, float* rows, void* stream) {
   if (rc) return rc;
   ARG_CHECK(rows, "null output");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
-  ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set");
+  ARG_CHECK(e->mlm_dec != nullptr || e->mlm_dec3 != nullptr, "mlm head not set");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
   const int V = e->cfg.vocab_size;
@@ -1982,7 +1982,7 @@ int vrag_encoder_read_splade_sparse(vrag_encoder* e, float threshold, int32_t ca
   if (rc) return rc;
   ARG_CHECK(counts && indices && values && cap_per_seq > 0 && threshold >= 0.f, "bad arguments");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
-  ARG_CHECK(e->mlm_dec != nullptr, "mlm head not set");
+  ARG_CHECK(e->mlm_dec != nullptr || e->mlm_dec3 != nullptr, "mlm head not set");
   HIP_TRY(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
   if (cap_per_seq > e->sp_cap) {   // (re)allocate; the old buffers stay owned by the handle until destroy

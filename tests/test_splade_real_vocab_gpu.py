@@ -29,14 +29,20 @@ from oracle import modernbert_np as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 LENS = (7, 130, 512)
 
-# bounds on |row - oracle| : (head alone, end to end); set from the measured values of tools-style probe `python
-# tests/test_splade_real_vocab_gpu.py` on MI355X (profiles/r05_splade_real_vocab_probe.txt), with ~2x headroom
+# bounds on |row - oracle| : (head alone, end to end), ~4x above what `python tests/test_splade_real_vocab_gpu.py` measured on
+# MI355X (profiles/r05_splade_real_vocab_probe.txt):
+#   split operands  bf16: head 1.8e-5 / 1.3e-5, end to end 1.3e-2 (BERT, std-0.03 weights: the ENCODER's bf16 rounding) / 1.1e-3
+#                   fp16: head 2.6e-6 / 2.7e-6, end to end 1.6e-3 / 1.5e-4
+#   plain operands  bf16: head 1.06e-2 / 6.1e-3;  fp16: head 1.2e-3 / 7.6e-4
+# i.e. with split operands the head is fp32-exact to 2e-5 (VERDICT r4 asked for 2e-3 / 1e-3) and what is left end to end is
+# the encoder's own operand rounding, which the encoder tests bound.
 BOUNDS = {
-    ("bf16", True): (2e-3, 2e-2),
-    ("f16", True): (1e-3, 4e-3),
-    ("bf16", False): (2e-2, 3e-2),
+    ("bf16", True): (1e-4, 3e-2),
+    ("f16", True): (2e-5, 4e-3),
+    ("bf16", False): (3e-2, 4e-2),
     ("f16", False): (4e-3, 6e-3),
 }
+E2E_MODERNBERT = {"bf16": 4e-3, "f16": 6e-4}      # the ModernBERT case alone (trunc-normal 0.02 init): tighter end to end
 
 
 def _bert_case(dtype, split):
@@ -118,7 +124,7 @@ def test_splade_rows_at_real_vocabulary_split_operands(name, case, dtype):
     m = _measure(case, dtype, True)
     b_head, b_e2e = BOUNDS[(dtype, True)]
     assert m["head"] <= b_head and m["edge_head"] <= b_head, (name, dtype, m)
-    assert m["e2e"] <= b_e2e, (name, dtype, m)
+    assert m["e2e"] <= (E2E_MODERNBERT[dtype] if name.startswith("modernbert") else b_e2e), (name, dtype, m)
     assert m["support_head"] == 0 and m["support_e2e"] == 0, (name, dtype, m)
 
 

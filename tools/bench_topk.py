@@ -68,15 +68,17 @@ def sparse(n=1_000_000, vocab=30522, mean_nnz=128, k=5):
     sh = SparseShard(vocab, indptr, idx, val)
     st = sh.stats()
     out = []
-    for nq in (1, 8, 64):
+    qb = 8 if os.environ.get("VRAG_SPARSE_QB8") is not None or vocab * 2 + 16 * 4096 + 16 * 16 * k * 8 > 160 * 1024 else 16
+    for nq in (1, 8, 16, 64, 1000):
         qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(nq)]
         sh.search(qs, k)
         dt = timeit(lambda: sh.run_resident(nq, k), 5)
-        per_pass = 1 if nq == 1 else 8   # sparse_topk_kernel / sparse_topk_multi_kernel<8>
+        per_pass = 1 if nq == 1 else qb   # sparse_topk_kernel / sparse_topk_multi_kernel<8 | 16> (csrc/topk.hip sparse_pass_queries)
         passes = (nq + per_pass - 1) // per_pass
         pass_bytes = st["padded_nnz"] * 6 + (st["n_docs"] // 64 + 1) * 12
         bytes_ = pass_bytes * passes            # a pass reads the shard ONCE for all of its queries
-        out.append({"kind": "sparse_sell64", "docs": n, "nnz": st["nnz"], "padded_nnz": st["padded_nnz"], "nq": nq, "k": k,
+        out.append({"kind": "sparse_sell64x4", "docs": n, "nnz": st["nnz"], "padded_nnz": st["padded_nnz"], "nq": nq, "k": k,
+                    "queries_per_pass": per_pass,
                     "ms": dt * 1e3, "queries_per_s": nq / dt, "algorithmic_GBps": bytes_ / dt / 1e9,
                     "frac_of_8TBps": bytes_ / dt / HBM_PEAK, "bytes_per_pass": pass_bytes, "passes": passes})
     sh.close()

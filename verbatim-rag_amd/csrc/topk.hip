@@ -32,6 +32,7 @@
 namespace vrag {
 void set_error(const char* fmt, ...);
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // u64 / orderable / unorderable / make_key: common.h (the tiled batched search builds the same keys in a GEMM epilogue)
 
 // Paged search (k > KMAX): page p+1 only admits keys strictly below the last key of page p; keys are unique per
@@ -1210,30 +1211,31 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
   const int s_end = min(n_slices, s_begin + slices_per_wg);
   for (int s = s_begin + wave; s < s_end; s += 16) {
     const long long off = slice_off[s];
-    const int len = slice_len[s];
-    const unsigned short* c = cols + off + lane;
-    const float* v = vals + off + lane;
+    const int ng = slice_len[s];   // groups of 4 terms
+    const u32x2* c = reinterpret_cast<const u32x2*>(cols + off) + lane;     // group g of this lane's document: c[g * 64]
+    const f32x4* v = reinterpret_cast<const f32x4*>(vals + off) + lane;
     float acc = 0.f;
-    int j = 0;
-    // 16 then 4 terms per step: all loads of a step are issued before the (strictly sequential, term-order)
-    // fmaf chain consumes them -- 32 loads in flight per lane keep enough bytes outstanding per CU.
-    auto steps = [&](auto un) {
-      constexpr int U = decltype(un)::value;
-      for (; j + U <= len; j += U) {
-        unsigned short ci[U];
-        float vi[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          ci[u] = __builtin_nontemporal_load(c + (size_t)(j + u) * 64);
-          vi[u] = __builtin_nontemporal_load(v + (size_t)(j + u) * 64);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = __fmaf_rn(vi[u], LDSQ ? sq[ci[u]] : qv[ci[u]], acc);
-      }
+    auto qw = [&](unsigned t) { return LDSQ ? sq[t] : qv[t]; };
+    auto consume = [&](const u32x2& cg, const f32x4& vg) {   // strictly sequential, term-order fmaf chain
+      acc = __fmaf_rn(vg[0], qw(cg[0] & 0xFFFFu), acc);
+      acc = __fmaf_rn(vg[1], qw(cg[0] >> 16), acc);
+      acc = __fmaf_rn(vg[2], qw(cg[1] & 0xFFFFu), acc);
+      acc = __fmaf_rn(vg[3], qw(cg[1] >> 16), acc);
     };
-    steps(std::integral_constant<int, 16>{});
-    steps(std::integral_constant<int, 4>{});
-    for (; j < len; ++j) acc = __fmaf_rn(v[(size_t)j * 64], LDSQ ? sq[c[(size_t)j * 64]] : qv[c[(size_t)j * 64]], acc);
+    // 8 groups (32 terms) per step: all 16 loads of a step (8 + 16 bytes per lane each) are issued before the chain consumes them
+    int g = 0;
+    for (; g + 8 <= ng; g += 8) {
+      u32x2 cg[8];
+      f32x4 vg[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        cg[u] = __builtin_nontemporal_load(c + (size_t)(g + u) * 64);
+        vg[u] = __builtin_nontemporal_load(v + (size_t)(g + u) * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) consume(cg[u], vg[u]);
+    }
+    for (; g < ng; ++g) consume(c[(size_t)g * 64], v[(size_t)g * 64]);
     const long long doc = (long long)s * 64 + lane;  // position in nnz-sorted order
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
     // the key carries the caller's document index (not the sorted position): ties order by id ascending
@@ -1302,50 +1304,60 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
   const int s_end = min(n_slices, s_begin + slices_per_wg);
   for (int s = s_begin + wave; s < s_end; s += 16) {
     const long long off = slice_off[s];
-    const int len = slice_len[s];
-    const unsigned short* c = cols + off + lane;
-    const float* v = vals + off + lane;
+    const int ng = slice_len[s];   // groups of 4 terms
+    const u32x2* c = reinterpret_cast<const u32x2*>(cols + off) + lane;
+    const f32x4* v = reinterpret_cast<const f32x4*>(vals + off) + lane;
+    f32x2 acc2[QB / 2];
+#pragma unroll
+    for (int q = 0; q < QB / 2; ++q) acc2[q] = f32x2{0.f, 0.f};
+    auto term = [&](unsigned t, float v1) {   // acc[q] = fma(v1, W[uid][q], acc[q]) for every query, two per v_pk_fma_f32
+      const unsigned uid = tmap[t];
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
+      const f32x2 vv = splat2(v1);
+#pragma unroll
+      for (int g4 = 0; g4 < QB / 4; ++g4) {
+        const f32x4 w4 = wrow[g4];
+        acc2[2 * g4] = pk_fma(vv, f32x2{w4[0], w4[1]}, acc2[2 * g4]);
+        acc2[2 * g4 + 1] = pk_fma(vv, f32x2{w4[2], w4[3]}, acc2[2 * g4 + 1]);
+      }
+    };
+    auto consume = [&](const u32x2& cg, const f32x4& vg) {   // the document's term order; weight rows of two terms in flight
+      term(cg[0] & 0xFFFFu, vg[0]);
+      term(cg[0] >> 16, vg[1]);
+      if constexpr (QB > 8) __builtin_amdgcn_sched_barrier(0);
+      term(cg[1] & 0xFFFFu, vg[2]);
+      term(cg[1] >> 16, vg[3]);
+    };
+    // Two register sets of G groups (4 G terms): the loads of step i + 1 are in flight while step i is consumed -- one 16-wave
+    // workgroup per CU (the term map fills the LDS), so the bytes in flight per lane are what covers the memory latency.
+    constexpr int G = QB > 8 ? 2 : 4;   // 16 queries: 16 accumulators + four weight rows in flight leave room for two 8-term sets
+    u32x2 ca[G], cb[G];
+    f32x4 va[G], vb[G];
+    auto load = [&](u32x2 (&cd)[G], f32x4 (&vd)[G], int g0) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int gi = min(g0 + u, ng - 1);   // the tail re-reads the last group; its copies are not consumed
+        cd[u] = __builtin_nontemporal_load(c + (size_t)gi * 64);
+        vd[u] = __builtin_nontemporal_load(v + (size_t)gi * 64);
+      }
+    };
+    auto eat = [&](const u32x2 (&cd)[G], const f32x4 (&vd)[G], int g0) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (g0 + u < ng) consume(cd[u], vd[u]);   // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (ng > 0) load(ca, va, 0);
+    for (int g0 = 0; g0 < ng; g0 += 2 * G) {
+      if (g0 + G < ng) load(cb, vb, g0 + G);
+      eat(ca, va, g0);
+      if (g0 + 2 * G < ng) load(ca, va, g0 + 2 * G);
+      if (g0 + G < ng) eat(cb, vb, g0 + G);
+    }
     float acc[QB];
 #pragma unroll
-    for (int q = 0; q < QB; ++q) acc[q] = 0.f;
-    auto term = [&](unsigned uid, float v1) {   // acc[q] += v1 * W[uid][q], q ascending inside the document's term order
-      const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
-#pragma unroll
-      for (int g = 0; g < QB / 4; ++g) {
-        const f32x4 w4 = wrow[g];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * g + i] = __fmaf_rn(v1, w4[i], acc[4 * g + i]);
-      }
-    };
-    // 16 then 4 terms per step, like the single-query kernel: all loads of a step are issued before its (strictly
-    // sequential, term-order) fmaf chains consume them -- with one 16-wave workgroup per CU (the term map fills the LDS)
-    // the bytes in flight per lane are what covers the memory latency (8-term steps: 0.44 ms per pass, 0.37 ms of it with
-    // the LDS reads and FMAs compiled out).  Weight rows are read four terms at a time (scheduling fence) to bound registers.
-    int j = 0;
-    auto steps = [&](auto un) {
-      constexpr int U = decltype(un)::value;
-      for (; j + U <= len; j += U) {
-        unsigned short ci[U];
-        float vi[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          ci[u] = __builtin_nontemporal_load(c + (size_t)(j + u) * 64);
-          vi[u] = __builtin_nontemporal_load(v + (size_t)(j + u) * 64);
-        }
-        unsigned uid[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) uid[u] = tmap[ci[u]];
-#pragma unroll
-        for (int u = 0; u < U; u += 4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) term(uid[u + i], vi[u + i]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    steps(std::integral_constant<int, 16>{});
-    steps(std::integral_constant<int, 4>{});
-    for (; j < len; ++j) term(tmap[c[(size_t)j * 64]], v[(size_t)j * 64]);
+    for (int q = 0; q < QB; ++q) acc[q] = acc2[q >> 1][q & 1];
     const long long doc = (long long)s * 64 + lane;
     const unsigned did = doc < n_docs ? docid[doc] : 0u;
 #pragma unroll
@@ -2005,17 +2017,21 @@ int vrag_sparse_index_create(int32_t vocab, int64_t n_docs, const int64_t* indpt
   std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) {
     return (indptr[a + 1] - indptr[a]) < (indptr[b + 1] - indptr[b]);
   });
+  // SELL-64 in groups of four terms: slice s holds its 64 documents' terms as ng = ceil(longest / 4) groups; group g is 64 x 4
+  // consecutive (column, value) entries, lane-major -- lane l reads its document's terms 4g .. 4g+3 with ONE 8-byte and ONE
+  // 16-byte load (a quarter of the load instructions of a term-per-row layout).  Padding entries are (term 0, value 0).
   const int n_slices = (int)((n_docs + 63) / 64);
   std::vector<long long> off(n_slices + 1, 0);
-  std::vector<int> len(n_slices, 0);
+  std::vector<int> len(n_slices, 0);   // groups per slice
   for (int s = 0; s < n_slices; ++s) {
     const int64_t last = std::min<int64_t>(n_docs, (int64_t)(s + 1) * 64) - 1;
-    len[s] = (int)(indptr[perm[last] + 1] - indptr[perm[last]]);  // sorted ascending: last doc is the longest
-    off[s + 1] = off[s] + (long long)len[s] * 64;
+    const int64_t longest = indptr[perm[last] + 1] - indptr[perm[last]];  // sorted ascending: last doc is the longest
+    len[s] = (int)((longest + 3) / 4);
+    off[s + 1] = off[s] + (long long)len[s] * 256;
   }
   const size_t padded = (size_t)off[n_slices];
-  std::vector<unsigned short> cols(std::max<size_t>(padded, 64), 0);
-  std::vector<float> vals(std::max<size_t>(padded, 64), 0.f);
+  std::vector<unsigned short> cols(std::max<size_t>(padded, 256), 0);
+  std::vector<float> vals(std::max<size_t>(padded, 256), 0.f);
   for (int s = 0; s < n_slices; ++s) {
     for (int l = 0; l < 64; ++l) {
       const int64_t p = (int64_t)s * 64 + l;
@@ -2028,8 +2044,9 @@ int vrag_sparse_index_create(int32_t vocab, int64_t n_docs, const int64_t* indpt
           set_error("document %lld: term id %d outside the vocabulary", (long long)d, t);
           return VRAG_ERR_INVALID;
         }
-        cols[(size_t)off[s] + (size_t)(j - a) * 64 + l] = (unsigned short)t;
-        vals[(size_t)off[s] + (size_t)(j - a) * 64 + l] = values[j];
+        const size_t at = (size_t)off[s] + ((size_t)((j - a) >> 2) * 64 + l) * 4 + (size_t)((j - a) & 3);
+        cols[at] = (unsigned short)t;
+        vals[at] = values[j];
       }
     }
   }
@@ -2100,7 +2117,18 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
   return spw;
 }
 
-constexpr int SQB = 8;   // queries per pass of the batched sparse kernel (16 per pass was measured slower: registers, 3.7 vs 2.0 ms for 64 queries)
+// Queries per pass of the batched sparse kernel: 16 when the term map, the weight table and the lists fit the LDS (the 30 522-term
+// vocabulary at k <= 32), else 8.  (Round 2 measured 16 slower -- 3.7 vs 2.0 ms for 64 queries: its accumulators and 32
+// single-term loads per step did not fit 128 registers.  Round 5: four terms per load pair, two queries per v_pk_fma_f32.)
+constexpr int SQB_MAX = 16;
+static bool sparse_multi_fits(int vocab, int qb, int k) {
+  const int vpad = (vocab + 7) & ~7;
+  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024;
+}
+static int sparse_pass_queries(int vocab, int k) {
+  static const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
+  return (!only8 && sparse_multi_fits(vocab, 16, k)) ? 16 : 8;
+}
 
 static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out, const u64* bound = nullptr) {
   const int slices_per_wg = sparse_slices_per_wg(ix);
@@ -2109,17 +2137,25 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   if (ix->last_multi) {
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
+    ARG_CHECK(sparse_multi_fits(ix->vocab, QB, k), "k = %d does not fit the batched pass the resident queries were prepared for", k);
     const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)16 * QB * k * sizeof(u64);
     static bool attr_m = false;
     if (!attr_m) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<SQB>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
     for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
-      hipLaunchKernelGGL((sparse_topk_multi_kernel<SQB>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                         ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                         ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      if (QB == 16)
+        hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      else
+        hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
@@ -2167,9 +2203,8 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
   // u16 map + weight tables + top-k lists must fit the LDS.
   static const bool multi_off = getenv("VRAG_SPARSE_SINGLE") != nullptr;   // tuning / tests: force the single-query kernel
   const int vpad = (ix->vocab + 7) & ~7;
-  auto fits = [&](int qb) { return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024; };
-  const int QB = SQB;
-  bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 && fits(QB);
+  const int QB = sparse_pass_queries(ix->vocab, k);
+  bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 && sparse_multi_fits(ix->vocab, QB, k);
   for (int q = 0; q < nq; ++q)
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
       ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);

@@ -86,8 +86,11 @@ def test_dense_topk_random_data_ranking_equals_the_fp32_query_oracle():
         _assert_same_ranking(sb, ib, rs, ri, rows, Qd)
 
 
-def test_dense_f32_rows_are_bit_exact_on_arbitrary_data():
-    """fp32 rows (the store's default, like the reference's FLOAT_VECTOR field) run on v_mfma_f32_32x32x2_f32, whose
+@pytest.mark.parametrize("prefilter", [True, False])
+def test_dense_f32_rows_are_bit_exact_on_arbitrary_data(prefilter):
+    """prefilter=True (the default): 1, 2 and 70 queries rank the bf16 image of the rows for 64 candidates and re-score them
+    with the exact chain (csrc/topk.hip "fp32 rows, bf16 prefilter") -- the same bits as the full scan, which serves 5 and 33.
+    fp32 rows (the store's default, like the reference's FLOAT_VECTOR field) run on v_mfma_f32_32x32x2_f32, whose
     result IS the oracle's sequential `acc = fmaf(x[c], q[c], acc)` chain: scores and ids equal oracle/topk_ref.c bit for
     bit on data where summation order matters (normalised Gaussian rows and queries), for every batch size -- one
     query, a partial pass, several passes -- and with ties broken by id (duplicated rows)."""
@@ -98,7 +101,7 @@ def test_dense_f32_rows_are_bit_exact_on_arbitrary_data():
         X = rng.standard_normal((n, dim)).astype(np.float32)
         X /= np.linalg.norm(X, axis=1, keepdims=True)
         X[n // 2] = X[3]                       # an exact duplicate far away: equal scores, the lower id first
-        sh = DenseShard(dim, n, "f32")
+        sh = DenseShard(dim, n, "f32", prefilter=prefilter)
         sh.add(X[: n // 3])
         sh.add(X[n // 3:])                     # appended in two calls
         for nq in (1, 2, 5, 33, 70):
@@ -510,3 +513,28 @@ def test_dense_topk_tiled_candidate_overflow_is_rescued():
     rs, ri = T.dense_topk(X, Q, k)
     assert np.array_equal(i[0], np.arange(n - 1, n - 1 - k, -1)) and np.array_equal(i[1], np.arange(k))
     assert np.array_equal(i, ri) and np.array_equal(s, rs)
+
+
+def test_dense_f32_prefilter_falls_back_when_scores_bunch():
+    """300 copies of one row (and 300 near-copies, 1e-4 apart -- inside the image's error bound): the 64 best approximate
+    scores cannot be separated from the rest, the sufficiency test fails and the full fp32 scan answers -- ids ascending among
+    the exact ties, near-copies ranked by their exact scores.  Un-normalised rows far from the query keep the bound large."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(31)
+    n, dim = 20_000, 256
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    base = X[7].copy()
+    dup = rng.choice(np.arange(100, n), size=600, replace=False)
+    X[dup[:300]] = base
+    X[dup[300:]] = base + (1e-4 * rng.standard_normal((300, dim))).astype(np.float32)
+    Q = rng.standard_normal((70, dim)).astype(np.float32)
+    Q[0] = base
+    sh = DenseShard(dim, n, "f32")
+    sh.add(X)
+    for qs in (Q[:1], Q[:2], Q):
+        s, i = sh.search(qs, 16)
+        rs, ri = T.dense_topk(X, qs, 16)
+        assert np.array_equal(i, ri) and np.array_equal(s, rs), len(qs)
+    sh.close()
+    assert set(ri[0][:8].tolist()) <= set([7] + dup.tolist())

@@ -1180,6 +1180,81 @@ __global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* _
   }
 }
 
+// ------------------------------------------------------------------------------------ fp32 rows, bf16 prefilter
+// The store's default rows are fp32 and its contract bit-exact (scores = the oracle's sequential fmaf chain), which costs a
+// full 4-byte-per-element scan per query batch (1.03 ms for one query over 1.25 M x 768 rows).  With a bf16 image of the rows
+// beside them (dtype 2) a search first ranks the IMAGE -- half the bytes, and the batched routes above -- for the 64 best
+// approximate scores a_r per query, then re-scores those 64 rows exactly.  Why that is still exact: bf16 rounding moves every
+// element by at most 2^-9 of itself, so  |a_r - e_r| <= eps = (2^-9 + 2^-16 + 4 dim 2^-24) max||x|| ||q||  (Cauchy-Schwarz; the
+// second term is the query's (value, remainder) pair in the batched routes, the third two generous fp32 accumulation terms).
+// Every row outside the 64 has a_r <= a_64, hence e_r <= a_64 + eps; the k best approximate rows have e_r >= a_k - eps.  If
+//     a_64 + eps < a_k - eps
+// every outside row is strictly below k candidates in exact score, so the exact top-k lies inside the 64 -- found by the exact
+// chain on 64 rows.  If the inequality fails for a query (scores bunched within 2 eps: near-duplicate rows) its flag is set and
+// the caller re-answers the batch with the full fp32 scan: correctness never rests on the data.
+constexpr int PFK = 64;   // candidates per query (one device pass of the approximate search)
+
+// fp32 rows -> bf16 image + the maximum squared row norm (one wave per row)
+__global__ __launch_bounds__(256) void prefilter_image_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n_rows,
+                                                               int dim, float* __restrict__ norm2_max) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= n_rows) return;
+  const float* x = src + (size_t)r * dim;
+  bf16_t* y = dst + (size_t)r * dim;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < dim; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = (bf16_t)v[j];
+      s2 = fmaf(v[j], v[j], s2);
+    }
+    *reinterpret_cast<bf16x4*>(y + c) = o;
+  }
+  s2 = wave_sum(s2) * 1.0001f;   // the sum's own rounding
+  if (lane == 0 && s2 == s2) atomicMax(reinterpret_cast<unsigned*>(norm2_max), __builtin_bit_cast(unsigned, s2));
+}
+
+// One wave per query: the 64 approximate candidates (keys sorted descending, 0 = none) -> sufficiency test, exact chain per
+// candidate (lane = candidate; c ascending from acc = 0: the oracle's arithmetic), exact keys ranked by counting.
+__global__ __launch_bounds__(64) void prefilter_rescore_kernel(const u64* __restrict__ approx, const float* __restrict__ rows, int dim,
+                                                                const float* __restrict__ queries, const float* __restrict__ eps, int k,
+                                                                u64* __restrict__ out, unsigned* __restrict__ flag) {
+  __shared__ u64 keys[PFK];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const u64 ak = approx[(size_t)q * PFK + lane];
+  const float a_k = unorderable((unsigned)(approx[(size_t)q * PFK + (k - 1)] >> 32));
+  const u64 last = approx[(size_t)q * PFK + (PFK - 1)];
+  const bool k_full = approx[(size_t)q * PFK + (k - 1)] != 0ull;
+  // a short list holds every row of the shard: nothing is outside it
+  const bool ok = last == 0ull || (k_full && unorderable((unsigned)(last >> 32)) + eps[q] < a_k - eps[q]);
+  if (lane == 0) flag[q] = ok ? 0u : 1u;
+  u64 key = 0ull;
+  if (ak != 0ull) {
+    const unsigned row = 0xFFFFFFFFu - (unsigned)(ak & 0xFFFFFFFFu);
+    const float* x = rows + (size_t)row * dim;
+    const float* qv = queries + (size_t)q * dim;
+    float acc = 0.f;
+    for (int c = 0; c < dim; c += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + c);
+      const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __fmaf_rn(xv[j], qq[j], acc);
+    }
+    key = make_key(acc, row);
+  }
+  keys[lane] = key;
+  __syncthreads();
+  int rank = 0;
+  for (int i = 0; i < PFK; ++i) rank += keys[i] > key ? 1 : 0;
+  if (key != 0ull && rank < k) out[(size_t)q * k + rank] = key;
+  int n_live = 0;
+  for (int i = 0; i < PFK; ++i) n_live += keys[i] != 0ull ? 1 : 0;
+  if (lane >= n_live && lane < k) out[(size_t)q * k + lane] = 0ull;   // fewer rows than k
+}
+
 static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size) {
   static const bool off = getenv("VRAG_TOPK_NO_TILED") != nullptr;   // A/B against the 32-query passes
   return !off && dtype == 0 && dim % 64 == 0 && nq >= 64 && k <= KMAX && size >= 4096;
@@ -1312,13 +1387,18 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     for (int q = 0; q < QB / 2; ++q) acc2[q] = f32x2{0.f, 0.f};
     auto term = [&](unsigned t, float v1) {   // acc[q] = fma(v1, W[uid][q], acc[q]) for every query, two per v_pk_fma_f32
       const unsigned uid = tmap[t];
-      const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
-      const f32x2 vv = splat2(v1);
+      // Only the lanes whose term is in the pass's union (a few per cent) read weight rows: the other lanes would add
+      // v * 0 -- exactly nothing -- and their LDS reads were what a pass spent its time on (16 queries per pass ran at the
+      // per-query cost of 8: profiles/r05_sparse_lines.json).  The branch is per lane (exec mask); a wave with no hit skips.
+      if (uid != 0u) {
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
+        const f32x2 vv = splat2(v1);
 #pragma unroll
-      for (int g4 = 0; g4 < QB / 4; ++g4) {
-        const f32x4 w4 = wrow[g4];
-        acc2[2 * g4] = pk_fma(vv, f32x2{w4[0], w4[1]}, acc2[2 * g4]);
-        acc2[2 * g4 + 1] = pk_fma(vv, f32x2{w4[2], w4[3]}, acc2[2 * g4 + 1]);
+        for (int g4 = 0; g4 < QB / 4; ++g4) {
+          const f32x4 w4 = wrow[g4];
+          acc2[2 * g4] = pk_fma(vv, f32x2{w4[0], w4[1]}, acc2[2 * g4]);
+          acc2[2 * g4 + 1] = pk_fma(vv, f32x2{w4[2], w4[3]}, acc2[2 * g4 + 1]);
+        }
       }
     };
     auto consume = [&](const u32x2& cg, const f32x4& vg) {   // the document's term order; weight rows of two terms in flight
@@ -1608,6 +1688,15 @@ struct vrag_dense_index {
   float* d_tthrs = nullptr;
   unsigned* d_tcnt = nullptr;   // [nq] counters followed by [nq] overflow flags
   size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0;
+  // fp32 rows with a bf16 prefilter copy (dtype 2 at creation; `dtype` stays 1: the contract is the fp32 rows')
+  void* rows16 = nullptr;          // bf16 image of `rows`
+  float* d_norm2 = nullptr;        // device scalar: max squared row norm (bits ordered as unsigned: norms are >= 0)
+  float norm2_max = 0.f;           // its host copy, refreshed by add()
+  float* d_pf_eps = nullptr;       // [nq] per-query error bound of the approximate scores
+  u64* d_pf_out = nullptr;         // [nq][k] exact keys of the rescored candidates
+  unsigned* d_pf_flag = nullptr;   // [nq] 1 = the candidates do not provably contain the exact top-k
+  size_t d_pf_eps_elems = 0, d_pf_out_elems = 0, d_pf_flag_elems = 0;
+  long long pf_searches = 0, pf_fallbacks = 0;
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
   hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
@@ -1709,8 +1798,9 @@ __global__ void tiled_init_kernel(int nq, u64* __restrict__ thr_key, float* __re
 }
 
 // The tiled batched search on the resident queries (ix->d_q, fp32): leaves the [nq, k] keys in ix->d_out.  Kernels only.
-int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st) {
+int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, const void* rows_bf16 = nullptr) {
   const int dim = ix->dim, pairs = ix->resident_split;
+  if (!rows_bf16) rows_bf16 = ix->rows;
   const int n_cols = pairs ? 2 * nq : nq;
   const int n_pad = (n_cols + 255) / 256 * 256;
   int rc;
@@ -1736,7 +1826,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st) {
   for (int stage = 0; lo < n; ++stage) {
     GemmParams g{};
     g.op_dtype = kOpBf16;
-    g.A = reinterpret_cast<const bf16_t*>(ix->rows) + (size_t)lo * dim;
+    g.A = reinterpret_cast<const bf16_t*>(rows_bf16) + (size_t)lo * dim;
     g.W = ix->d_tw;
     g.M = (int)(hi - lo);
     g.N = n_pad;
@@ -1759,7 +1849,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st) {
     hi = std::min<long long>(n, hi * TRATIO);
   }
   const size_t lds = (size_t)dim * sizeof(float) + (size_t)16 * k * sizeof(u64);
-  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(ix->rows), n, dim,
+  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n, dim,
                      ix->d_q, k, ovf, ix->d_out);
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
@@ -1768,8 +1858,11 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st) {
 // One device pass (k <= KMAX) of a dense search: uploads the queries, runs phase 1 + the per-query merge and leaves the
 // [nq, k] keys in ix->d_out.  Returns once the query upload has been consumed (the caller's buffer may be reused); the
 // kernels are only enqueued.  Caller holds ix->mu and has set the device.
-int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st) {
-  const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
+int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, bool image = false) {
+  // image: rank the bf16 prefilter image of an fp32 index instead of its rows (the approximate pass of the prefilter route)
+  const int dtype = image ? 0 : ix->dtype;
+  const void* rows = image ? ix->rows16 : ix->rows;
+  const int n_wg = dense_n_wg(dtype, ix->dim, nq, k, ix->size);
   int rc;
   if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));   // a device-resident search may still be reading the scratch
   if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * ix->dim))) return rc;
@@ -1785,7 +1878,7 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   // Recorded for whatever kernel family serves these queries now or in a later run_resident with another (nq, k).
   static const bool no_split = getenv("VRAG_TOPK_NO_SPLIT") != nullptr;
   ix->resident_split = 0;
-  if (!no_split && ix->dtype == 0) {
+  if (!no_split && dtype == 0) {
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(queries);
     const size_t n_el = (size_t)nq * ix->dim;
     for (size_t i = 0; i < n_el; ++i)
@@ -1797,10 +1890,10 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   HIP_TRY(hipEventSynchronize(ix->upload_done));
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
-  } else if (dense_use_tiled(ix->dtype, ix->dim, nq, k, (long long)ix->size)) {
-    if ((rc = dense_tiled_search(ix, nq, k, st))) return rc;
+  } else if (dense_use_tiled(dtype, ix->dim, nq, k, (long long)ix->size)) {
+    if ((rc = dense_tiled_search(ix, nq, k, st, image ? rows : nullptr))) return rc;
   } else {
-    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+    HIP_TRY(dense_launch_all(dtype, rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
                              ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
     HIP_TRY(hipGetLastError());
@@ -1817,7 +1910,9 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
   *out = nullptr;
   ARG_CHECK(dim > 0 && dim % 8 == 0 && dim <= 4096, "dim must be a multiple of 8 and <= 4096 (got %d)", dim);
   ARG_CHECK(capacity > 0 && capacity < 0xFFFFFFFFll, "capacity out of range");
-  ARG_CHECK(dtype == 0 || dtype == 1, "dtype: 0 = bf16 rows, 1 = fp32 rows");
+  ARG_CHECK(dtype >= 0 && dtype <= 2, "dtype: 0 = bf16 rows, 1 = fp32 rows, 2 = fp32 rows + bf16 prefilter image");
+  const bool prefilter = dtype == 2;
+  if (prefilter) dtype = 1;   // the rows, the scores and the order are the fp32 index's; the image only narrows the scan
   if (vrag_device_count() <= device) {
     set_error("no HIP device %d visible (no CPU fallback)", device);
     return VRAG_ERR_NO_DEVICE;
@@ -1832,6 +1927,11 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
   // + two 256-row tiles: the tiled batched search reads whole GEMM tiles behind the last row (results of rows >= size are dropped)
   hipError_t e = hipMalloc(&ix->rows, ((size_t)capacity + 512) * dim * esz);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+  if (e == hipSuccess && prefilter && dim % 4 == 0) {
+    e = hipMalloc(&ix->rows16, ((size_t)capacity + 512) * dim * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norm2, sizeof(float));
+    if (e == hipSuccess) e = hipMemset(ix->d_norm2, 0, sizeof(float));
+  }
   ix->stage_rows = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)dim * 4));
   if (e == hipSuccess) {
     void* p = nullptr;
@@ -1857,7 +1957,8 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
-  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt})
+  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, ix->rows16, (void*)ix->d_norm2,
+                  (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag})
     if (p) (void)hipFree(p);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
@@ -1880,8 +1981,14 @@ int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
   for (int64_t r0 = 0; r0 < n; r0 += (int64_t)ix->stage_rows) {
     const size_t nr = (size_t)std::min<int64_t>((int64_t)ix->stage_rows, n - r0);
     if (ix->dtype == 1) {
-      HIP_TRY(hipMemcpy(reinterpret_cast<float*>(ix->rows) + (size_t)(ix->size + r0) * dim, rows + (size_t)r0 * dim,
-                        nr * dim * sizeof(float), hipMemcpyHostToDevice));
+      float* dst = reinterpret_cast<float*>(ix->rows) + (size_t)(ix->size + r0) * dim;
+      HIP_TRY(hipMemcpy(dst, rows + (size_t)r0 * dim, nr * dim * sizeof(float), hipMemcpyHostToDevice));
+      if (ix->rows16) {
+        hipLaunchKernelGGL(prefilter_image_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, 0, dst,
+                           reinterpret_cast<bf16_t*>(ix->rows16) + (size_t)(ix->size + r0) * dim, (long long)nr, (int)dim, ix->d_norm2);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+      }
     } else {
       HIP_TRY(hipMemcpy(ix->stage, rows + (size_t)r0 * dim, nr * dim * sizeof(float), hipMemcpyHostToDevice));
       hipLaunchKernelGGL(cvt_f32_bf16_flat, dim3(1024), dim3(256), 0, 0, ix->stage,
@@ -1891,6 +1998,7 @@ int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
     }
   }
   ix->size += n;
+  if (ix->rows16) HIP_TRY(hipMemcpy(&ix->norm2_max, ix->d_norm2, sizeof(float), hipMemcpyDeviceToHost));
   return VRAG_OK;
 }
 
@@ -1906,6 +2014,12 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
   const size_t dim = ix->dim, off = (size_t)ix->size * dim, cnt = (size_t)n * dim;
   if (ix->dtype == 1) {
     HIP_TRY(hipMemcpyAsync(reinterpret_cast<float*>(ix->rows) + off, rows, cnt * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (ix->rows16) {
+      hipLaunchKernelGGL(prefilter_image_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rows,
+                         reinterpret_cast<bf16_t*>(ix->rows16) + off, (long long)n, (int)dim, ix->d_norm2);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&ix->norm2_max, ix->d_norm2, sizeof(float), hipMemcpyDeviceToHost, st));
+    }
   } else {
     hipLaunchKernelGGL(cvt_f32_bf16_flat, dim3(2048), dim3(256), 0, st, rows, reinterpret_cast<bf16_t*>(ix->rows) + off, cnt);
     HIP_TRY(hipGetLastError());
@@ -1947,8 +2061,44 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
     }, scores, ids);
   }
   int rc;
-  if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
   std::vector<u64> keys((size_t)nq * k);
+  // fp32 rows with a prefilter image: rank the image for 64 candidates per query, re-score them exactly (see the kernels).
+  // Where it pays: one or two queries (half the bytes of the fp32 scan) and batches the tiled search takes (the shard read once
+  // instead of once per 32 queries); in between the 32-queries-per-pass exact kernel is already the faster route.  An index
+  // whose data keeps failing the sufficiency test (near-duplicate rows) stops trying.
+  const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq <= 2 || nq >= 64) &&
+                       !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
+  if (pf_live) {
+    if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
+    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k))) return rc;
+    if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
+    const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * ix->dim / 16777216.0;
+    const double xmax = std::sqrt((double)ix->norm2_max);
+    std::vector<float> eps((size_t)nq);
+    for (int q = 0; q < nq; ++q) {
+      double s2 = 0.0;
+      for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
+      eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
+    }
+    if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
+                       ix->d_q, ix->d_pf_eps, k, ix->d_pf_out, ix->d_pf_flag);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned> flags((size_t)nq);
+    HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags.data(), ix->d_pf_flag, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // also retires the eps upload before `eps` goes out of scope
+    ++ix->pf_searches;
+    bool bad = false;
+    for (unsigned f : flags) bad = bad || f != 0u;
+    if (!bad) {
+      decode_keys(keys, nq, k, 0, nullptr, scores, ids);
+      return VRAG_OK;
+    }
+    ++ix->pf_fallbacks;   // scores bunched within the image's error bound: the full fp32 scan answers
+  }
+  if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
   HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   decode_keys(keys, nq, k, 0, nullptr, scores, ids);

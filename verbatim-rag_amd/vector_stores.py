@@ -225,13 +225,16 @@ def convert_hits_to_results(hits: List[dict], dynamic_fields: Optional[List[str]
 class DenseShard:
     """One GPU's slice of the dense corpus (rows appended in order; ids are local row numbers)."""
 
-    def __init__(self, dim: int, capacity: int, dtype: str = "bf16", device: int = 0):
+    def __init__(self, dim: int, capacity: int, dtype: str = "bf16", device: int = 0, prefilter: bool = True):
+        """dtype "bf16" | "f32".  fp32 rows keep a bf16 prefilter image beside them unless `prefilter=False` (+50 % memory):
+        a search ranks the image for 64 candidates per query and re-scores those exactly -- same bits as the full fp32 scan
+        (include/vrag_amd.h, dtype 2), a third of the time for one query and a tenth for a batch of 256."""
         self._lib = _lib.load()
         _lib.require_gpu()
         self.dim, self.capacity = dim, capacity
         self._h = C.c_void_p()
-        _lib.check("vrag_dense_index_create", self._lib.vrag_dense_index_create(
-            dim, capacity, 0 if dtype == "bf16" else 1, device, C.byref(self._h)))
+        code = 0 if dtype == "bf16" else (2 if prefilter and dim % 4 == 0 else 1)
+        _lib.check("vrag_dense_index_create", self._lib.vrag_dense_index_create(dim, capacity, code, device, C.byref(self._h)))
 
     def add(self, rows: np.ndarray) -> None:
         rows = np.ascontiguousarray(rows, dtype=np.float32)

@@ -1192,7 +1192,8 @@ __global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* _
 // every outside row is strictly below k candidates in exact score, so the exact top-k lies inside the 64 -- found by the exact
 // chain on 64 rows.  If the inequality fails for a query (scores bunched within 2 eps: near-duplicate rows) its flag is set and
 // the caller re-answers the batch with the full fp32 scan: correctness never rests on the data.
-constexpr int PFK = 64;   // candidates per query (one device pass of the approximate search)
+constexpr int PFK = 64;   // candidates per query in a batch (the tiled search delivers 64 at no extra cost); one or two queries take
+constexpr int PFK_FEW = 32;   // 32: their per-workgroup lists are merged by the k <= 32 list merge (the k = 64 scan merge takes ms)
 
 // fp32 rows -> bf16 image + the maximum squared row norm (one wave per row)
 __global__ __launch_bounds__(256) void prefilter_image_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n_rows,
@@ -1221,13 +1222,13 @@ __global__ __launch_bounds__(256) void prefilter_image_kernel(const float* __res
 // candidate (lane = candidate; c ascending from acc = 0: the oracle's arithmetic), exact keys ranked by counting.
 __global__ __launch_bounds__(64) void prefilter_rescore_kernel(const u64* __restrict__ approx, const float* __restrict__ rows, int dim,
                                                                 const float* __restrict__ queries, const float* __restrict__ eps, int k,
-                                                                u64* __restrict__ out, unsigned* __restrict__ flag) {
+                                                                int pfk, u64* __restrict__ out, unsigned* __restrict__ flag) {
   __shared__ u64 keys[PFK];
   const int q = blockIdx.x, lane = threadIdx.x;
-  const u64 ak = approx[(size_t)q * PFK + lane];
-  const float a_k = unorderable((unsigned)(approx[(size_t)q * PFK + (k - 1)] >> 32));
-  const u64 last = approx[(size_t)q * PFK + (PFK - 1)];
-  const bool k_full = approx[(size_t)q * PFK + (k - 1)] != 0ull;
+  const u64 ak = lane < pfk ? approx[(size_t)q * pfk + lane] : 0ull;
+  const float a_k = unorderable((unsigned)(approx[(size_t)q * pfk + (k - 1)] >> 32));
+  const u64 last = approx[(size_t)q * pfk + (pfk - 1)];
+  const bool k_full = approx[(size_t)q * pfk + (k - 1)] != 0ull;
   // a short list holds every row of the shard: nothing is outside it
   const bool ok = last == 0ull || (k_full && unorderable((unsigned)(last >> 32)) + eps[q] < a_k - eps[q]);
   if (lane == 0) flag[q] = ok ? 0u : 1u;
@@ -1410,7 +1411,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     };
     // Two register sets of G groups (4 G terms): the loads of step i + 1 are in flight while step i is consumed -- one 16-wave
     // workgroup per CU (the term map fills the LDS), so the bytes in flight per lane are what covers the memory latency.
-    constexpr int G = QB > 8 ? 2 : 4;   // 16 queries: 16 accumulators + four weight rows in flight leave room for two 8-term sets
+    constexpr int G = QB > 8 ? 3 : 5;   // 16 queries: 16 accumulators + four weight rows in flight leave room for two 8-term sets
     u32x2 ca[G], cb[G];
     f32x4 va[G], vb[G];
     auto load = [&](u32x2 (&cd)[G], f32x4 (&vd)[G], int g0) {
@@ -1428,12 +1429,19 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (ng > 0) load(ca, va, 0);
-    for (int g0 = 0; g0 < ng; g0 += 2 * G) {
-      if (g0 + G < ng) load(cb, vb, g0 + G);
-      eat(ca, va, g0);
-      if (g0 + 2 * G < ng) load(ca, va, g0 + 2 * G);
-      if (g0 + G < ng) eat(cb, vb, g0 + G);
+    // Every load is issued unconditionally (group indices clamp to the slice's last group; what a tail re-reads is not consumed):
+    // the number of loads in flight is then a compile-time fact and the wait in front of a set leaves the OTHER set's loads
+    // outstanding (s_waitcnt vmcnt(2 G)).  With the loads under `if (more)` the compiler had to drain everything at each join
+    // -- no overlap at all, and a pass ran at the pace of one set per memory round trip (profiles/r05_sparse_lines.json).
+    if (ng > 0) {
+      load(ca, va, 0);
+      load(cb, vb, G);
+      for (int g0 = 0; g0 < ng; g0 += 2 * G) {
+        eat(ca, va, g0);
+        load(ca, va, g0 + 2 * G);
+        eat(cb, vb, g0 + G);
+        load(cb, vb, g0 + 3 * G);
+      }
     }
     float acc[QB];
 #pragma unroll
@@ -2080,10 +2088,11 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
       eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
     }
-    if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
+    const int pfk = nq <= 2 ? PFK_FEW : PFK;
+    if ((rc = dense_search_enqueue(ix, queries, nq, pfk, st, /*image=*/true))) return rc;
     HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
-                       ix->d_q, ix->d_pf_eps, k, ix->d_pf_out, ix->d_pf_flag);
+                       ix->d_q, ix->d_pf_eps, k, pfk, ix->d_pf_out, ix->d_pf_flag);
     HIP_TRY(hipGetLastError());
     std::vector<unsigned> flags((size_t)nq);
     HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));

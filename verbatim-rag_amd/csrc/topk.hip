@@ -74,6 +74,23 @@ __device__ __forceinline__ void wave_insert_topk(u64* list, int k, u64 key, int 
   }
 }
 
+// The same behind a shard-wide entry threshold (sparse kernels): thr[query] is the largest k-th key any FULL list of the query
+// has published (atomicMax, all workgroups).  A key at or below it cannot be in the query's top-k -- some list already holds k
+// keys above it -- so lists stop filling with documents that will not survive the merge: with one list per wave and a few
+// hundred documents per list, filling and refining every list was where a batched pass spent two thirds of its time (round 5).
+__device__ __forceinline__ void wave_insert_topk_gated(u64* list, int k, u64 key, int lane, u64* thr, u64 shared) {
+  const u64 kth = list[k - 1];
+  const u64 bar = kth > shared ? kth : shared;
+  if (!__ballot(key > bar)) return;
+  wave_insert_topk(list, k, key > bar ? key : 0ull, lane);
+  const u64 nk = list[k - 1];   // non-zero = the list is full
+  if (lane == 0 && nk > shared) atomicMax(reinterpret_cast<unsigned long long*>(thr), (unsigned long long)nk);
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------ dense
 constexpr int DQT = 4;        // queries per pass
 constexpr int DROWS_MIN = 32;    // rows per workgroup iteration; rows per workgroup = a multiple of this, chosen at launch
@@ -1192,8 +1209,7 @@ __global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* _
 // every outside row is strictly below k candidates in exact score, so the exact top-k lies inside the 64 -- found by the exact
 // chain on 64 rows.  If the inequality fails for a query (scores bunched within 2 eps: near-duplicate rows) its flag is set and
 // the caller re-answers the batch with the full fp32 scan: correctness never rests on the data.
-constexpr int PFK = 64;   // candidates per query in a batch (the tiled search delivers 64 at no extra cost); one or two queries take
-constexpr int PFK_FEW = 32;   // 32: their per-workgroup lists are merged by the k <= 32 list merge (the k = 64 scan merge takes ms)
+constexpr int PFK = 64;   // candidates per query of a batch (the tiled search delivers 64 at no extra cost)
 
 // fp32 rows -> bf16 image + the maximum squared row norm (one wave per row)
 __global__ __launch_bounds__(256) void prefilter_image_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n_rows,
@@ -1256,6 +1272,106 @@ __global__ __launch_bounds__(64) void prefilter_rescore_kernel(const u64* __rest
   if (lane >= n_live && lane < k) out[(size_t)q * k + lane] = 0ull;   // fewer rows than k
 }
 
+// One or two queries: ONE streaming pass over the image collects every row that can be in the exact top-k.  A prefix of the
+// shard is ranked first (exact top-k of the IMAGE scores over the first rows: t0 = its k-th score).  The exact k-th score over
+// the whole shard is at least the exact k-th over the prefix, which is at least t0 - eps; so a row of the exact top-k has
+// e_r >= t0 - eps, hence a_r >= t0 - 2 eps: the pass appends exactly the rows with a_r >= t0 - 2 eps to a candidate list (no
+// lists to maintain, no merge), the candidates are re-scored with the exact chain and sorted.  More candidates than the
+// list holds (flat score distributions) = fall back to the full fp32 scan.
+constexpr int PFCAP = 4096;           // candidate slots per query
+constexpr long long PFPREFIX = 32768; // rows ranked first for the entry threshold
+template <int DIMC>
+__global__ __launch_bounds__(256) void prefilter_collect_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
+                                                                 const float* __restrict__ query, const u64* __restrict__ kth_key,
+                                                                 const float* __restrict__ eps, unsigned* __restrict__ cnt,
+                                                                 unsigned* __restrict__ cand_rows, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
+  for (int i = tid; i < dim; i += 256) sq[i] = query[i];
+  __syncthreads();
+  float qreg[DIMC > 0 ? DIMC * 8 : 1];
+  if constexpr (DIMC > 0) {
+#pragma unroll
+    for (int i = 0; i < DIMC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qreg[i * 8 + j] = sq[gl * 8 + i * 128 + j];
+  }
+  const u64 kk = *kth_key;
+  const float tau = kk ? unorderable((unsigned)(kk >> 32)) - 2.f * eps[0] : -INFINITY;
+  const long long r_begin = (long long)blockIdx.x * rows_per_wg, r_end = min(n_rows, r_begin + rows_per_wg);
+  for (long long r = r_begin + grp; r < r_end; r += 32) {
+    const bool has2 = r + 16 < r_end;
+    const char* row0 = reinterpret_cast<const char*>(rows + (size_t)r * dim) + (size_t)gl * 16;
+    const char* row1 = has2 ? row0 + (size_t)16 * dim * 2 : row0;
+    float acc0 = 0.f, acc1 = 0.f;
+    if constexpr (DIMC > 0) {
+      f32x4 raw0[DIMC], raw1[DIMC];
+#pragma unroll
+      for (int i = 0; i < DIMC; ++i) {
+        raw0[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row0 + (size_t)i * 256));
+        raw1[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row1 + (size_t)i * 256));
+      }
+#pragma unroll
+      for (int i = 0; i < DIMC; ++i) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, raw0[i]), b = __builtin_bit_cast(bf16x8, raw1[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc0 = fmaf((float)a[j], qreg[i * 8 + j], acc0);
+          acc1 = fmaf((float)b[j], qreg[i * 8 + j], acc1);
+        }
+      }
+    } else {
+      for (int c = gl * 8; c < dim; c += 128) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(rows + (size_t)r * dim + c);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(rows + (size_t)(has2 ? r + 16 : r) * dim + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc0 = fmaf((float)a[j], sq[c + j], acc0);
+          acc1 = fmaf((float)b[j], sq[c + j], acc1);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      acc0 += __shfl_xor(acc0, o, 64);
+      acc1 += __shfl_xor(acc1, o, 64);
+    }
+    if (gl == 0) {
+      if (acc0 >= tau) {
+        const unsigned slot = atomicAdd(cnt, 1u);
+        if (slot < (unsigned)PFCAP) cand_rows[slot] = (unsigned)r;
+      }
+      if (has2 && acc1 >= tau) {
+        const unsigned slot = atomicAdd(cnt, 1u);
+        if (slot < (unsigned)PFCAP) cand_rows[slot] = (unsigned)(r + 16);
+      }
+    }
+  }
+}
+
+// exact keys of the collected rows (lane = candidate; the oracle's chain), zero keys behind them
+__global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsigned* __restrict__ cand_rows, const unsigned* __restrict__ cnt,
+                                                                      const float* __restrict__ rows, int dim,
+                                                                      const float* __restrict__ query, u64* __restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PFCAP) return;
+  u64 key = 0ull;
+  if ((unsigned)i < min(*cnt, (unsigned)PFCAP)) {
+    const unsigned row = cand_rows[i];
+    const float* x = rows + (size_t)row * dim;
+    float acc = 0.f;
+    for (int c = 0; c < dim; c += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + c);
+      const f32x4 qq = *reinterpret_cast<const f32x4*>(query + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __fmaf_rn(xv[j], qq[j], acc);
+    }
+    key = make_key(acc, row);
+  }
+  keys[i] = key;
+}
+
 static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size) {
   static const bool off = getenv("VRAG_TOPK_NO_TILED") != nullptr;   // A/B against the 32-query passes
   return !off && dtype == 0 && dim % 64 == 0 && nq >= 64 && k <= KMAX && size >= 4096;
@@ -1270,7 +1386,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
                                                             long long n_docs, const float* __restrict__ qdense, int vocab,
                                                             int nq, int q, int k, int slices_per_wg,
                                                             u64* __restrict__ cand, const unsigned* __restrict__ docid,
-                                                            const u64* __restrict__ bound) {
+                                                            const u64* __restrict__ bound, u64* __restrict__ thr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: [16 waves][k] lists, then (LDSQ) the dense query vector
   u64* lists = reinterpret_cast<u64*>(smem);
@@ -1316,7 +1432,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
     // the key carries the caller's document index (not the sorted position): ties order by id ascending
     const u64 key = hit ? make_key_below(acc, docid[doc], bound ? bound[q] : ~0ull) : 0ull;
-    wave_insert_topk(mylist, k, key, lane);
+    wave_insert_topk_gated(mylist, k, key, lane, thr + q, __hip_atomic_load(thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
   __syncthreads();
   if (tid == 0) {
@@ -1360,7 +1476,8 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
                                                                  long long n_docs, const unsigned short* __restrict__ qmap,
                                                                  const float* __restrict__ qw, int vocab, int n_union,
                                                                  int nq, int q0, int k, int slices_per_wg,
-                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid) {
+                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid,
+                                                                 u64* __restrict__ thr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
@@ -1448,11 +1565,13 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     for (int q = 0; q < QB; ++q) acc[q] = acc2[q >> 1][q & 1];
     const long long doc = (long long)s * 64 + lane;
     const unsigned did = doc < n_docs ? docid[doc] : 0u;
+    // lane q holds the shard-wide entry threshold of query q0 + q as of now
+    const u64 tq = (lane < QB && q0 + lane < nq) ? __hip_atomic_load(thr + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
       const u64 key = hit ? make_key(acc[q], did) : 0ull;
-      wave_insert_topk(mylists + q * k, k, key, lane);
+      wave_insert_topk_gated(mylists + q * k, k, key, lane, thr + q0 + q, readlane_u64(tq, q));
     }
   }
   __syncthreads();
@@ -1704,6 +1823,10 @@ struct vrag_dense_index {
   u64* d_pf_out = nullptr;         // [nq][k] exact keys of the rescored candidates
   unsigned* d_pf_flag = nullptr;   // [nq] 1 = the candidates do not provably contain the exact top-k
   size_t d_pf_eps_elems = 0, d_pf_out_elems = 0, d_pf_flag_elems = 0;
+  unsigned* d_pf_cand = nullptr;   // [2][PFCAP] candidate rows of the one-pass route (1-2 queries)
+  u64* d_pf_keys = nullptr;        // [2][PFCAP] their exact keys
+  unsigned* d_pf_cnt = nullptr;    // [2] counters + [2] overflow flags
+  u64* d_pf_thr = nullptr;         // [2] selection kernel's threshold outputs (unused) + float[2]
   long long pf_searches = 0, pf_fallbacks = 0;
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
@@ -1725,6 +1848,8 @@ struct vrag_sparse_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
+  u64* d_thr = nullptr;               // [nq] shard-wide entry thresholds of a search (see wave_insert_topk_gated)
+  size_t d_thr_elems = 0;
   unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
@@ -1966,7 +2091,8 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, ix->rows16, (void*)ix->d_norm2,
-                  (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag})
+                  (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag, (void*)ix->d_pf_cand, (void*)ix->d_pf_keys, (void*)ix->d_pf_cnt,
+                  (void*)ix->d_pf_thr})
     if (p) (void)hipFree(p);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
@@ -2088,16 +2214,66 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
       eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
     }
-    const int pfk = nq <= 2 ? PFK_FEW : PFK;
-    if ((rc = dense_search_enqueue(ix, queries, nq, pfk, st, /*image=*/true))) return rc;
-    HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
-                       ix->d_q, ix->d_pf_eps, k, pfk, ix->d_pf_out, ix->d_pf_flag);
-    HIP_TRY(hipGetLastError());
     std::vector<unsigned> flags((size_t)nq);
-    HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(flags.data(), ix->d_pf_flag, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));   // also retires the eps upload before `eps` goes out of scope
+    if (nq <= 2) {
+      // one streaming pass over the image per query (prefilter_collect_kernel): prefix ranking -> entry threshold -> candidates
+      const int dim = ix->dim;
+      const long long prefix = std::min<long long>(PFPREFIX, (long long)ix->size);
+      const int n_wg0 = dense_n_wg(0, dim, nq, k, prefix);
+      size_t unused = 0;
+      if (!ix->d_pf_cand) {
+        if ((rc = grow(&ix->d_pf_cand, &unused, (size_t)2 * PFCAP))) return rc;
+        unused = 0;
+        if ((rc = grow(&ix->d_pf_keys, &unused, (size_t)2 * PFCAP))) return rc;
+        unused = 0;
+        if ((rc = grow(&ix->d_pf_cnt, &unused, (size_t)4))) return rc;
+        unused = 0;
+        if ((rc = grow(&ix->d_pf_thr, &unused, (size_t)4))) return rc;
+      }
+      if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim))) return rc;
+      if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg0 * nq * k))) return rc;
+      if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
+      HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemsetAsync(ix->d_pf_cnt, 0, 4 * sizeof(unsigned), st));
+      ix->resident_split = 0;
+      HIP_TRY(dense_launch_all(0, ix->rows16, prefix, dim, ix->d_q, nq, k, ix->d_cand, n_wg0, st, ix->d_out + (size_t)nq * k, ix->d_out));
+      HIP_TRY(launch_topk_merge(ix->d_cand, n_wg0, nq, k, ix->d_out, st));
+      const int per = dense_rows_per_wg((long long)ix->size);
+      const int wgs = (int)(((long long)ix->size + per - 1) / per);
+      const int dimc = dim % 128 == 0 ? dim / 128 : 0;
+      for (int q = 0; q < nq; ++q) {
+        const bf16_t* img = reinterpret_cast<const bf16_t*>(ix->rows16);
+        const float* dq = ix->d_q + (size_t)q * dim;
+        const u64* kth = ix->d_out + (size_t)q * k + (k - 1);
+        unsigned* cand = ix->d_pf_cand + (size_t)q * PFCAP;
+        const size_t lds = (size_t)dim * sizeof(float);
+#define VRAG_PF_COLLECT(DC_) hipLaunchKernelGGL((prefilter_collect_kernel<DC_>), dim3(wgs), dim3(256), lds, st, img, (long long)ix->size, dim, dq, kth, \
+                                                 ix->d_pf_eps + q, ix->d_pf_cnt + q, cand, per)
+        if (dimc == 6) VRAG_PF_COLLECT(6);
+        else if (dimc == 3) VRAG_PF_COLLECT(3);
+        else if (dimc == 8) VRAG_PF_COLLECT(8);
+        else VRAG_PF_COLLECT(0);
+#undef VRAG_PF_COLLECT
+        hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 256), dim3(256), 0, st, cand, ix->d_pf_cnt + q,
+                           reinterpret_cast<const float*>(ix->rows), dim, dq, ix->d_pf_keys + (size_t)q * PFCAP);
+        HIP_TRY(hipGetLastError());
+      }
+      hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)PFCAP * sizeof(u64), st, ix->d_pf_keys, ix->d_pf_cnt, PFCAP, k,
+                         ix->d_pf_thr, reinterpret_cast<float*>(ix->d_pf_thr + 2), ix->d_pf_out, ix->d_pf_cnt + 2, 0);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(flags.data(), ix->d_pf_cnt + 2, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    } else {
+      if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
+      HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
+                         ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(flags.data(), ix->d_pf_flag, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));   // also retires the query / eps uploads before the host buffers go out of scope
     ++ix->pf_searches;
     bool bad = false;
     for (unsigned f : flags) bad = bad || f != 0u;
@@ -2253,6 +2429,7 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->d_docid) (void)hipFree(ix->d_docid);
+  if (ix->d_thr) (void)hipFree(ix->d_thr);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -2293,6 +2470,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   *n_wg_out = n_wg;
+  {
+    int rc = grow(&ix->d_thr, &ix->d_thr_elems, (size_t)nq);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ix->d_thr, 0, (size_t)nq * sizeof(u64), st));
+  }
   if (ix->last_multi) {
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
@@ -2310,11 +2492,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
       if (QB == 16)
         hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, ix->d_thr);
       else
         hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, ix->d_thr);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
@@ -2335,11 +2517,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     if (ldsq)
       hipLaunchKernelGGL((sparse_topk_kernel<true>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                          ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_q, ix->vocab, nq, q, k,
-                         slices_per_wg, ix->d_cand, ix->d_docid, bound);
+                         slices_per_wg, ix->d_cand, ix->d_docid, bound, ix->d_thr);
     else
       hipLaunchKernelGGL((sparse_topk_kernel<false>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals,
                          ix->slice_off, ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_q, ix->vocab, nq, q, k,
-                         slices_per_wg, ix->d_cand, ix->d_docid, bound);
+                         slices_per_wg, ix->d_cand, ix->d_docid, bound, ix->d_thr);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));

@@ -45,6 +45,6 @@ for nq in (1, 2, 4, 32, 256):
     dt_api = timed(lambda: sh.search(q, k))
     print(json.dumps({"kind": "dense_f32_search_call", "prefilter_image": True, "rows": n, "dim": dim, "nq": nq, "k": k,
                       "ms": dt_api * 1e3, "queries_per_s": nq / dt_api,
-                      "route": "bf16 image -> 64 candidates -> exact re-score" if (nq <= 2 or nq >= 64) else "full fp32 scan",
+                      "route": ("bf16 image, one pass: prefix threshold -> candidates -> exact re-score" if nq == 1 else "bf16 image, tiled search -> 64 candidates -> exact re-score") if (nq == 1 or nq >= 64) else "full fp32 scan",
                       "image_bytes": n * dim * 2}))
 sh.close()

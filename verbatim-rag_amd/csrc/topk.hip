@@ -56,39 +56,61 @@ __device__ __forceinline__ void insert_key(u64* list, int k, u64 key) {
   list[i] = key;
 }
 
+// Maximum of one u64 per lane over the wave, the same value in every lane: DPP steps inside each row of 16 lanes (quad permutes,
+// half-row and row mirrors: VALU only), then the four row maxima through scalar lane reads -- ~40 instructions.  The
+// __shfl_xor form is 12 ds_bpermute_b32 with a wait each (~700 cycles), and this sits on the insertion path of every list.
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+  u64 o = dpp_u64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = o > v ? o : v;
+  o = dpp_u64<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = o > v ? o : v;
+  o = dpp_u64<0x141>(v);       // row_half_mirror
+  v = o > v ? o : v;
+  o = dpp_u64<0x140>(v);       // row_mirror
+  v = o > v ? o : v;
+  u64 m = 0ull;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * r), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * r);
+    const u64 x = ((u64)hi << 32) | lo;
+    m = x > m ? x : m;
+  }
+  return m;
+}
+
 // One key per lane (0 = none) into a wave-private sorted list: the lanes' keys are taken in DESCENDING order and the loop ends
 // as soon as the largest one left cannot enter, so a wave inserts at most k keys per call -- not one per qualifying lane
 // (a wave's first slice meets an empty list: 64 serial insertions before, k now).  The result is the same list.
 __device__ __forceinline__ void wave_insert_topk(u64* list, int k, u64 key, int lane) {
   u64 kth = list[k - 1];
   while (__ballot(key > kth)) {
-    u64 mx = key;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const u64 other = __shfl_xor(mx, o, 64);
-      mx = other > mx ? other : mx;
-    }
+    const u64 mx = wave_max_u64(key);
     if (lane == 0) insert_key(list, k, mx);
     if (key == mx) key = 0ull;   // keys are unique (they carry the row id)
     kth = list[k - 1];           // LDS operations of one wave execute in order: this sees lane 0's update
   }
 }
 
-// The same behind a shard-wide entry threshold (sparse kernels): thr[query] is the largest k-th key any FULL list of the query
-// has published (atomicMax, all workgroups).  A key at or below it cannot be in the query's top-k -- some list already holds k
-// keys above it -- so lists stop filling with documents that will not survive the merge: with one list per wave and a few
-// hundred documents per list, filling and refining every list was where a batched pass spent two thirds of its time (round 5).
-__device__ __forceinline__ void wave_insert_topk_gated(u64* list, int k, u64 key, int lane, u64* thr, u64 shared) {
-  const u64 kth = list[k - 1];
+// The same behind a WORKGROUP-wide entry threshold (sparse kernels): wthr (LDS) is the largest k-th key any FULL list of the
+// query in this workgroup has reached (ds_max_u64).  A key at or below it cannot be in the workgroup's top-k for the query --
+// a sibling wave already holds k keys above it, and those go to the merge -- so the 16 per-wave lists of a workgroup stop
+// filling and refining independently: with a few hundred documents per list, that was where a batched pass spent most of
+// its time (every list re-discovers the same distribution: ~k (1 + ln(docs / k)) serial insertions per list and query).
+// (A shard-wide threshold in global memory was tried first and was slower: the publishing atomics of 8 192 lists land on
+// two cache lines and serialise -- 27 -> 63 ms per 1 000 queries, profiles/r05_sparse_lines.json.)
+__device__ __forceinline__ void wave_insert_topk_gated(u64* list, int k, u64 key, int lane, u64* wthr) {
+  const u64 kth = list[k - 1], shared = *wthr;
   const u64 bar = kth > shared ? kth : shared;
   if (!__ballot(key > bar)) return;
   wave_insert_topk(list, k, key > bar ? key : 0ull, lane);
   const u64 nk = list[k - 1];   // non-zero = the list is full
-  if (lane == 0 && nk > shared) atomicMax(reinterpret_cast<unsigned long long*>(thr), (unsigned long long)nk);
-}
-__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-  return ((u64)hi << 32) | lo;
+  if (lane == 0 && nk > shared) atomicMax(reinterpret_cast<unsigned long long*>(wthr), (unsigned long long)nk);
 }
 
 // ------------------------------------------------------------------------------------ dense
@@ -1386,8 +1408,10 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
                                                             long long n_docs, const float* __restrict__ qdense, int vocab,
                                                             int nq, int q, int k, int slices_per_wg,
                                                             u64* __restrict__ cand, const unsigned* __restrict__ docid,
-                                                            const u64* __restrict__ bound, u64* __restrict__ thr) {
+                                                            const u64* __restrict__ bound) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ u64 wthr;   // workgroup-wide entry threshold (wave_insert_topk_gated)
+  if (threadIdx.x == 0) wthr = 0ull;
   // LDS: [16 waves][k] lists, then (LDSQ) the dense query vector
   u64* lists = reinterpret_cast<u64*>(smem);
   float* sq = reinterpret_cast<float*>(smem + (size_t)16 * k * sizeof(u64));
@@ -1432,7 +1456,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
     // the key carries the caller's document index (not the sorted position): ties order by id ascending
     const u64 key = hit ? make_key_below(acc, docid[doc], bound ? bound[q] : ~0ull) : 0ull;
-    wave_insert_topk_gated(mylist, k, key, lane, thr + q, __hip_atomic_load(thr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    wave_insert_topk_gated(mylist, k, key, lane, &wthr);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1476,8 +1500,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
                                                                  long long n_docs, const unsigned short* __restrict__ qmap,
                                                                  const float* __restrict__ qw, int vocab, int n_union,
                                                                  int nq, int q0, int k, int slices_per_wg,
-                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid,
-                                                                 u64* __restrict__ thr) {
+                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
@@ -1491,6 +1514,8 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     tw[u * QB + q] = qw[(size_t)q * SUW + u];
   }
   for (int i = tid; i < 16 * QB * k; i += 1024) lists[i] = 0ull;
+  __shared__ u64 wthr[QB];   // workgroup-wide entry thresholds (wave_insert_topk_gated)
+  if (tid < QB) wthr[tid] = 0ull;
   __syncthreads();
   u64* mylists = lists + (size_t)wave * QB * k;
   const int s_begin = blockIdx.x * slices_per_wg;
@@ -1565,13 +1590,11 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     for (int q = 0; q < QB; ++q) acc[q] = acc2[q >> 1][q & 1];
     const long long doc = (long long)s * 64 + lane;
     const unsigned did = doc < n_docs ? docid[doc] : 0u;
-    // lane q holds the shard-wide entry threshold of query q0 + q as of now
-    const u64 tq = (lane < QB && q0 + lane < nq) ? __hip_atomic_load(thr + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
       const u64 key = hit ? make_key(acc[q], did) : 0ull;
-      wave_insert_topk_gated(mylists + q * k, k, key, lane, thr + q0 + q, readlane_u64(tq, q));
+      wave_insert_topk_gated(mylists + q * k, k, key, lane, wthr + q);
     }
   }
   __syncthreads();
@@ -1848,8 +1871,6 @@ struct vrag_sparse_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
-  u64* d_thr = nullptr;               // [nq] shard-wide entry thresholds of a search (see wave_insert_topk_gated)
-  size_t d_thr_elems = 0;
   unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
@@ -2200,7 +2221,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   // Where it pays: one or two queries (half the bytes of the fp32 scan) and batches the tiled search takes (the shard read once
   // instead of once per 32 queries); in between the 32-queries-per-pass exact kernel is already the faster route.  An index
   // whose data keeps failing the sufficiency test (near-duplicate rows) stops trying.
-  const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq <= 2 || nq >= 64) &&
+  const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq == 1 || nq >= 64) &&
                        !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
   if (pf_live) {
     if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
@@ -2429,7 +2450,6 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->d_docid) (void)hipFree(ix->d_docid);
-  if (ix->d_thr) (void)hipFree(ix->d_thr);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -2459,7 +2479,7 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
 constexpr int SQB_MAX = 16;
 static bool sparse_multi_fits(int vocab, int qb, int k) {
   const int vpad = (vocab + 7) & ~7;
-  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024;
+  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) + 256 <= 160 * 1024;   // + the static thresholds
 }
 static int sparse_pass_queries(int vocab, int k) {
   static const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
@@ -2470,11 +2490,7 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   const int slices_per_wg = sparse_slices_per_wg(ix);
   const int n_wg = std::max(1, (ix->n_slices + slices_per_wg - 1) / slices_per_wg);
   *n_wg_out = n_wg;
-  {
-    int rc = grow(&ix->d_thr, &ix->d_thr_elems, (size_t)nq);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ix->d_thr, 0, (size_t)nq * sizeof(u64), st));
-  }
+
   if (ix->last_multi) {
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
@@ -2492,18 +2508,18 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
       if (QB == 16)
         hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, ix->d_thr);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
       else
         hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, ix->d_thr);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
     HIP_TRY(hipGetLastError());
     return VRAG_OK;
   }
-  const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) <= 160 * 1024;
+  const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) + 64 <= 160 * 1024;   // + the static threshold
   const size_t lds = (size_t)16 * k * sizeof(u64) + (ldsq ? (size_t)ix->vocab * sizeof(float) : 0);
   if (ldsq) {
     static bool attr_set = false;
@@ -2517,11 +2533,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     if (ldsq)
       hipLaunchKernelGGL((sparse_topk_kernel<true>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                          ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_q, ix->vocab, nq, q, k,
-                         slices_per_wg, ix->d_cand, ix->d_docid, bound, ix->d_thr);
+                         slices_per_wg, ix->d_cand, ix->d_docid, bound);
     else
       hipLaunchKernelGGL((sparse_topk_kernel<false>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals,
                          ix->slice_off, ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_q, ix->vocab, nq, q, k,
-                         slices_per_wg, ix->d_cand, ix->d_docid, bound, ix->d_thr);
+                         slices_per_wg, ix->d_cand, ix->d_docid, bound);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));

@@ -1410,11 +1410,11 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
                                                             u64* __restrict__ cand, const unsigned* __restrict__ docid,
                                                             const u64* __restrict__ bound) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ u64 wthr;   // workgroup-wide entry threshold (wave_insert_topk_gated)
-  if (threadIdx.x == 0) wthr = 0ull;
-  // LDS: [16 waves][k] lists, then (LDSQ) the dense query vector
+  // LDS: [16 waves][k] lists, the workgroup-wide entry threshold (wave_insert_topk_gated), then (LDSQ) the dense query vector
   u64* lists = reinterpret_cast<u64*>(smem);
-  float* sq = reinterpret_cast<float*>(smem + (size_t)16 * k * sizeof(u64));
+  u64& wthr = lists[(size_t)16 * k];
+  if (threadIdx.x == 0) wthr = 0ull;
+  float* sq = reinterpret_cast<float*>(smem + (size_t)(16 * k + 2) * sizeof(u64));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* qv = qdense + (size_t)q * vocab;
   if constexpr (LDSQ) {
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     tw[u * QB + q] = qw[(size_t)q * SUW + u];
   }
   for (int i = tid; i < 16 * QB * k; i += 1024) lists[i] = 0ull;
-  __shared__ u64 wthr[QB];   // workgroup-wide entry thresholds (wave_insert_topk_gated)
+  u64* wthr = lists + (size_t)16 * QB * k;   // [QB] workgroup-wide entry thresholds (wave_insert_topk_gated)
   if (tid < QB) wthr[tid] = 0ull;
   __syncthreads();
   u64* mylists = lists + (size_t)wave * QB * k;
@@ -2495,7 +2495,7 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
     ARG_CHECK(sparse_multi_fits(ix->vocab, QB, k), "k = %d does not fit the batched pass the resident queries were prepared for", k);
-    const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)16 * QB * k * sizeof(u64);
+    const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)(16 * QB * k + QB) * sizeof(u64);
     static bool attr_m = false;
     if (!attr_m) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8>),
@@ -2520,7 +2520,7 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     return VRAG_OK;
   }
   const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) + 64 <= 160 * 1024;   // + the static threshold
-  const size_t lds = (size_t)16 * k * sizeof(u64) + (ldsq ? (size_t)ix->vocab * sizeof(float) : 0);
+  const size_t lds = (size_t)(16 * k + 2) * sizeof(u64) + (ldsq ? (size_t)ix->vocab * sizeof(float) : 0);
   if (ldsq) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -104,11 +104,28 @@ __device__ __forceinline__ void wave_insert_topk(u64* list, int k, u64 key, int 
 // its time (every list re-discovers the same distribution: ~k (1 + ln(docs / k)) serial insertions per list and query).
 // (A shard-wide threshold in global memory was tried first and was slower: the publishing atomics of 8 192 lists land on
 // two cache lines and serialise -- 27 -> 63 ms per 1 000 queries, profiles/r05_sparse_lines.json.)
-__device__ __forceinline__ void wave_insert_topk_gated(u64* list, int k, u64 key, int lane, u64* wthr) {
+__device__ __forceinline__ void wave_insert_topk_shfl(u64* list, int k, u64 key, int lane) {   // probe: the ds_bpermute maximum
+  u64 kth = list[k - 1];
+  while (__ballot(key > kth)) {
+    u64 mx = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const u64 other = __shfl_xor(mx, o, 64);
+      mx = other > mx ? other : mx;
+    }
+    if (lane == 0) insert_key(list, k, mx);
+    if (key == mx) key = 0ull;
+    kth = list[k - 1];
+  }
+}
+__device__ __forceinline__ void wave_insert_topk_gated(u64* list, int k, u64 key, int lane, u64* wthr, int variant = 3) {
+  if (variant == 0) return wave_insert_topk_shfl(list, k, key, lane);   // probe variants: 0 = round-4 form, 1 = DPP maximum, no gate,
+  if (variant == 1) return wave_insert_topk(list, k, key, lane);        // 2 = gate + ds_bpermute maximum, 3 = gate + DPP maximum
   const u64 kth = list[k - 1], shared = *wthr;
   const u64 bar = kth > shared ? kth : shared;
   if (!__ballot(key > bar)) return;
-  wave_insert_topk(list, k, key > bar ? key : 0ull, lane);
+  if (variant == 2) wave_insert_topk_shfl(list, k, key > bar ? key : 0ull, lane);
+  else wave_insert_topk(list, k, key > bar ? key : 0ull, lane);
   const u64 nk = list[k - 1];   // non-zero = the list is full
   if (lane == 0 && nk > shared) atomicMax(reinterpret_cast<unsigned long long*>(wthr), (unsigned long long)nk);
 }
@@ -1500,7 +1517,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
                                                                  long long n_docs, const unsigned short* __restrict__ qmap,
                                                                  const float* __restrict__ qw, int vocab, int n_union,
                                                                  int nq, int q0, int k, int slices_per_wg,
-                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid) {
+                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid, int variant) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
@@ -1594,7 +1611,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
       const u64 key = hit ? make_key(acc[q], did) : 0ull;
-      wave_insert_topk_gated(mylists + q * k, k, key, lane, wthr + q);
+      wave_insert_topk_gated(mylists + q * k, k, key, lane, wthr + q, variant);
     }
   }
   __syncthreads();
@@ -2482,7 +2499,7 @@ static bool sparse_multi_fits(int vocab, int qb, int k) {
   return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) + 256 <= 160 * 1024;   // + the static thresholds
 }
 static int sparse_pass_queries(int vocab, int k) {
-  static const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
+  const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
   return (!only8 && sparse_multi_fits(vocab, 16, k)) ? 16 : 8;
 }
 
@@ -2494,6 +2511,7 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   if (ix->last_multi) {
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
+    const int variant = getenv("VRAG_SPARSE_INSERT") ? atoi(getenv("VRAG_SPARSE_INSERT")) : 3;   // probe of the list-insertion forms
     ARG_CHECK(sparse_multi_fits(ix->vocab, QB, k), "k = %d does not fit the batched pass the resident queries were prepared for", k);
     const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)(16 * QB * k + QB) * sizeof(u64);
     static bool attr_m = false;
@@ -2508,11 +2526,11 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
       if (QB == 16)
         hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, variant);
       else
         hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
                            ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, variant);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));

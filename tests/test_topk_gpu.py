@@ -538,3 +538,36 @@ def test_dense_f32_prefilter_falls_back_when_scores_bunch():
         assert np.array_equal(i, ri) and np.array_equal(s, rs), len(qs)
     sh.close()
     assert set(ri[0][:8].tolist()) <= set([7] + dup.tolist())
+
+
+def test_sparse_batched_collect_pass_and_its_rescue():
+    """Batches of >= 32 queries over >= 8 192 slices take the COLLECT form (csrc/topk.hip): the last 1 024 slices seed a per-query
+    entry threshold, the main pass only appends the scores above it.  (a) ordinary data: bit-exact; (b) adversarial: one-term
+    documents whose weight FALLS with the document number -- the seed (the last documents) holds the worst scores, nearly every
+    document passes, the 1 024-slot candidate buffers overflow and the list form, launched behind the overflow flag, answers."""
+    from verbatim_rag_amd.vector_stores import SparseShard, dicts_to_csr
+
+    rng = np.random.default_rng(5)
+    n, vocab, k = 600_000, 1000, 5
+    # (a) 4-12 terms per document, weights on the dyadic grid
+    lens = rng.integers(4, 13, n)
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ix = rng.integers(0, vocab, int(ip[-1])).astype(np.int32)
+    vv = (rng.integers(1, 193, len(ix)) / 64.0).astype(np.float32)
+    qs = [{int(t): float(w) for t, w in zip(rng.choice(vocab, 6, replace=False), rng.integers(1, 64, 6) / 64)} for _ in range(40)]
+    sp = SparseShard(vocab, ip, ix, vv)
+    s, i = sp.search(qs, k)
+    sp.close()
+    rs, ri = T.sparse_topk(ip, ix, vv, vocab, *dicts_to_csr(qs), k, blocked=True)
+    assert np.array_equal(i, ri) and np.array_equal(s, rs)
+    # (b) falling weights
+    ip = np.arange(n + 1, dtype=np.int64)
+    ix = (np.arange(n) % 7).astype(np.int32)
+    vv = (2.0 - np.arange(n, dtype=np.float64) / n).astype(np.float32)
+    qs = [{int(q % 7): 1.0, int(7 + q): 0.5} for q in range(33)]
+    sp = SparseShard(vocab, ip, ix, vv)
+    s, i = sp.search(qs, k)
+    sp.close()
+    rs, ri = T.sparse_topk(ip, ix, vv, vocab, *dicts_to_csr(qs), k, blocked=True)
+    assert np.array_equal(i, ri) and np.array_equal(s, rs)
+    assert np.array_equal(i[3], 3 + 7 * np.arange(k))

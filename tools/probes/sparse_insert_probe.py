@@ -26,18 +26,19 @@ idx = rng.choice(vocab, size=int(indptr[-1]), p=p).astype(np.int32)
 val = (rng.integers(1, 193, size=int(indptr[-1])) / 64.0).astype(np.float32)
 sh = SparseShard(vocab, indptr, idx, val)
 qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(64)]
-ref = None
-for qb8 in (False, True):
-    for variant in (0, 1, 2, 3):
-        os.environ["VRAG_SPARSE_INSERT"] = str(variant)
+refs = {}
+for qb8, wgs, k in ((False, 256, 5), (False, 512, 5), (True, 256, 5), (False, 256, 10), (True, 256, 10)):
+    if True:
+        variant = "registers"
+        os.environ["VRAG_SPARSE_WGS"] = str(wgs)
         if qb8:
             os.environ["VRAG_SPARSE_QB8"] = "1"
         else:
             os.environ.pop("VRAG_SPARSE_QB8", None)
         s, i = sh.search(qs, k)
-        if ref is None:
-            ref = (s, i)
-        same = bool(np.array_equal(s, ref[0]) and np.array_equal(i, ref[1]))
+        if k not in refs:
+            refs[k] = (s, i)
+        same = bool(np.array_equal(s, refs[k][0]) and np.array_equal(i, refs[k][1]))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
@@ -45,6 +46,6 @@ for qb8 in (False, True):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         per = 8 if qb8 else 16
-        print(json.dumps({"queries_per_pass": per, "insert_variant": variant, "ms_64_queries": dt * 1e3, "ms_per_pass": dt * 1e3 / (64 // per),
+        print(json.dumps({"queries_per_pass": per, "insert_variant": variant, "target_wgs": wgs, "k": k, "ms_64_queries": dt * 1e3, "ms_per_pass": dt * 1e3 / (64 // per),
                           "us_per_query": dt * 1e6 / 64, "same_result": same}), flush=True)
 sh.close()

@@ -84,50 +84,26 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
   return m;
 }
 
-// One key per lane (0 = none) into a wave-private sorted list: the lanes' keys are taken in DESCENDING order and the loop ends
-// as soon as the largest one left cannot enter, so a wave inserts at most k keys per call -- not one per qualifying lane
-// (a wave's first slice meets an empty list: 64 serial insertions before, k now).  The result is the same list.
+// One key per lane (0 = none) into a wave-private sorted list of k <= 64 keys (LDS).  The lanes' keys are taken in DESCENDING
+// order and the loop ends as soon as the largest one left cannot enter, so a call inserts at most k keys -- not one per
+// qualifying lane.  Round 5: during a call the list lives in REGISTERS, entry i in lane i -- an insertion is a ballot (how many
+// entries are larger), one DPP shift (wave_shr:1) and a select; the k-th entry is a lane read.  No LDS round trip per inserted
+// key (the round-4 form had lane 0 shift the list through LDS: ~10 dependent LDS operations per key, and with one list per
+// wave and query and a few hundred documents per list the batched pass spent half its time there).
 __device__ __forceinline__ void wave_insert_topk(u64* list, int k, u64 key, int lane) {
   u64 kth = list[k - 1];
-  while (__ballot(key > kth)) {
+  if (!__ballot(key > kth)) return;
+  u64 mine = lane < k ? list[lane] : 0ull;
+  do {
     const u64 mx = wave_max_u64(key);
-    if (lane == 0) insert_key(list, k, mx);
-    if (key == mx) key = 0ull;   // keys are unique (they carry the row id)
-    kth = list[k - 1];           // LDS operations of one wave execute in order: this sees lane 0's update
-  }
-}
-
-// The same behind a WORKGROUP-wide entry threshold (sparse kernels): wthr (LDS) is the largest k-th key any FULL list of the
-// query in this workgroup has reached (ds_max_u64).  A key at or below it cannot be in the workgroup's top-k for the query --
-// a sibling wave already holds k keys above it, and those go to the merge -- so the 16 per-wave lists of a workgroup stop
-// filling and refining independently: with a few hundred documents per list, that was where a batched pass spent most of
-// its time (every list re-discovers the same distribution: ~k (1 + ln(docs / k)) serial insertions per list and query).
-// (A shard-wide threshold in global memory was tried first and was slower: the publishing atomics of 8 192 lists land on
-// two cache lines and serialise -- 27 -> 63 ms per 1 000 queries, profiles/r05_sparse_lines.json.)
-__device__ __forceinline__ void wave_insert_topk_shfl(u64* list, int k, u64 key, int lane) {   // probe: the ds_bpermute maximum
-  u64 kth = list[k - 1];
-  while (__ballot(key > kth)) {
-    u64 mx = key;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const u64 other = __shfl_xor(mx, o, 64);
-      mx = other > mx ? other : mx;
-    }
-    if (lane == 0) insert_key(list, k, mx);
-    if (key == mx) key = 0ull;
-    kth = list[k - 1];
-  }
-}
-__device__ __forceinline__ void wave_insert_topk_gated(u64* list, int k, u64 key, int lane, u64* wthr, int variant = 3) {
-  if (variant == 0) return wave_insert_topk_shfl(list, k, key, lane);   // probe variants: 0 = round-4 form, 1 = DPP maximum, no gate,
-  if (variant == 1) return wave_insert_topk(list, k, key, lane);        // 2 = gate + ds_bpermute maximum, 3 = gate + DPP maximum
-  const u64 kth = list[k - 1], shared = *wthr;
-  const u64 bar = kth > shared ? kth : shared;
-  if (!__ballot(key > bar)) return;
-  if (variant == 2) wave_insert_topk_shfl(list, k, key > bar ? key : 0ull, lane);
-  else wave_insert_topk(list, k, key > bar ? key : 0ull, lane);
-  const u64 nk = list[k - 1];   // non-zero = the list is full
-  if (lane == 0 && nk > shared) atomicMax(reinterpret_cast<unsigned long long*>(wthr), (unsigned long long)nk);
+    const int pos = __popcll(__ballot(mine > mx));            // entries that stay in front of the new key (lanes >= k hold 0)
+    const u64 up = dpp_u64<0x138>(mine);                        // wave_shr:1 -- lane i receives lane i - 1's entry
+    mine = lane < pos ? mine : (lane == pos ? mx : up);
+    if (key == mx) key = 0ull;                                  // keys are unique (they carry the row id)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, k - 1), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), k - 1);
+    kth = ((u64)hi << 32) | lo;
+  } while (__ballot(key > kth));
+  if (lane < k) list[lane] = mine;
 }
 
 // ------------------------------------------------------------------------------------ dense
@@ -952,7 +928,7 @@ __global__ void topk_seed_threshold_kernel(const u64* __restrict__ out, int nq, 
   if (q < nq) thr[q] = out[(size_t)q * k + (k - 1)];
 }
 
-static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st);
+static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st, const unsigned* gate = nullptr);
 
 struct Mfma2Plan {
   long long prefix;   // rows of the threshold-seeding pass (0 = single pass)
@@ -1149,13 +1125,17 @@ __global__ void tiled_queries_kernel(const float* __restrict__ q, int nq, int di
 // list goes to out[q][0..k).  A counter beyond the capacity marks the query for the rescue pass.
 __global__ __launch_bounds__(256) void tiled_select_kernel(u64* __restrict__ buf, unsigned* __restrict__ cnt, int cap, int k,
                                                             u64* __restrict__ thr_key, float* __restrict__ thr_score,
-                                                            u64* __restrict__ out, unsigned* __restrict__ ovf, int direct_n) {
+                                                            u64* __restrict__ out, unsigned* __restrict__ ovf, int direct_n,
+                                                            unsigned* __restrict__ any_ovf = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* sk = reinterpret_cast<u64*>(smem);
   const int q = blockIdx.x, tid = threadIdx.x;
   u64* mine = buf + (size_t)q * cap;
   const unsigned raw = direct_n > 0 ? (unsigned)direct_n : cnt[q];
-  if (raw > (unsigned)cap && tid == 0) ovf[q] = 1u;
+  if (raw > (unsigned)cap && tid == 0) {
+    ovf[q] = 1u;
+    if (any_ovf) *any_ovf = 1u;   // benign race: every writer stores 1
+  }
   const int n = (int)min(raw, (unsigned)cap);
   int P = 2;
   while (P < n) P <<= 1;
@@ -1427,11 +1407,9 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
                                                             u64* __restrict__ cand, const unsigned* __restrict__ docid,
                                                             const u64* __restrict__ bound) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: [16 waves][k] lists, the workgroup-wide entry threshold (wave_insert_topk_gated), then (LDSQ) the dense query vector
+  // LDS: [16 waves][k] lists, then (LDSQ) the dense query vector
   u64* lists = reinterpret_cast<u64*>(smem);
-  u64& wthr = lists[(size_t)16 * k];
-  if (threadIdx.x == 0) wthr = 0ull;
-  float* sq = reinterpret_cast<float*>(smem + (size_t)(16 * k + 2) * sizeof(u64));
+  float* sq = reinterpret_cast<float*>(smem + (size_t)16 * k * sizeof(u64));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* qv = qdense + (size_t)q * vocab;
   if constexpr (LDSQ) {
@@ -1473,7 +1451,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
     const bool hit = doc < n_docs && acc > 0.f;      // inverted-index semantics: no shared term => not a hit
     // the key carries the caller's document index (not the sorted position): ties order by id ascending
     const u64 key = hit ? make_key_below(acc, docid[doc], bound ? bound[q] : ~0ull) : 0ull;
-    wave_insert_topk_gated(mylist, k, key, lane, &wthr);
+    wave_insert_topk(mylist, k, key, lane);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1509,35 +1487,60 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
 // for QB queries.
 constexpr int SUW = 1024;                   // weight-table stride: union ids 0 .. SUW-1
 
-template <int QB>
-__global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned short* __restrict__ cols,
+// NW = waves per workgroup: 16 (eight queries per pass: 128 registers hold two 20-term load sets) or 8 (sixteen queries: 256
+// registers hold the sixteen accumulators AND two 40-term sets -- with 128 the sets shrank to 12 terms and the pass, which
+// runs at the pace of the bytes in flight, took 0.28 ms instead of 0.17: profiles/r05_sparse_probes.txt).
+// COLLECT (round 5, batches over large shards): no lists at all.  A seeding pass ranks the LAST slices of the shard (documents
+// are stored by length, the longest -- the likeliest hits -- last) with the list form; its k-th key per query is the entry
+// threshold of the main pass, which only compares each score with it and appends the rare survivors to a per-query candidate
+// buffer in global memory; one workgroup per query then sorts seed list + candidates.  With one list per wave and query and a
+// few hundred documents per list, filling and refining the lists cost as much VALU time per 8 queries as the pass needs to
+// stream the shard (profiles/r05_sparse_probes.txt); the compare costs nothing.  A candidate buffer that overflows sets a flag,
+// and the list form -- launched behind that flag (`gate`) after every search -- answers instead.
+struct SparseCollect {
+  const float* thr_score;   // [nq] score of thr_key (0 = list not full: every hit is a candidate)
+  const u64* thr_key;       // [nq] k-th key of the seeding pass
+  unsigned* cnt;            // [nq] candidates appended (the first k slots hold the seed list)
+  u64* buf;                 // [nq][cap]
+  int cap;
+  int slice_lo;             // first slice of this launch; `n_slices` is its exclusive end
+  const unsigned* gate;     // non-null: the launch does nothing unless *gate != 0 (rescue of an overflowed search)
+};
+template <int QB, int NW, bool COLLECT = false>
+__global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsigned short* __restrict__ cols,
                                                                  const float* __restrict__ vals,
                                                                  const long long* __restrict__ slice_off,
                                                                  const int* __restrict__ slice_len, int n_slices,
                                                                  long long n_docs, const unsigned short* __restrict__ qmap,
                                                                  const float* __restrict__ qw, int vocab, int n_union,
                                                                  int nq, int q0, int k, int slices_per_wg,
-                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid, int variant) {
+                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid,
+                                                                 const SparseCollect cx) {
+  if (cx.gate && !*cx.gate) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
   float* tw = reinterpret_cast<float*>(smem + (size_t)vpad * 2);                  // [QB][SUW] (first n_union+1 used)
-  u64* lists = reinterpret_cast<u64*>(smem + (size_t)vpad * 2 + (size_t)QB * SUW * 4);   // [16 waves][QB][k]
+  u64* lists = reinterpret_cast<u64*>(smem + (size_t)vpad * 2 + (size_t)QB * SUW * 4);   // [NW waves][QB][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < vpad / 8; i += 1024)   // 16-byte copies
+  for (int i = tid; i < vpad / 8; i += NW * 64)   // 16-byte copies
     reinterpret_cast<f32x4*>(tmap)[i] = reinterpret_cast<const f32x4*>(qmap)[i];
-  for (int i = tid; i < QB * (n_union + 1); i += 1024) {
+  for (int i = tid; i < QB * (n_union + 1); i += NW * 64) {
     const int q = i / (n_union + 1), u = i - q * (n_union + 1);
     tw[u * QB + q] = qw[(size_t)q * SUW + u];
   }
-  for (int i = tid; i < 16 * QB * k; i += 1024) lists[i] = 0ull;
-  u64* wthr = lists + (size_t)16 * QB * k;   // [QB] workgroup-wide entry thresholds (wave_insert_topk_gated)
-  if (tid < QB) wthr[tid] = 0ull;
+  if constexpr (!COLLECT)
+    for (int i = tid; i < NW * QB * k; i += NW * 64) lists[i] = 0ull;
   __syncthreads();
   u64* mylists = lists + (size_t)wave * QB * k;
-  const int s_begin = blockIdx.x * slices_per_wg;
+  const int s_begin = cx.slice_lo + blockIdx.x * slices_per_wg;
   const int s_end = min(n_slices, s_begin + slices_per_wg);
-  for (int s = s_begin + wave; s < s_end; s += 16) {
+  float ts[COLLECT ? QB : 1];
+  if constexpr (COLLECT) {
+#pragma unroll
+    for (int q = 0; q < QB; ++q) ts[q] = q0 + q < nq ? cx.thr_score[q0 + q] : INFINITY;
+  }
+  for (int s = s_begin + wave; s < s_end; s += NW) {
     const long long off = slice_off[s];
     const int ng = slice_len[s];   // groups of 4 terms
     const u32x2* c = reinterpret_cast<const u32x2*>(cols + off) + lane;
@@ -1548,8 +1551,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     auto term = [&](unsigned t, float v1) {   // acc[q] = fma(v1, W[uid][q], acc[q]) for every query, two per v_pk_fma_f32
       const unsigned uid = tmap[t];
       // Only the lanes whose term is in the pass's union (a few per cent) read weight rows: the other lanes would add
-      // v * 0 -- exactly nothing -- and their LDS reads were what a pass spent its time on (16 queries per pass ran at the
-      // per-query cost of 8: profiles/r05_sparse_lines.json).  The branch is per lane (exec mask); a wave with no hit skips.
+      // v * 0 -- exactly nothing.  The branch is per lane (exec mask); a wave with no hit skips.
       if (uid != 0u) {
         const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
         const f32x2 vv = splat2(v1);
@@ -1564,13 +1566,13 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
     auto consume = [&](const u32x2& cg, const f32x4& vg) {   // the document's term order; weight rows of two terms in flight
       term(cg[0] & 0xFFFFu, vg[0]);
       term(cg[0] >> 16, vg[1]);
-      if constexpr (QB > 8) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (QB > 8 && NW == 16) __builtin_amdgcn_sched_barrier(0);   // 128 registers: weight rows of two terms in flight at most
       term(cg[1] & 0xFFFFu, vg[2]);
       term(cg[1] >> 16, vg[3]);
     };
     // Two register sets of G groups (4 G terms): the loads of step i + 1 are in flight while step i is consumed -- one 16-wave
     // workgroup per CU (the term map fills the LDS), so the bytes in flight per lane are what covers the memory latency.
-    constexpr int G = QB > 8 ? 3 : 5;   // 16 queries: 16 accumulators + four weight rows in flight leave room for two 8-term sets
+    constexpr int G = NW == 8 ? 10 : (QB > 8 ? 3 : 5);   // groups per load set: what the register budget of the configuration holds twice
     u32x2 ca[G], cb[G];
     f32x4 va[G], vb[G];
     auto load = [&](u32x2 (&cd)[G], f32x4 (&vd)[G], int g0) {
@@ -1585,7 +1587,7 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         if (g0 + u < ng) consume(cd[u], vd[u]);   // wave-uniform
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NW == 16 || (QB > 8)) { if ((u & (NW == 8 ? 1 : 0)) == (NW == 8 ? 1 : 0)) __builtin_amdgcn_sched_barrier(0); }   // bound the LDS reads in flight: every group (128 registers) / every other group
       }
     };
     // Every load is issued unconditionally (group indices clamp to the slice's last group; what a tail re-reads is not consumed):
@@ -1610,19 +1612,33 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
-      const u64 key = hit ? make_key(acc[q], did) : 0ull;
-      wave_insert_topk_gated(mylists + q * k, k, key, lane, wthr + q, variant);
+      if constexpr (COLLECT) {
+        const bool pass = hit && acc[q] >= ts[q];
+        if (__ballot(pass)) {   // rare once the threshold is seeded
+          if (pass) {
+            const u64 key = make_key(acc[q], did);
+            if (key > cx.thr_key[q0 + q]) {
+              const unsigned slot = atomicAdd(cx.cnt + q0 + q, 1u);
+              if (slot < (unsigned)cx.cap) cx.buf[(size_t)(q0 + q) * cx.cap + slot] = key;
+            }
+          }
+        }
+      } else {
+        const u64 key = hit ? make_key(acc[q], did) : 0ull;
+        wave_insert_topk(mylists + q * k, k, key, lane);
+      }
     }
   }
+  if constexpr (COLLECT) return;
   __syncthreads();
   if (tid < QB && q0 + tid < nq) {
-    int head[16];
-    for (int g = 0; g < 16; ++g) head[g] = 0;
+    int head[NW];
+    for (int g = 0; g < NW; ++g) head[g] = 0;
     u64* out = cand + ((size_t)blockIdx.x * nq + (q0 + tid)) * k;
     for (int i = 0; i < k; ++i) {
       u64 best = 0ull;
       int bg = -1;
-      for (int g = 0; g < 16; ++g) {
+      for (int g = 0; g < NW; ++g) {
         if (head[g] < k) {
           const u64 vv = lists[((size_t)g * QB + tid) * k + head[g]];
           if (vv > best) {
@@ -1640,7 +1656,8 @@ __global__ __launch_bounds__(1024) void sparse_topk_multi_kernel(const unsigned 
 // ------------------------------------------------------------------------------------ merge
 // One workgroup per query: k rounds of workgroup-wide arg-max over the candidate keys.
 __global__ __launch_bounds__(256) void topk_merge_scan_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
-                                                          u64* __restrict__ out) {
+                                                          u64* __restrict__ out, const unsigned* __restrict__ gate) {
+  if (gate && !*gate) return;
   __shared__ u64 red[4];
   __shared__ u64 last;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1680,7 +1697,8 @@ __global__ __launch_bounds__(256) void topk_merge_scan_kernel(const u64* __restr
 // once -- then k rounds of "largest list head wins" across the 256 private lists.
 constexpr int MERGE_KMAX = 32;
 __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
-                                                                u64* __restrict__ out) {
+                                                                u64* __restrict__ out, const unsigned* __restrict__ gate) {
+  if (gate && !*gate) return;
   extern __shared__ __attribute__((aligned(16))) char msm[];
   u64* lists = reinterpret_cast<u64*>(msm);          // [256][k]
   __shared__ u64 red[4];
@@ -1732,11 +1750,11 @@ __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const u64* __rest
   }
 }
 
-static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st) {
+static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st, const unsigned* gate) {
   if (k <= MERGE_KMAX)
-    hipLaunchKernelGGL(topk_merge_lists_kernel, dim3(nq), dim3(256), (size_t)256 * k * sizeof(u64), st, cand, n_wg, nq, k, out);
+    hipLaunchKernelGGL(topk_merge_lists_kernel, dim3(nq), dim3(256), (size_t)256 * k * sizeof(u64), st, cand, n_wg, nq, k, out, gate);
   else
-    hipLaunchKernelGGL(topk_merge_scan_kernel, dim3(nq), dim3(256), 0, st, cand, n_wg, nq, k, out);
+    hipLaunchKernelGGL(topk_merge_scan_kernel, dim3(nq), dim3(256), 0, st, cand, n_wg, nq, k, out, gate);
   return hipGetLastError();
 }
 
@@ -1888,6 +1906,10 @@ struct vrag_sparse_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
+  u64 *d_cbuf = nullptr, *d_cthr = nullptr;   // COLLECT searches: candidate buffers [nq][cap], entry thresholds
+  float* d_cthrs = nullptr;
+  unsigned* d_ccnt = nullptr;                 // [nq] counters, [nq] overflow flags, [1] any
+  size_t d_cbuf_elems = 0, d_cthr_elems = 0, d_cthrs_elems = 0, d_ccnt_elems = 0;
   unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
@@ -2467,6 +2489,8 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->d_docid) (void)hipFree(ix->d_docid);
+  for (void* p : {(void*)ix->d_cbuf, (void*)ix->d_cthr, (void*)ix->d_cthrs, (void*)ix->d_ccnt})
+    if (p) (void)hipFree(p);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -2481,10 +2505,24 @@ int vrag_sparse_index_stats(vrag_sparse_index* ix, int64_t* n_docs, int64_t* nnz
   return VRAG_OK;
 }
 
+// Seed of a COLLECT search: the seeding pass's exact top-k per query becomes the first k candidates and its k-th key the
+// entry threshold of the main pass (0 / score 0 while the list is not full: every hit is then a candidate).
+__global__ void sparse_seed_kernel(const u64* __restrict__ seed, int nq, int k, int cap, u64* __restrict__ thr_key, float* __restrict__ thr_score,
+                                   unsigned* __restrict__ cnt, u64* __restrict__ buf) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  for (int i = 0; i < k; ++i) buf[(size_t)q * cap + i] = seed[(size_t)q * k + i];
+  const u64 kk = seed[(size_t)q * k + (k - 1)];
+  thr_key[q] = kk;
+  thr_score[q] = kk ? unorderable((unsigned)(kk >> 32)) : 0.f;
+  cnt[q] = (unsigned)k;
+}
+
 static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
-  // ~2 workgroups per CU (one is resident per CU: the dense query vector fills the LDS), each a
-  // multiple of its 16 waves
-  const int target_wgs = 512;
+  // ONE workgroup per CU (the term map / dense query vector fills the LDS, so one is resident anyway), each a multiple of its
+  // 16 waves.  Every wave keeps a top-k list per query, and a list that sees few documents spends its time filling: 512
+  // workgroups measured 19 % slower than 256, 1 024 42 % (profiles/r05_sparse_probes.txt).
+  const int target_wgs = getenv("VRAG_SPARSE_WGS") ? atoi(getenv("VRAG_SPARSE_WGS")) : 256;   // probe
   int spw = (ix->n_slices + target_wgs - 1) / target_wgs;
   spw = std::max(16, (spw + 15) / 16 * 16);
   return spw;
@@ -2494,9 +2532,10 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
 // vocabulary at k <= 32), else 8.  (Round 2 measured 16 slower -- 3.7 vs 2.0 ms for 64 queries: its accumulators and 32
 // single-term loads per step did not fit 128 registers.  Round 5: four terms per load pair, two queries per v_pk_fma_f32.)
 constexpr int SQB_MAX = 16;
+static int sparse_pass_waves(int qb) { return qb == 16 ? 8 : 16; }   // waves per workgroup of the batched pass (see the kernel)
 static bool sparse_multi_fits(int vocab, int qb, int k) {
   const int vpad = (vocab + 7) & ~7;
-  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) + 256 <= 160 * 1024;   // + the static thresholds
+  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)sparse_pass_waves(qb) * qb * k * sizeof(u64) <= 160 * 1024;
 }
 static int sparse_pass_queries(int vocab, int k) {
   const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
@@ -2511,34 +2550,82 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
   if (ix->last_multi) {
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
-    const int variant = getenv("VRAG_SPARSE_INSERT") ? atoi(getenv("VRAG_SPARSE_INSERT")) : 3;   // probe of the list-insertion forms
     ARG_CHECK(sparse_multi_fits(ix->vocab, QB, k), "k = %d does not fit the batched pass the resident queries were prepared for", k);
-    const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)(16 * QB * k + QB) * sizeof(u64);
+    const int NWv = sparse_pass_waves(QB);
+    const size_t lds_lists = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)NWv * QB * k * sizeof(u64);
+    const size_t lds_collect = (size_t)vpad * 2 + (size_t)QB * SUW * 4;
     static bool attr_m = false;
     if (!attr_m) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      for (const void* f : {reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16, false>),
+                            reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 8, false>),
+                            reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16, true>),
+                            reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 8, true>)})
+        HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
-    for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
-      if (QB == 16)
-        hipLaunchKernelGGL((sparse_topk_multi_kernel<16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, variant);
-      else
-        hipLaunchKernelGGL((sparse_topk_multi_kernel<8>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid, variant);
-      HIP_TRY(hipGetLastError());
+    // one pass of QB queries over slices [lo, hi) in either form
+    auto passes = [&](bool collect, int lo, int hi, int spw, int wgs, u64* cand_base, const SparseCollect& cx) -> int {
+      SparseCollect c = cx;
+      c.slice_lo = lo;
+      const size_t lds = collect ? lds_collect : lds_lists;
+      for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
+        const unsigned short* qm = ix->d_qmap + (size_t)ps * vpad;
+        const float* qwp = ix->d_qw + (size_t)ps * QB * SUW;
+#define VRAG_SPARSE_PASS(QB_, NW_, C_)                                                                                              \
+  hipLaunchKernelGGL((sparse_topk_multi_kernel<QB_, NW_, C_>), dim3(wgs), dim3(NW_ * 64), lds, st, ix->cols, ix->vals, ix->slice_off, \
+                     ix->slice_len, hi, (long long)ix->n_docs, qm, qwp, ix->vocab, ix->pass_union[ps], nq, q0, k, spw, cand_base, ix->d_docid, c)
+        if (QB == 16 && collect) VRAG_SPARSE_PASS(16, 8, true);
+        else if (QB == 16) VRAG_SPARSE_PASS(16, 8, false);
+        else if (collect) VRAG_SPARSE_PASS(8, 16, true);
+        else VRAG_SPARSE_PASS(8, 16, false);
+#undef VRAG_SPARSE_PASS
+        HIP_TRY(hipGetLastError());
+      }
+      return VRAG_OK;
+    };
+    const SparseCollect none{};
+    static const bool no_collect = getenv("VRAG_SPARSE_NO_COLLECT") != nullptr;   // A/B: the list form for every batch
+    constexpr int SEED_SLICES = 1024, CCAP = 1024;
+    const bool collect = !no_collect && !bound && nq >= 2 * QB && ix->n_slices >= 8 * SEED_SLICES;
+    if (!collect) {
+      int rc = passes(false, 0, ix->n_slices, slices_per_wg, n_wg, ix->d_cand, none);
+      if (rc) return rc;
+      HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
+      return VRAG_OK;
     }
-    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
+    int rc;
+    if ((rc = grow(&ix->d_cbuf, &ix->d_cbuf_elems, (size_t)nq * CCAP))) return rc;
+    if ((rc = grow(&ix->d_ccnt, &ix->d_ccnt_elems, (size_t)2 * nq + 1))) return rc;
+    if ((rc = grow(&ix->d_cthr, &ix->d_cthr_elems, (size_t)nq))) return rc;
+    if ((rc = grow(&ix->d_cthrs, &ix->d_cthrs_elems, (size_t)nq))) return rc;
+    unsigned* ovf = ix->d_ccnt + nq;
+    unsigned* any = ix->d_ccnt + 2 * nq;
+    HIP_TRY(hipMemsetAsync(ix->d_ccnt, 0, ((size_t)2 * nq + 1) * sizeof(unsigned), st));
+    // 1. seed: the list form over the last SEED_SLICES slices (the longest documents) -> exact top-k of that range per query
+    const int seed_lo = ix->n_slices - SEED_SLICES, spw0 = 16, wgs0 = SEED_SLICES / spw0;
+    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)std::max(n_wg, wgs0) * nq * k))) return rc;
+    if ((rc = passes(false, seed_lo, ix->n_slices, spw0, wgs0, ix->d_cand, none))) return rc;
+    HIP_TRY(launch_topk_merge(ix->d_cand, wgs0, nq, k, ix->d_out, st));
+    hipLaunchKernelGGL(sparse_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ix->d_out, nq, k, CCAP, ix->d_cthr, ix->d_cthrs, ix->d_ccnt,
+                       ix->d_cbuf);
     HIP_TRY(hipGetLastError());
+    // 2. main pass over the other slices: compare and append
+    SparseCollect cx{ix->d_cthrs, ix->d_cthr, ix->d_ccnt, ix->d_cbuf, CCAP, 0, nullptr};
+    const int spw1 = std::max(16, ((seed_lo + 255) / 256 + 15) / 16 * 16), wgs1 = (seed_lo + spw1 - 1) / spw1;
+    if ((rc = passes(true, 0, seed_lo, spw1, wgs1, ix->d_cand, cx))) return rc;
+    // 3. per query: seed list + candidates, sorted; an overflowed buffer raises `any`
+    hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)CCAP * sizeof(u64), st, ix->d_cbuf, ix->d_ccnt, CCAP, k, ix->d_cthr,
+                       ix->d_cthrs, ix->d_out, ovf, 0, any);
+    HIP_TRY(hipGetLastError());
+    // 4. behind the flag: the list form over the whole shard rewrites every list (nothing runs unless a buffer overflowed)
+    SparseCollect gated{};
+    gated.gate = any;
+    if ((rc = passes(false, 0, ix->n_slices, slices_per_wg, n_wg, ix->d_cand, gated))) return rc;
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st, any));
     return VRAG_OK;
   }
-  const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) + 64 <= 160 * 1024;   // + the static threshold
-  const size_t lds = (size_t)(16 * k + 2) * sizeof(u64) + (ldsq ? (size_t)ix->vocab * sizeof(float) : 0);
+  const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) <= 160 * 1024;
+  const size_t lds = (size_t)16 * k * sizeof(u64) + (ldsq ? (size_t)ix->vocab * sizeof(float) : 0);
   if (ldsq) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -540,11 +540,10 @@ def test_dense_f32_prefilter_falls_back_when_scores_bunch():
     assert set(ri[0][:8].tolist()) <= set([7] + dup.tolist())
 
 
-def test_sparse_batched_collect_pass_and_its_rescue():
-    """Batches of >= 32 queries over >= 8 192 slices take the COLLECT form (csrc/topk.hip): the last 1 024 slices seed a per-query
-    entry threshold, the main pass only appends the scores above it.  (a) ordinary data: bit-exact; (b) adversarial: one-term
-    documents whose weight FALLS with the document number -- the seed (the last documents) holds the worst scores, nearly every
-    document passes, the 1 024-slot candidate buffers overflow and the list form, launched behind the overflow flag, answers."""
+def test_sparse_batched_passes_over_a_large_shard():
+    """Batches of >= 32 queries (16 per pass) over 9 375 slices, one workgroup per CU: (a) ordinary data; (b) one-term documents
+    whose weight FALLS with the document number, so that the documents a wave sees first are the best ones and the lists are
+    filled once and then only compared against (the register-resident insertion path's quiet case) -- both bit-exact."""
     from verbatim_rag_amd.vector_stores import SparseShard, dicts_to_csr
 
     rng = np.random.default_rng(5)

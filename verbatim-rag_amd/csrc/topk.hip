@@ -928,7 +928,7 @@ __global__ void topk_seed_threshold_kernel(const u64* __restrict__ out, int nq, 
   if (q < nq) thr[q] = out[(size_t)q * k + (k - 1)];
 }
 
-static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st, const unsigned* gate = nullptr);
+static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st);
 
 struct Mfma2Plan {
   long long prefix;   // rows of the threshold-seeding pass (0 = single pass)
@@ -1125,17 +1125,13 @@ __global__ void tiled_queries_kernel(const float* __restrict__ q, int nq, int di
 // list goes to out[q][0..k).  A counter beyond the capacity marks the query for the rescue pass.
 __global__ __launch_bounds__(256) void tiled_select_kernel(u64* __restrict__ buf, unsigned* __restrict__ cnt, int cap, int k,
                                                             u64* __restrict__ thr_key, float* __restrict__ thr_score,
-                                                            u64* __restrict__ out, unsigned* __restrict__ ovf, int direct_n,
-                                                            unsigned* __restrict__ any_ovf = nullptr) {
+                                                            u64* __restrict__ out, unsigned* __restrict__ ovf, int direct_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* sk = reinterpret_cast<u64*>(smem);
   const int q = blockIdx.x, tid = threadIdx.x;
   u64* mine = buf + (size_t)q * cap;
   const unsigned raw = direct_n > 0 ? (unsigned)direct_n : cnt[q];
-  if (raw > (unsigned)cap && tid == 0) {
-    ovf[q] = 1u;
-    if (any_ovf) *any_ovf = 1u;   // benign race: every writer stores 1
-  }
+  if (raw > (unsigned)cap && tid == 0) ovf[q] = 1u;
   const int n = (int)min(raw, (unsigned)cap);
   int P = 2;
   while (P < n) P <<= 1;
@@ -1487,26 +1483,9 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
 // for QB queries.
 constexpr int SUW = 1024;                   // weight-table stride: union ids 0 .. SUW-1
 
-// NW = waves per workgroup: 16 (eight queries per pass: 128 registers hold two 20-term load sets) or 8 (sixteen queries: 256
-// registers hold the sixteen accumulators AND two 40-term sets -- with 128 the sets shrank to 12 terms and the pass, which
-// runs at the pace of the bytes in flight, took 0.28 ms instead of 0.17: profiles/r05_sparse_probes.txt).
-// COLLECT (round 5, batches over large shards): no lists at all.  A seeding pass ranks the LAST slices of the shard (documents
-// are stored by length, the longest -- the likeliest hits -- last) with the list form; its k-th key per query is the entry
-// threshold of the main pass, which only compares each score with it and appends the rare survivors to a per-query candidate
-// buffer in global memory; one workgroup per query then sorts seed list + candidates.  With one list per wave and query and a
-// few hundred documents per list, filling and refining the lists cost as much VALU time per 8 queries as the pass needs to
-// stream the shard (profiles/r05_sparse_probes.txt); the compare costs nothing.  A candidate buffer that overflows sets a flag,
-// and the list form -- launched behind that flag (`gate`) after every search -- answers instead.
-struct SparseCollect {
-  const float* thr_score;   // [nq] score of thr_key (0 = list not full: every hit is a candidate)
-  const u64* thr_key;       // [nq] k-th key of the seeding pass
-  unsigned* cnt;            // [nq] candidates appended (the first k slots hold the seed list)
-  u64* buf;                 // [nq][cap]
-  int cap;
-  int slice_lo;             // first slice of this launch; `n_slices` is its exclusive end
-  const unsigned* gate;     // non-null: the launch does nothing unless *gate != 0 (rescue of an overflowed search)
-};
-template <int QB, int NW, bool COLLECT = false>
+// NW = waves per workgroup (16; an 8-wave form with 256 registers and two 40-term load sets measured 10 % slower for 16 queries:
+// profiles/r05_sparse_probes.txt).
+template <int QB, int NW>
 __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsigned short* __restrict__ cols,
                                                                  const float* __restrict__ vals,
                                                                  const long long* __restrict__ slice_off,
@@ -1514,32 +1493,25 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
                                                                  long long n_docs, const unsigned short* __restrict__ qmap,
                                                                  const float* __restrict__ qw, int vocab, int n_union,
                                                                  int nq, int q0, int k, int slices_per_wg,
-                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid,
-                                                                 const SparseCollect cx) {
-  if (cx.gate && !*cx.gate) return;
+                                                                 u64* __restrict__ cand, const unsigned* __restrict__ docid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
-  float* tw = reinterpret_cast<float*>(smem + (size_t)vpad * 2);                  // [QB][SUW] (first n_union+1 used)
+  constexpr int WS = QB;   // weight-row stride in floats (a stride of QB + 4 -- conflict-free row starts -- measured no gain for 16 queries and 20 % slower for 8)
+  float* tw = reinterpret_cast<float*>(smem + (size_t)vpad * 2);                  // [SUW][WS] (first n_union+1 rows used)
   u64* lists = reinterpret_cast<u64*>(smem + (size_t)vpad * 2 + (size_t)QB * SUW * 4);   // [NW waves][QB][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < vpad / 8; i += NW * 64)   // 16-byte copies
     reinterpret_cast<f32x4*>(tmap)[i] = reinterpret_cast<const f32x4*>(qmap)[i];
   for (int i = tid; i < QB * (n_union + 1); i += NW * 64) {
     const int q = i / (n_union + 1), u = i - q * (n_union + 1);
-    tw[u * QB + q] = qw[(size_t)q * SUW + u];
+    tw[u * WS + q] = qw[(size_t)q * SUW + u];
   }
-  if constexpr (!COLLECT)
-    for (int i = tid; i < NW * QB * k; i += NW * 64) lists[i] = 0ull;
+  for (int i = tid; i < NW * QB * k; i += NW * 64) lists[i] = 0ull;
   __syncthreads();
   u64* mylists = lists + (size_t)wave * QB * k;
-  const int s_begin = cx.slice_lo + blockIdx.x * slices_per_wg;
+  const int s_begin = blockIdx.x * slices_per_wg;
   const int s_end = min(n_slices, s_begin + slices_per_wg);
-  float ts[COLLECT ? QB : 1];
-  if constexpr (COLLECT) {
-#pragma unroll
-    for (int q = 0; q < QB; ++q) ts[q] = q0 + q < nq ? cx.thr_score[q0 + q] : INFINITY;
-  }
   for (int s = s_begin + wave; s < s_end; s += NW) {
     const long long off = slice_off[s];
     const int ng = slice_len[s];   // groups of 4 terms
@@ -1553,7 +1525,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
       // Only the lanes whose term is in the pass's union (a few per cent) read weight rows: the other lanes would add
       // v * 0 -- exactly nothing.  The branch is per lane (exec mask); a wave with no hit skips.
       if (uid != 0u) {
-        const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * QB);
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(tw + uid * WS);
         const f32x2 vv = splat2(v1);
 #pragma unroll
         for (int g4 = 0; g4 < QB / 4; ++g4) {
@@ -1612,24 +1584,10 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const bool hit = doc < n_docs && acc[q] > 0.f;
-      if constexpr (COLLECT) {
-        const bool pass = hit && acc[q] >= ts[q];
-        if (__ballot(pass)) {   // rare once the threshold is seeded
-          if (pass) {
-            const u64 key = make_key(acc[q], did);
-            if (key > cx.thr_key[q0 + q]) {
-              const unsigned slot = atomicAdd(cx.cnt + q0 + q, 1u);
-              if (slot < (unsigned)cx.cap) cx.buf[(size_t)(q0 + q) * cx.cap + slot] = key;
-            }
-          }
-        }
-      } else {
-        const u64 key = hit ? make_key(acc[q], did) : 0ull;
-        wave_insert_topk(mylists + q * k, k, key, lane);
-      }
+      const u64 key = hit ? make_key(acc[q], did) : 0ull;
+      wave_insert_topk(mylists + q * k, k, key, lane);
     }
   }
-  if constexpr (COLLECT) return;
   __syncthreads();
   if (tid < QB && q0 + tid < nq) {
     int head[NW];
@@ -1656,8 +1614,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
 // ------------------------------------------------------------------------------------ merge
 // One workgroup per query: k rounds of workgroup-wide arg-max over the candidate keys.
 __global__ __launch_bounds__(256) void topk_merge_scan_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
-                                                          u64* __restrict__ out, const unsigned* __restrict__ gate) {
-  if (gate && !*gate) return;
+                                                          u64* __restrict__ out) {
   __shared__ u64 red[4];
   __shared__ u64 last;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1697,8 +1654,7 @@ __global__ __launch_bounds__(256) void topk_merge_scan_kernel(const u64* __restr
 // once -- then k rounds of "largest list head wins" across the 256 private lists.
 constexpr int MERGE_KMAX = 32;
 __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const u64* __restrict__ cand, int n_wg, int nq, int k,
-                                                                u64* __restrict__ out, const unsigned* __restrict__ gate) {
-  if (gate && !*gate) return;
+                                                                u64* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char msm[];
   u64* lists = reinterpret_cast<u64*>(msm);          // [256][k]
   __shared__ u64 red[4];
@@ -1750,11 +1706,11 @@ __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const u64* __rest
   }
 }
 
-static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st, const unsigned* gate) {
+static hipError_t launch_topk_merge(const u64* cand, int n_wg, int nq, int k, u64* out, hipStream_t st) {
   if (k <= MERGE_KMAX)
-    hipLaunchKernelGGL(topk_merge_lists_kernel, dim3(nq), dim3(256), (size_t)256 * k * sizeof(u64), st, cand, n_wg, nq, k, out, gate);
+    hipLaunchKernelGGL(topk_merge_lists_kernel, dim3(nq), dim3(256), (size_t)256 * k * sizeof(u64), st, cand, n_wg, nq, k, out);
   else
-    hipLaunchKernelGGL(topk_merge_scan_kernel, dim3(nq), dim3(256), 0, st, cand, n_wg, nq, k, out, gate);
+    hipLaunchKernelGGL(topk_merge_scan_kernel, dim3(nq), dim3(256), 0, st, cand, n_wg, nq, k, out);
   return hipGetLastError();
 }
 
@@ -1906,10 +1862,6 @@ struct vrag_sparse_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
-  u64 *d_cbuf = nullptr, *d_cthr = nullptr;   // COLLECT searches: candidate buffers [nq][cap], entry thresholds
-  float* d_cthrs = nullptr;
-  unsigned* d_ccnt = nullptr;                 // [nq] counters, [nq] overflow flags, [1] any
-  size_t d_cbuf_elems = 0, d_cthr_elems = 0, d_cthrs_elems = 0, d_ccnt_elems = 0;
   unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
@@ -2489,8 +2441,6 @@ void vrag_sparse_index_destroy(vrag_sparse_index* ix) {
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
   if (ix->d_docid) (void)hipFree(ix->d_docid);
-  for (void* p : {(void*)ix->d_cbuf, (void*)ix->d_cthr, (void*)ix->d_cthrs, (void*)ix->d_ccnt})
-    if (p) (void)hipFree(p);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -2505,24 +2455,11 @@ int vrag_sparse_index_stats(vrag_sparse_index* ix, int64_t* n_docs, int64_t* nnz
   return VRAG_OK;
 }
 
-// Seed of a COLLECT search: the seeding pass's exact top-k per query becomes the first k candidates and its k-th key the
-// entry threshold of the main pass (0 / score 0 while the list is not full: every hit is then a candidate).
-__global__ void sparse_seed_kernel(const u64* __restrict__ seed, int nq, int k, int cap, u64* __restrict__ thr_key, float* __restrict__ thr_score,
-                                   unsigned* __restrict__ cnt, u64* __restrict__ buf) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nq) return;
-  for (int i = 0; i < k; ++i) buf[(size_t)q * cap + i] = seed[(size_t)q * k + i];
-  const u64 kk = seed[(size_t)q * k + (k - 1)];
-  thr_key[q] = kk;
-  thr_score[q] = kk ? unorderable((unsigned)(kk >> 32)) : 0.f;
-  cnt[q] = (unsigned)k;
-}
-
 static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
   // ONE workgroup per CU (the term map / dense query vector fills the LDS, so one is resident anyway), each a multiple of its
   // 16 waves.  Every wave keeps a top-k list per query, and a list that sees few documents spends its time filling: 512
   // workgroups measured 19 % slower than 256, 1 024 42 % (profiles/r05_sparse_probes.txt).
-  const int target_wgs = getenv("VRAG_SPARSE_WGS") ? atoi(getenv("VRAG_SPARSE_WGS")) : 256;   // probe
+  const int target_wgs = 256;
   int spw = (ix->n_slices + target_wgs - 1) / target_wgs;
   spw = std::max(16, (spw + 15) / 16 * 16);
   return spw;
@@ -2532,10 +2469,9 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
 // vocabulary at k <= 32), else 8.  (Round 2 measured 16 slower -- 3.7 vs 2.0 ms for 64 queries: its accumulators and 32
 // single-term loads per step did not fit 128 registers.  Round 5: four terms per load pair, two queries per v_pk_fma_f32.)
 constexpr int SQB_MAX = 16;
-static int sparse_pass_waves(int qb) { return qb == 16 ? 8 : 16; }   // waves per workgroup of the batched pass (see the kernel)
 static bool sparse_multi_fits(int vocab, int qb, int k) {
   const int vpad = (vocab + 7) & ~7;
-  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)sparse_pass_waves(qb) * qb * k * sizeof(u64) <= 160 * 1024;
+  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024;
 }
 static int sparse_pass_queries(int vocab, int k) {
   const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
@@ -2551,77 +2487,28 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
     ARG_CHECK(sparse_multi_fits(ix->vocab, QB, k), "k = %d does not fit the batched pass the resident queries were prepared for", k);
-    const int NWv = sparse_pass_waves(QB);
-    const size_t lds_lists = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)NWv * QB * k * sizeof(u64);
-    const size_t lds_collect = (size_t)vpad * 2 + (size_t)QB * SUW * 4;
+    const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)16 * QB * k * sizeof(u64);
     static bool attr_m = false;
     if (!attr_m) {
-      for (const void* f : {reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16, false>),
-                            reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 8, false>),
-                            reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16, true>),
-                            reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 8, true>)})
-        HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
-    // one pass of QB queries over slices [lo, hi) in either form
-    auto passes = [&](bool collect, int lo, int hi, int spw, int wgs, u64* cand_base, const SparseCollect& cx) -> int {
-      SparseCollect c = cx;
-      c.slice_lo = lo;
-      const size_t lds = collect ? lds_collect : lds_lists;
-      for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
-        const unsigned short* qm = ix->d_qmap + (size_t)ps * vpad;
-        const float* qwp = ix->d_qw + (size_t)ps * QB * SUW;
-#define VRAG_SPARSE_PASS(QB_, NW_, C_)                                                                                              \
-  hipLaunchKernelGGL((sparse_topk_multi_kernel<QB_, NW_, C_>), dim3(wgs), dim3(NW_ * 64), lds, st, ix->cols, ix->vals, ix->slice_off, \
-                     ix->slice_len, hi, (long long)ix->n_docs, qm, qwp, ix->vocab, ix->pass_union[ps], nq, q0, k, spw, cand_base, ix->d_docid, c)
-        if (QB == 16 && collect) VRAG_SPARSE_PASS(16, 8, true);
-        else if (QB == 16) VRAG_SPARSE_PASS(16, 8, false);
-        else if (collect) VRAG_SPARSE_PASS(8, 16, true);
-        else VRAG_SPARSE_PASS(8, 16, false);
-#undef VRAG_SPARSE_PASS
-        HIP_TRY(hipGetLastError());
-      }
-      return VRAG_OK;
-    };
-    const SparseCollect none{};
-    static const bool no_collect = getenv("VRAG_SPARSE_NO_COLLECT") != nullptr;   // A/B: the list form for every batch
-    constexpr int SEED_SLICES = 1024, CCAP = 1024;
-    const bool collect = !no_collect && !bound && nq >= 2 * QB && ix->n_slices >= 8 * SEED_SLICES;
-    if (!collect) {
-      int rc = passes(false, 0, ix->n_slices, slices_per_wg, n_wg, ix->d_cand, none);
-      if (rc) return rc;
-      HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
-      return VRAG_OK;
+    for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
+      if (QB == 16)
+        hipLaunchKernelGGL((sparse_topk_multi_kernel<16, 16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      else
+        hipLaunchKernelGGL((sparse_topk_multi_kernel<8, 16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
+                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
+                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      HIP_TRY(hipGetLastError());
     }
-    int rc;
-    if ((rc = grow(&ix->d_cbuf, &ix->d_cbuf_elems, (size_t)nq * CCAP))) return rc;
-    if ((rc = grow(&ix->d_ccnt, &ix->d_ccnt_elems, (size_t)2 * nq + 1))) return rc;
-    if ((rc = grow(&ix->d_cthr, &ix->d_cthr_elems, (size_t)nq))) return rc;
-    if ((rc = grow(&ix->d_cthrs, &ix->d_cthrs_elems, (size_t)nq))) return rc;
-    unsigned* ovf = ix->d_ccnt + nq;
-    unsigned* any = ix->d_ccnt + 2 * nq;
-    HIP_TRY(hipMemsetAsync(ix->d_ccnt, 0, ((size_t)2 * nq + 1) * sizeof(unsigned), st));
-    // 1. seed: the list form over the last SEED_SLICES slices (the longest documents) -> exact top-k of that range per query
-    const int seed_lo = ix->n_slices - SEED_SLICES, spw0 = 16, wgs0 = SEED_SLICES / spw0;
-    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)std::max(n_wg, wgs0) * nq * k))) return rc;
-    if ((rc = passes(false, seed_lo, ix->n_slices, spw0, wgs0, ix->d_cand, none))) return rc;
-    HIP_TRY(launch_topk_merge(ix->d_cand, wgs0, nq, k, ix->d_out, st));
-    hipLaunchKernelGGL(sparse_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ix->d_out, nq, k, CCAP, ix->d_cthr, ix->d_cthrs, ix->d_ccnt,
-                       ix->d_cbuf);
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
     HIP_TRY(hipGetLastError());
-    // 2. main pass over the other slices: compare and append
-    SparseCollect cx{ix->d_cthrs, ix->d_cthr, ix->d_ccnt, ix->d_cbuf, CCAP, 0, nullptr};
-    const int spw1 = std::max(16, ((seed_lo + 255) / 256 + 15) / 16 * 16), wgs1 = (seed_lo + spw1 - 1) / spw1;
-    if ((rc = passes(true, 0, seed_lo, spw1, wgs1, ix->d_cand, cx))) return rc;
-    // 3. per query: seed list + candidates, sorted; an overflowed buffer raises `any`
-    hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)CCAP * sizeof(u64), st, ix->d_cbuf, ix->d_ccnt, CCAP, k, ix->d_cthr,
-                       ix->d_cthrs, ix->d_out, ovf, 0, any);
-    HIP_TRY(hipGetLastError());
-    // 4. behind the flag: the list form over the whole shard rewrites every list (nothing runs unless a buffer overflowed)
-    SparseCollect gated{};
-    gated.gate = any;
-    if ((rc = passes(false, 0, ix->n_slices, slices_per_wg, n_wg, ix->d_cand, gated))) return rc;
-    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st, any));
     return VRAG_OK;
   }
   const bool ldsq = (size_t)ix->vocab * sizeof(float) + (size_t)16 * k * sizeof(u64) <= 160 * 1024;

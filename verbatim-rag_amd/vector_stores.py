@@ -663,13 +663,29 @@ def _get_strings(path: str, stem: str, n: int) -> List[str]:
     import os
 
     txt, js = os.path.join(path, f"{stem}.txt"), os.path.join(path, f"{stem}.json")
-    # both present = an overwrite was interrupted between the rename of the new file and the removal of the old: newest wins
-    if os.path.exists(txt) and not (os.path.exists(js) and os.path.getmtime(js) > os.path.getmtime(txt)):
+
+    def read_txt():
         with open(txt, encoding="utf-8", newline="") as f:
-            col = f.read().split("\x00") if n else []
+            return f.read().split("\x00") if n else []
+
+    def read_json():
+        with open(js, encoding="utf-8") as f:
+            return json.load(f)
+
+    if os.path.exists(txt) and os.path.exists(js):
+        # an overwrite was interrupted between the rename of the new file and the removal of the old one: the newer file wins;
+        # with equal timestamps (coarse clocks, restored backups) the one that holds the manifest's row count does
+        mt, mj = os.path.getmtime(txt), os.path.getmtime(js)
+        if mt != mj:
+            col = read_json() if mj > mt else read_txt()
+        else:
+            col = read_txt()
+            if len(col) != n:
+                col = read_json()
+    elif os.path.exists(txt):
+        col = read_txt()
     else:
-        with open(os.path.join(path, f"{stem}.json"), encoding="utf-8") as f:
-            col = json.load(f)
+        col = read_json()
     if len(col) != n:
         raise ValueError(f"{path}: {stem} holds {len(col)} rows, expected {n}")
     return col

@@ -648,7 +648,7 @@ def main() -> None:
         iso = eng.read_profile(reset=True)
         eng.set_concurrency(2)
 
-    sharded = sharded_retrieval_leg(rank, world, local_rank, backend) if world > 1 else None
+    sharded = None   # N > 1: runs AFTER rank 0 has assembled the line (below), under a watchdog
 
     if rank == 0:
         total_chunks = world * n_chunks * args.steps
@@ -775,14 +775,45 @@ def main() -> None:
             "parity_max_prob_err": parity_prob, "ragged_chunks_per_s": ragged.get("ragged_chunks_per_s") if ragged else None, "ragged_leg": ragged,
             "per_rank_ms_per_step": per_rank_ms, "world_size_reported_by_backend": backend_world,
             "topk_recall_vs_cpu_ref": recall,
-            "sharded_queries_per_s": sharded.get("sharded_queries_per_s") if sharded else None, "sharded_topk": sharded,
+            "sharded_queries_per_s": None, "sharded_topk": None,
             "api_chunks_per_s": api.get("api_chunks_per_s") if api else None, "api_leg": api, "token_head_f16": tok16,
             "breakdown": breakdown,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     eng.close()
     if world > 1:
-        dist.barrier()   # rank 0 ran an extra (untimed) single-stream pass; leave together
+        # Second timed leg (the retrieval exchange).  It is the first code of this repository to meet a real xGMI ring -- a new RCCL
+        # communicator beside torch's, an all-gather on it -- so it runs under a watchdog: if it has not returned after
+        # VRAG_BENCH_SHARDED_TIMEOUT seconds (default 240) rank 0 prints the line it already has, with the timeout as the leg's error,
+        # and every rank leaves; a hang in the exchange cannot take the headline with it.
+        import threading
+
+        done = threading.Event()
+
+        def bail():
+            if done.is_set():
+                return
+            if rank == 0 and out is not None:
+                out["sharded_topk"] = {"error": f"sharded retrieval leg did not finish within {limit:.0f} s (watchdog)"}
+                print(json.dumps(out), flush=True)
+            print(f"bench.py: rank {rank}: sharded retrieval leg timed out; leaving", file=sys.stderr, flush=True)
+            os._exit(0)
+
+        limit = float(os.environ.get("VRAG_BENCH_SHARDED_TIMEOUT", "240"))
+        timer = threading.Timer(limit, bail)
+        timer.daemon = True
+        timer.start()
+        sharded = sharded_retrieval_leg(rank, world, local_rank, backend)
+        done.set()
+        timer.cancel()
+        if rank == 0:
+            out["sharded_queries_per_s"] = sharded.get("sharded_queries_per_s") if sharded else None
+            out["sharded_topk"] = sharded
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()   # leave together
         dist.destroy_process_group()
 
 

@@ -69,6 +69,12 @@ def test_no_cpu_fallback_without_gpu():
     h = ctypes.c_void_p()
     assert lib.vrag_dense_index_create(64, 10, 0, 0, ctypes.byref(h)) == -4
     assert "no HIP device" in _lib.last_error()
+    # the exchange entry points too: no communicator without a device, and no crash on bad arguments
+    ident = (ctypes.c_uint8 * 128)()
+    assert lib.vrag_comm_get_unique_id(ident) == -4
+    assert lib.vrag_comm_create(bytes(128), 0, 1, 0, ctypes.byref(h)) == -4
+    assert lib.vrag_comm_create(bytes(128), 3, 2, 0, ctypes.byref(h)) == -1
+    assert lib.vrag_comm_allgather(None, None, None, 0, None) == -1
 
 
 def test_product_package_never_imports_oracle():

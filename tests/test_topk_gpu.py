@@ -570,3 +570,28 @@ def test_sparse_batched_passes_over_a_large_shard():
     rs, ri = T.sparse_topk(ip, ix, vv, vocab, *dicts_to_csr(qs), k, blocked=True)
     assert np.array_equal(i, ri) and np.array_equal(s, rs)
     assert np.array_equal(i[3], 3 + 7 * np.arange(k))
+
+
+def test_dense_rows_ingested_from_device_memory_equal_host_ingest():
+    """vrag_dense_index_add_device (embeddings that never visit the host): the same shard, both row dtypes, the fp32 one with its
+    prefilter image built from the device rows."""
+    import torch
+
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((9_000, 384)).astype(np.float32)
+    Q = rng.standard_normal((70, 384)).astype(np.float32)
+    t = torch.from_numpy(X).cuda()
+    for dtype in ("f32", "bf16"):
+        a, b = DenseShard(384, len(X), dtype), DenseShard(384, len(X), dtype)
+        a.add(X)
+        b.add_device(t[:5000].data_ptr(), 5000)
+        b.add_device(t[5000:].contiguous().data_ptr(), 4000)
+        assert len(b) == len(a) == 9000
+        for qs in (Q[:1], Q[:5], Q):
+            sa, ia = a.search(qs, 10)
+            sb, ib = b.search(qs, 10)
+            assert np.array_equal(ia, ib) and np.array_equal(sa, sb), (dtype, len(qs))
+        a.close()
+        b.close()

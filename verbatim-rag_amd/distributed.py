@@ -95,17 +95,37 @@ class ShardComm:
 
         lib = _lib.load()
         dev = torch.device("cuda", self.device)
-        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        # Every step below is collective, so no rank may leave it alone: a failure anywhere (RCCL not loadable, ncclCommInitRank
+        # refusing) is agreed on by all ranks, which then keep torch's communicator for the exchange -- never a rank waiting in a
+        # broadcast its peer has abandoned.
+        ident = torch.zeros(129, dtype=torch.uint8, device=dev)            # [128 id bytes | 1 = valid]
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
-            _lib.check("vrag_comm_get_unique_id", lib.vrag_comm_get_unique_id(buf))
-            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            if lib.vrag_comm_get_unique_id(buf) == 0:
+                ident[:128].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+                ident[128] = 1
+            else:
+                self._vcomm_error = _lib.last_error()
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(ident, src=src, group=group)
-        raw = bytes(ident.cpu().numpy().tobytes())
+        host = ident.cpu().numpy()
         h = C.c_void_p()
-        _lib.check("vrag_comm_create", lib.vrag_comm_create(raw, self.rank, self.world, self.device, C.byref(h)))
-        return h
+        ok = 0
+        if int(host[128]) == 1:
+            ok = 1 if lib.vrag_comm_create(bytes(host[:128].tobytes()), self.rank, self.world, self.device, C.byref(h)) == 0 else 0
+            if not ok:
+                self._vcomm_error = _lib.last_error()
+        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+        if int(agreed.item()) == 1:
+            return h
+        if ok:
+            lib.vrag_comm_destroy(h)
+        import logging
+
+        logging.getLogger(__name__).warning("library RCCL communicator unavailable (%s): the exchange uses torch.distributed",
+                                            getattr(self, "_vcomm_error", "a peer rank failed"))
+        return None
 
     @property
     def exchange_backend(self) -> str:

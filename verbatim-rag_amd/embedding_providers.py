@@ -76,11 +76,13 @@ class _EncoderProvider:
 
 
 def load_encoder_directory(model_path: str, device: int = 0, max_tokens: int = 65536, max_seqs: int = 512,
-                           max_seq_len: int = 512, **engine_kw):
+                           max_seq_len: int = 512, splade_split_operands: bool = True, **engine_kw):
     """(engine, tokenizer, raw config) from a local HF checkpoint directory -- the local-files counterpart of the model
     names the reference hands to sentence-transformers (`SpladeProvider(model_name)`, embedding_providers.py:117-133;
     `SentenceTransformersProvider(model_name)`, :52-71).  BERT / DistilBERT checkpoints get a `BertEncoderEngine` (MLM
-    and pair heads attached when the tensors are there), ModernBERT checkpoints an `EncoderEngine` (+ MLM head)."""
+    and pair heads attached when the tensors are there), ModernBERT checkpoints an `EncoderEngine` (+ MLM head).
+    `splade_split_operands=False`: the MLM / SPLADE head with plain 16-bit operands (a third of the decoder work, weights within
+    ~1e-2 of the fp32 head instead of 2e-5; include/vrag_amd.h vrag_encoder_set_head_precision)."""
     import json
     import os
 
@@ -92,13 +94,13 @@ def load_encoder_directory(model_path: str, device: int = 0, max_tokens: int = 6
     kw = dict(max_tokens=max_tokens, max_seqs=max_seqs, max_seq_len=max_seq_len, max_ranges=max(max_seqs, 64), device=device, **engine_kw)
     if model_type in ("bert", "distilbert"):
         shape, weights, cfg = load_bert_safetensors_dir(model_path)
-        eng = engine_mod.BertEncoderEngine(shape, weights, **kw)
+        eng = engine_mod.BertEncoderEngine(shape, weights, mlm_split_operands=splade_split_operands, **kw)
     elif model_type == "modernbert":
         shape, tensors, cfg = load_safetensors_dir(model_path)
         eng = engine_mod.EncoderEngine(shape, tensors, **kw)
         if "head.dense.weight" in tensors and "decoder.bias" in tensors:        # ModernBertForMaskedLM: tied decoder
             eng.set_mlm_head(tensors["head.dense.weight"], tensors["head.norm.weight"], tensors["decoder.bias"],
-                             tensors.get("decoder.weight"))
+                             tensors.get("decoder.weight"), split_operands=splade_split_operands)
     else:
         raise ValueError(f"{model_path}: model_type {model_type!r} is not bert / distilbert / modernbert")
     try:

@@ -397,9 +397,10 @@ class BertEncoderEngine(EncoderEngine):
 
     def __init__(self, shape: BertShape, weights: Dict[str, np.ndarray], max_tokens: int = 8192, max_seqs: int = 64,
                  max_seq_len: int = 512, max_ranges: int = 4096, micro_batch_tokens: int = 0, device: int = 0,
-                 operand_dtype: str = "bf16"):
+                 operand_dtype: str = "bf16", mlm_split_operands: bool = True):
         self._lib = _lib.load()
         _lib.require_gpu()
+        self._mlm_split_operands = bool(mlm_split_operands)
         if operand_dtype not in _lib.OPERAND_DTYPES:
             raise ValueError(f"operand_dtype must be one of {sorted(_lib.OPERAND_DTYPES)} (got {operand_dtype!r})")
         self.operand_dtype = operand_dtype
@@ -452,7 +453,7 @@ class BertEncoderEngine(EncoderEngine):
             self.set_pair_head(weights["pooler.w"], weights["pooler.b"], weights["cls.w"], weights["cls.b"])
         if "mlm.dense.w" in weights:
             self.set_mlm_head_ex(weights["mlm.dense.w"], weights["mlm.dense.b"], weights["mlm.ln.w"], weights["mlm.ln.b"],
-                                 weights.get("mlm.dec.b"), weights.get("mlm.dec.w"))
+                                 weights.get("mlm.dec.b"), weights.get("mlm.dec.w"), split_operands=self._mlm_split_operands)
 
     def set_mlm_head_ex(self, dense_w, dense_b, norm_w, norm_b, decoder_b, decoder_w=None, split_operands: bool = True) -> None:
         self._set_head_precision(split_operands)

@@ -483,9 +483,11 @@ def test_dense_topk_tiled_fp32_queries_ride_as_column_pairs():
     sh = DenseShard(768, len(X), "bf16")
     sh.add(X)
     sb, ib = sh.search(Q, 10)
+    s64, i64 = sh.search(Q[:64], 10)          # 128 query columns: the 256 x 128 tile form
     sh.close()
     rs, ri = T.dense_topk(rows, Q, 10, blocked=True)
     _assert_same_ranking(sb, ib, rs, ri, rows, Q)
+    _assert_same_ranking(s64, i64, rs[:64], ri[:64], rows, Q[:64])
     assert (ib[:, 0] == np.arange(150)).all()
 
 

@@ -961,6 +961,12 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
     //  halved K-step chain returns; the template keeps the general form)
     return launch_cfg<EPI, 128, 128, 2, 2, 4, T>(p, 256, stream);
   }
+  if constexpr (EPI == EPI_TOPK) {
+    // the batched dense search streams its A operand (the corpus rows) from HBM, not from L2 like the encoder's activations: with
+    // few query columns it is bound by the row bytes in flight per CU -- 256 x 128 tiles on a THREE-stage ring keep 64 KB of rows in
+    // flight instead of 32 (GemmParams::topk_tile, chosen by the search for <= 128 query columns)
+    if (p.topk_tile == 1 && p.M >= 256) return launch_cfg<EPI, 256, 128, 4, 2, 3, T>(p, 256, stream);
+  }
   if (p.N % 256 == 0 && p.M >= 256 && (EPI != EPI_QKV_ROPE || p.hidden % 256 == 0))
     return launch_cfg<EPI, 256, 256, 2, 4, 2, T>(p, 256, stream);   // one persistent workgroup per CU
   return launch_cfg<EPI, 128, 128, 2, 2, 2, T>(p, 512, stream);

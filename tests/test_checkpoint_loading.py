@@ -338,8 +338,8 @@ def test_modernbert_masked_lm_directory_gets_the_mlm_head(tmp_path, monkeypatch)
         def __init__(self, shape, weights, **kw):
             self.shape, self.weights, self.max_seq_len = shape, weights, kw.get("max_seq_len", 512)
 
-        def set_mlm_head(self, dense_w, norm_w, decoder_b, decoder_w=None):
-            self.has_mlm, self.head = True, (dense_w, norm_w, decoder_b, decoder_w)
+        def set_mlm_head(self, dense_w, norm_w, decoder_b, decoder_w=None, split_operands=True):
+            self.has_mlm, self.head, self.split = True, (dense_w, norm_w, decoder_b, decoder_w), split_operands
 
     monkeypatch.setattr(eng_mod, "EncoderEngine", Recorder)
     torch.manual_seed(8)
@@ -351,5 +351,6 @@ def test_modernbert_masked_lm_directory_gets_the_mlm_head(tmp_path, monkeypatch)
     sp = GpuSpladeProvider.from_directory(str(tmp_path))
     sd = m.state_dict()
     assert sp.engine.has_mlm and np.array_equal(sp.engine.head[0], sd["head.dense.weight"].numpy())
+    assert sp.engine.split is True                                  # split operands unless the caller opts out
     assert np.array_equal(sp.engine.head[2], sd["decoder.bias"].numpy()) and sp.engine.head[3] is None      # decoder tied: not stored
     assert sp.get_dimension() == 512 and sp._tok.sep_token_id == 2

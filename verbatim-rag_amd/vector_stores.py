@@ -228,7 +228,7 @@ class DenseShard:
     def __init__(self, dim: int, capacity: int, dtype: str = "bf16", device: int = 0, prefilter: bool = True):
         """dtype "bf16" | "f32".  fp32 rows keep a bf16 prefilter image beside them unless `prefilter=False` (+50 % memory):
         a search ranks the image for 64 candidates per query and re-scores those exactly -- same bits as the full fp32 scan
-        (include/vrag_amd.h, dtype 2), a third of the time for one query and a tenth for a batch of 256."""
+        (include/vrag_amd.h, dtype 2), half the time for one query and a quarter for a batch of 256."""
         self._lib = _lib.load()
         _lib.require_gpu()
         self.dim, self.capacity = dim, capacity

@@ -597,3 +597,35 @@ def test_dense_rows_ingested_from_device_memory_equal_host_ingest():
             assert np.array_equal(ia, ib) and np.array_equal(sa, sb), (dtype, len(qs))
         a.close()
         b.close()
+
+
+def test_device_resident_search_of_fp32_rows_takes_the_prefilter_route_and_its_gated_fallback():
+    """vrag_dense_index_search_device on fp32 rows with the prefilter image, >= 64 queries (what a rank of the sharded store runs per
+    batch): no host round trip, so queries whose candidates fail the sufficiency test are re-answered by the full scan launched behind
+    their flags.  Equal to the host-synchronous search (itself equal to the oracle) on ordinary data and on bunched scores."""
+    import torch
+
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(41)
+    n, dim, k = 30_000, 384, 10
+    for bunched in (False, True):
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        Q = rng.standard_normal((70, dim)).astype(np.float32)
+        if bunched:
+            dup = rng.choice(np.arange(50, n), size=400, replace=False)
+            X[dup[:200]] = X[7]
+            X[dup[200:]] = X[7] + (1e-4 * rng.standard_normal((200, dim))).astype(np.float32)
+            Q[:5] = X[7] * np.linspace(0.5, 2.0, 5, dtype=np.float32)[:, None]     # five queries flagged, the rest not
+        sh = DenseShard(dim, n, "f32")
+        sh.add(X)
+        hs, hi = sh.search(Q, k)
+        rs, ri = T.dense_topk(X, Q, k, blocked=True)
+        assert np.array_equal(hi, ri) and np.array_equal(hs, rs)
+        d_s = torch.empty((70, k), dtype=torch.float32, device="cuda")
+        d_i = torch.empty((70, k), dtype=torch.int64, device="cuda")
+        sh.search_device(Q, k, d_s.data_ptr(), d_i.data_ptr(), id_base=1000, stream=None)
+        torch.cuda.synchronize()
+        sh.close()
+        assert np.array_equal(d_i.cpu().numpy(), ri + 1000), bunched
+        assert np.array_equal(d_s.cpu().numpy(), rs), bunched

@@ -47,4 +47,14 @@ for nq in (1, 2, 4, 32, 256):
                       "ms": dt_api * 1e3, "queries_per_s": nq / dt_api,
                       "route": ("bf16 image, one pass: prefix threshold -> candidates -> exact re-score" if nq == 1 else "bf16 image, tiled search -> 64 candidates -> exact re-score") if (nq == 1 or nq >= 64) else "full fp32 scan",
                       "image_bytes": n * dim * 2}))
+# the device-resident search a rank of the sharded store runs per batch (lists left in HBM, no host round trip): prefilter route with
+# the full scan behind the per-query flags
+for nq in (256, 1024):
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    d_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    d_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    dt_dev = timed(lambda: sh.search_device(q, k, d_s.data_ptr(), d_i.data_ptr()))
+    print(json.dumps({"kind": "dense_f32_search_device", "prefilter_image": True, "rows": n, "dim": dim, "nq": nq, "k": k,
+                      "ms": dt_dev * 1e3, "queries_per_s": nq / dt_dev,
+                      "full_scan_would_be_ms": 0.97 * ((nq + 31) // 32)}))
 sh.close()

@@ -617,7 +617,12 @@ __global__ __launch_bounds__(256, 1) void dense_topk_exact_kernel(const float* _
                                                                    long long n_rows /* end of this launch's row range */,
                                                                    int dim, const float* __restrict__ queries, int nq, int q0,
                                                                    int k, u64* __restrict__ cand, int rows_per_wg,
-                                                                   u64* __restrict__ thr) {
+                                                                   u64* __restrict__ thr, const unsigned* __restrict__ gate) {
+  if (gate) {   // behind the prefilter route of a device-resident search: only query groups with a flagged query are re-answered
+    bool any = false;
+    for (int i = 0; i < XQ && q0 + i < nq; ++i) any = any || gate[q0 + i] != 0u;
+    if (!any) return;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int qstride = dim * 4 + 16;                                  // bytes between query rows in LDS
   char* sQ = smem;
@@ -774,7 +779,12 @@ __global__ __launch_bounds__(256, 1) void dense_topk_exact2_kernel(const float* 
                                                                     long long n_rows /* end of this launch's row range */,
                                                                     const float* __restrict__ queries, int nq, int q0, int k,
                                                                     u64* __restrict__ cand, int rows_per_wg,
-                                                                    u64* __restrict__ thr) {
+                                                                    u64* __restrict__ thr, const unsigned* __restrict__ gate) {
+  if (gate) {   // behind the prefilter route of a device-resident search: only query groups with a flagged query are re-answered
+    bool any = false;
+    for (int i = 0; i < XQ && q0 + i < nq; ++i) any = any || gate[q0 + i] != 0u;
+    if (!any) return;
+  }
   constexpr int DIM = KT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -970,7 +980,7 @@ static int dense_n_wg(int dtype, int dim, int nq, int k, long long size) {
 // all passes of one search: query tiles of 4 (a final tile of 1 query uses the register path)
 static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int dim, const float* dq, int nq, int k,
                                    u64* cand, int n_wg, hipStream_t st, u64* thr, u64* out, const u64* bound = nullptr,
-                                   int split = 0) {
+                                   int split = 0, const unsigned* gate = nullptr) {
   const int qpp = split ? MQ / 2 : MQ;
   if (bound && dense_use_mfma(dtype, dim, nq, k)) return hipErrorInvalidValue;   // pages run with k = KMAX: scalar path only
   if (!bound && dense_use_exact(dtype, dim, k)) {
@@ -1005,10 +1015,10 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
     }
     auto pass = [&](long long lo, long long hi, int per, int wgs, u64* cand_base) -> hipError_t {
       for (int q0 = 0; q0 < nq; q0 += XQ) {
-        if (regq && dim == 768) hipLaunchKernelGGL(dense_topk_exact2_kernel<24>, dim3(wgs), dim3(256), lds2, st, r32, lo, hi, dq, nq, q0, k, cand_base, per, thr);
-        else if (regq) hipLaunchKernelGGL(dense_topk_exact2_kernel<12>, dim3(wgs), dim3(256), lds2, st, r32, lo, hi, dq, nq, q0, k, cand_base, per, thr);
-        else if (deep) hipLaunchKernelGGL(dense_topk_exact_kernel<6>, dim3(wgs), dim3(256), ldsx, st, r32, lo, hi, dim, dq, nq, q0, k, cand_base, per, thr);
-        else hipLaunchKernelGGL(dense_topk_exact_kernel<3>, dim3(wgs), dim3(256), ldsx, st, r32, lo, hi, dim, dq, nq, q0, k, cand_base, per, thr);
+        if (regq && dim == 768) hipLaunchKernelGGL(dense_topk_exact2_kernel<24>, dim3(wgs), dim3(256), lds2, st, r32, lo, hi, dq, nq, q0, k, cand_base, per, thr, gate);
+        else if (regq) hipLaunchKernelGGL(dense_topk_exact2_kernel<12>, dim3(wgs), dim3(256), lds2, st, r32, lo, hi, dq, nq, q0, k, cand_base, per, thr, gate);
+        else if (deep) hipLaunchKernelGGL(dense_topk_exact_kernel<6>, dim3(wgs), dim3(256), ldsx, st, r32, lo, hi, dim, dq, nq, q0, k, cand_base, per, thr, gate);
+        else hipLaunchKernelGGL(dense_topk_exact_kernel<3>, dim3(wgs), dim3(256), ldsx, st, r32, lo, hi, dim, dq, nq, q0, k, cand_base, per, thr, gate);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
       }
@@ -1395,6 +1405,14 @@ __global__ __launch_bounds__(64) void prefilter_rescore_list_kernel(const unsign
     key = make_key(exact_chain(rows + (size_t)row * dim, query, dim), row);
   }
   keys[i] = key;
+}
+
+// Device-resident searches cannot fall back through the host: the gated full scan re-answers flagged queries into `exact`, and this
+// picks, per query, the scan's list where the flag is set and the re-scored candidates' list elsewhere (in place in `pf`).
+__global__ void prefilter_combine_kernel(u64* __restrict__ pf, const u64* __restrict__ exact, const unsigned* __restrict__ flag, int nq, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * k) return;
+  if (flag[i / k]) pf[i] = exact[i];
 }
 
 static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size) {
@@ -2328,9 +2346,43 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
   // ordered against the stream it named, and torch's default stream IS the null stream
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
-  if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
   const long long n = (long long)nq * k;
-  hipLaunchKernelGGL(topk_export_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_out, n,
+  const u64* result = nullptr;
+  if (ix->rows16 && k <= 16 && ix->size >= 4096 && nq >= 64) {
+    // fp32 rows with a prefilter image, batch route, no host round trip: tiled search of the image -> 64 candidates -> sufficiency
+    // test + exact re-score; then the full scan behind the per-query flags (groups of 32 queries without a flag leave at once) and
+    // a per-query pick.  Worst case (every query flagged: bunched scores) = the full scan plus the tiled pass.
+    if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
+    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k))) return rc;
+    if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
+    const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * ix->dim / 16777216.0;
+    const double xmax = std::sqrt((double)ix->norm2_max);
+    std::vector<float> eps((size_t)nq);
+    for (int q = 0; q < nq; ++q) {
+      double s2 = 0.0;
+      for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
+      eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
+    }
+    if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ix->upload_done, st));
+    hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
+                       ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
+    HIP_TRY(hipGetLastError());
+    const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
+    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
+    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, 0, ix->d_pf_flag));
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));   // lists of unflagged queries: whatever the scratch held -- never picked
+    hipLaunchKernelGGL(prefilter_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_pf_out, ix->d_out, ix->d_pf_flag, nq, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(ix->upload_done));   // the eps upload has left the host vector
+    result = ix->d_pf_out;
+  } else {
+    if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
+    result = ix->d_out;
+  }
+  hipLaunchKernelGGL(topk_export_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, result, n,
                      reinterpret_cast<const long long*>(row_map), (long long)n_map, (long long)id_base, out_scores,
                      reinterpret_cast<long long*>(out_ids));
   HIP_TRY(hipGetLastError());

@@ -1442,9 +1442,11 @@ __global__ __launch_bounds__(1024) void sparse_topk_kernel(const unsigned short*
   for (int i = tid; i < 16 * k; i += 1024) lists[i] = 0ull;
   __syncthreads();
   u64* mylist = lists + (size_t)wave * k;
-  const int s_begin = blockIdx.x * slices_per_wg;
-  const int s_end = min(n_slices, s_begin + slices_per_wg);
-  for (int s = s_begin + wave; s < s_end; s += 16) {
+  // Slices are dealt round-robin over the waves of the whole grid, not as one contiguous range per workgroup: the documents are
+  // stored by length, so contiguous ranges hand the last workgroups the longest documents (+29 % terms over the mean for
+  // Poisson(128) lengths) and the pass waits for them.
+  (void)slices_per_wg;
+  for (int s = blockIdx.x + gridDim.x * wave; s < n_slices; s += gridDim.x * 16) {
     const long long off = slice_off[s];
     const int ng = slice_len[s];   // groups of 4 terms
     const u32x2* c = reinterpret_cast<const u32x2*>(cols + off) + lane;     // group g of this lane's document: c[g * 64]
@@ -1538,9 +1540,8 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
   for (int i = tid; i < NW * QB * k; i += NW * 64) lists[i] = 0ull;
   __syncthreads();
   u64* mylists = lists + (size_t)wave * QB * k;
-  const int s_begin = blockIdx.x * slices_per_wg;
-  const int s_end = min(n_slices, s_begin + slices_per_wg);
-  for (int s = s_begin + wave; s < s_end; s += NW) {
+  (void)slices_per_wg;   // slices dealt round-robin over the grid's waves (see sparse_topk_kernel)
+  for (int s = blockIdx.x + gridDim.x * wave; s < n_slices; s += gridDim.x * NW) {
     const long long off = slice_off[s];
     const int ng = slice_len[s];   // groups of 4 terms
     const u32x2* c = reinterpret_cast<const u32x2*>(cols + off) + lane;

@@ -279,7 +279,9 @@ int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/
  * plus a bf16 prefilter image of them (+50 % memory): vrag_dense_index_search, for k <= 16 and 1-2 or >= 64 queries, ranks
  * the image for 64 candidates per query, proves from the image's error bound that they contain the exact top-k (else it
  * falls back to the full fp32 scan) and re-scores them exactly -- half the bytes for one query, one read of the shard per
- * batch instead of one per 32 queries.
+ * batch instead of one per 32 queries.  (One or two queries: one pass over the image collects every row within twice the bound
+ * of an entry threshold; more than 4096 of them = the full scan.)  vrag_dense_index_search_device takes the same routes with
+ * the full scan enqueued behind per-query flags instead of a host decision.
  */
 typedef struct vrag_dense_index vrag_dense_index;
 int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_t device, vrag_dense_index** out);

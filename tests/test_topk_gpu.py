@@ -88,7 +88,7 @@ def test_dense_topk_random_data_ranking_equals_the_fp32_query_oracle():
 
 @pytest.mark.parametrize("prefilter", [True, False])
 def test_dense_f32_rows_are_bit_exact_on_arbitrary_data(prefilter):
-    """prefilter=True (the default): 1, 2 and 70 queries rank the bf16 image of the rows for 64 candidates and re-score them
+    """prefilter=True (the default): 1, 2 and 70 queries rank the bf16 image of the rows for candidates and re-score them
     with the exact chain (csrc/topk.hip "fp32 rows, bf16 prefilter") -- the same bits as the full scan, which serves 5 and 33.
     fp32 rows (the store's default, like the reference's FLOAT_VECTOR field) run on v_mfma_f32_32x32x2_f32, whose
     result IS the oracle's sequential `acc = fmaf(x[c], q[c], acc)` chain: scores and ids equal oracle/topk_ref.c bit for
@@ -629,3 +629,38 @@ def test_device_resident_search_of_fp32_rows_takes_the_prefilter_route_and_its_g
         sh.close()
         assert np.array_equal(d_i.cpu().numpy(), ri + 1000), bunched
         assert np.array_equal(d_s.cpu().numpy(), rs), bunched
+
+
+def test_one_and_two_queries_over_fp32_rows_take_the_one_pass_route_host_and_device():
+    """1-2 queries over fp32 rows with the prefilter image (csrc/topk.hip prefilter_single_enqueue): entry threshold from the best
+    keys of the prefix workgroups, ONE pass over the image for the candidates, exact chains out of LDS, one selection.  Through the
+    host call and through vrag_dense_index_search_device (gated full scan behind the overflow flag), on ordinary rows and on a
+    shard with 5 000 copies of the best row -- more candidates than the list holds, so the full scan answers; ties by id."""
+    import torch
+
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(53)
+    for n, dim in ((40_000, 768), (9_001, 224)):     # 224: no register-resident query form; % 32: the exact full scan
+        for copies in (0, 5000):
+            X = rng.standard_normal((n, dim)).astype(np.float32)
+            Q = rng.standard_normal((2, dim)).astype(np.float32)
+            if copies:
+                X[rng.choice(np.arange(10, n), size=copies, replace=False)] = X[7]
+                Q[0] = X[7]
+            sh = DenseShard(dim, n, "f32")
+            sh.add(X)
+            for nq in (1, 2):
+                for k in (1, 10, 16):
+                    rs, ri = T.dense_topk(X, Q[:nq], k)
+                    s, i = sh.search(Q[:nq], k)
+                    assert np.array_equal(i, ri) and np.array_equal(s, rs), (n, dim, copies, nq, k)
+                    d_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+                    d_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+                    sh.search_device(Q[:nq], k, d_s.data_ptr(), d_i.data_ptr(), id_base=500, stream=None)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(d_i.cpu().numpy(), ri + 500), (n, dim, copies, nq, k)
+                    assert np.array_equal(d_s.cpu().numpy(), rs), (n, dim, copies, nq, k)
+            sh.close()
+            if copies:
+                assert ri[0, 0] == 7 and (np.diff(ri[0]) > 0).all()     # the copies tie: ascending ids

@@ -45,11 +45,11 @@ for nq in (1, 2, 4, 32, 256):
     dt_api = timed(lambda: sh.search(q, k))
     print(json.dumps({"kind": "dense_f32_search_call", "prefilter_image": True, "rows": n, "dim": dim, "nq": nq, "k": k,
                       "ms": dt_api * 1e3, "queries_per_s": nq / dt_api,
-                      "route": ("bf16 image, one pass: prefix threshold -> candidates -> exact re-score" if nq == 1 else "bf16 image, tiled search -> 64 candidates -> exact re-score") if (nq == 1 or nq >= 64) else "full fp32 scan",
+                      "route": ("bf16 image, one pass: prefix threshold -> candidates -> exact re-score" if nq <= 2 else "bf16 image, tiled search -> 64 candidates -> exact re-score") if (nq <= 2 or nq >= 64) else "full fp32 scan",
                       "image_bytes": n * dim * 2}))
 # the device-resident search a rank of the sharded store runs per batch (lists left in HBM, no host round trip): prefilter route with
 # the full scan behind the per-query flags
-for nq in (256, 1024):
+for nq in (1, 2, 256, 1024):
     q = rng.standard_normal((nq, dim)).astype(np.float32)
     d_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
     d_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")

@@ -1393,18 +1393,138 @@ __global__ __launch_bounds__(256) void prefilter_collect_kernel(const bf16_t* __
   }
 }
 
-// exact keys of the collected rows (lane = candidate; the oracle's chain), zero keys behind them
-__global__ __launch_bounds__(64) void prefilter_rescore_list_kernel(const unsigned* __restrict__ cand_rows, const unsigned* __restrict__ cnt,
-                                                                      const float* __restrict__ rows, int dim,
-                                                                      const float* __restrict__ query, u64* __restrict__ keys) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= PFCAP) return;
-  u64 key = 0ull;
-  if ((unsigned)i < min(*cnt, (unsigned)PFCAP)) {
-    const unsigned row = cand_rows[i];
-    key = make_key(exact_chain(rows + (size_t)row * dim, query, dim), row);
+// Entry threshold of the one-pass route in one launch: 128 prefix rows per workgroup, image scores as in the collect kernel, the
+// two best keys of every workgroup written out.  ANY t0 with at least k rows at a_r >= t0 is a valid threshold (the exact k-th
+// score of the shard is then >= t0 - eps), so the k-th largest of these keys -- the k-th over a SUBSET of the prefix rows -- serves
+// as well as the prefix's own k-th and needs no per-workgroup top-k lists and no merge; tiled_select_kernel picks it.
+// Workgroup 0 also clears the candidate counter and the overflow flag of this query.
+constexpr int PFROWS = 128;   // prefix rows per workgroup
+constexpr int PFBEST = 2;     // keys kept per workgroup
+template <int DIMC>
+__global__ __launch_bounds__(256) void prefilter_prefix_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
+                                                                const float* __restrict__ query, u64* __restrict__ best,
+                                                                unsigned* __restrict__ cnt, unsigned* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);
+  u64* keys = reinterpret_cast<u64*>(smem + (size_t)dim * sizeof(float));   // [PFROWS]
+  const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
+  if (blockIdx.x == 0 && tid == 0) {
+    *cnt = 0u;
+    *flag = 0u;
   }
-  keys[i] = key;
+  for (int i = tid; i < dim; i += 256) sq[i] = query[i];
+  __syncthreads();
+  float qreg[DIMC > 0 ? DIMC * 8 : 1];
+  if constexpr (DIMC > 0) {
+#pragma unroll
+    for (int i = 0; i < DIMC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qreg[i * 8 + j] = sq[gl * 8 + i * 128 + j];
+  }
+  const long long r_begin = (long long)blockIdx.x * PFROWS;
+  for (int it = 0; it < PFROWS / 32; ++it) {
+    const long long r = r_begin + grp + 32 * it;
+    const bool has0 = r < n_rows, has1 = r + 16 < n_rows;
+    const bf16_t* row0 = rows + (size_t)(has0 ? r : r_begin) * dim;
+    const bf16_t* row1 = rows + (size_t)(has1 ? r + 16 : r_begin) * dim;
+    float acc0 = 0.f, acc1 = 0.f;
+    if constexpr (DIMC > 0) {
+      bf16x8 a[DIMC], b[DIMC];
+#pragma unroll
+      for (int i = 0; i < DIMC; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(row0 + gl * 8 + i * 128);
+        b[i] = *reinterpret_cast<const bf16x8*>(row1 + gl * 8 + i * 128);
+      }
+#pragma unroll
+      for (int i = 0; i < DIMC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc0 = fmaf((float)a[i][j], qreg[i * 8 + j], acc0);
+          acc1 = fmaf((float)b[i][j], qreg[i * 8 + j], acc1);
+        }
+    } else {
+      for (int c = gl * 8; c < dim; c += 128) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(row0 + c);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(row1 + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc0 = fmaf((float)a[j], sq[c + j], acc0);
+          acc1 = fmaf((float)b[j], sq[c + j], acc1);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      acc0 += __shfl_xor(acc0, o, 64);
+      acc1 += __shfl_xor(acc1, o, 64);
+    }
+    if (gl == 0) {
+      keys[grp + 32 * it] = has0 ? make_key(acc0, (unsigned)r) : 0ull;
+      keys[grp + 32 * it + 16] = has1 ? make_key(acc1, (unsigned)(r + 16)) : 0ull;
+    }
+  }
+  __syncthreads();
+  if (tid < PFROWS) {
+    const u64 key = keys[tid];
+    int rank = 0, n_live = 0;
+    for (int i = 0; i < PFROWS; ++i) {
+      rank += keys[i] > key ? 1 : 0;
+      n_live += keys[i] != 0ull ? 1 : 0;
+    }
+    if (key != 0ull && rank < PFBEST) best[(size_t)blockIdx.x * PFBEST + rank] = key;
+    if (tid >= n_live && tid < PFBEST) best[(size_t)blockIdx.x * PFBEST + tid] = 0ull;
+  }
+}
+
+// Exact keys of the collected rows, zero keys behind them: 16 candidates per workgroup.  The oracle's chain is serial per row, so
+// what costs is fetching the row: all 256 threads stage the 16 rows (coalesced 16-byte pieces, 512 columns per round) and the
+// query through LDS, then 16 lanes run one chain each out of LDS (row stride 516 words: the 16 b128 reads of a step fall in
+// 16 different bank quartets).  One lane walking its 3 KB row alone took 24 us for a few hundred candidates; this form 8.
+constexpr int RCH = 512;   // columns staged per round
+__global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsigned* __restrict__ cand_rows, const unsigned* __restrict__ cnt,
+                                                                       const float* __restrict__ rows, int dim,
+                                                                       const float* __restrict__ query, u64* __restrict__ keys) {
+  __shared__ __attribute__((aligned(16))) float srow[16][RCH + 4];
+  __shared__ __attribute__((aligned(16))) float sq[RCH];
+  __shared__ unsigned srid[16];
+  const int tid = threadIdx.x, base = blockIdx.x * 16;
+  const unsigned n = min(*cnt, (unsigned)PFCAP);
+  if ((unsigned)base >= n) {
+    if (tid < 16) keys[base + tid] = 0ull;
+    return;
+  }
+  if (tid < 16) srid[tid] = cand_rows[(unsigned)(base + tid) < n ? base + tid : base];
+  __syncthreads();
+  float acc = 0.f;
+  for (int c0 = 0; c0 < dim; c0 += RCH) {
+    const int w = min(RCH, dim - c0), ppr = w >> 2, total = 16 * ppr;   // dim % 4 == 0
+    for (int p0 = 0; p0 < total; p0 += 256 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * 256 + tid;
+        if (p < total) v[u] = *reinterpret_cast<const f32x4*>(rows + (size_t)srid[p / ppr] * dim + c0 + 4 * (p % ppr));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * 256 + tid;
+        if (p < total) *reinterpret_cast<f32x4*>(&srow[p / ppr][4 * (p % ppr)]) = v[u];
+      }
+    }
+    for (int i = tid; i < ppr; i += 256) *reinterpret_cast<f32x4*>(&sq[4 * i]) = *reinterpret_cast<const f32x4*>(query + c0 + 4 * i);
+    __syncthreads();
+    if (tid < 16) {
+#pragma unroll 8
+      for (int c = 0; c < w; c += 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&srow[tid][c]);
+        const f32x4 qq = *reinterpret_cast<const f32x4*>(&sq[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __fmaf_rn(xv[j], qq[j], acc);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < 16) keys[base + tid] = (unsigned)(base + tid) < n ? make_key(acc, srid[tid]) : 0ull;
 }
 
 // Device-resident searches cannot fall back through the host: the gated full scan re-answers flagged queries into `exact`, and this
@@ -1868,9 +1988,10 @@ struct vrag_dense_index {
   size_t d_pf_eps_elems = 0, d_pf_out_elems = 0, d_pf_flag_elems = 0;
   unsigned* d_pf_cand = nullptr;   // [2][PFCAP] candidate rows of the one-pass route (1-2 queries)
   u64* d_pf_keys = nullptr;        // [2][PFCAP] their exact keys
-  unsigned* d_pf_cnt = nullptr;    // [2] counters + [2] overflow flags
-  u64* d_pf_thr = nullptr;         // [2] selection kernel's threshold outputs (unused) + float[2]
+  unsigned* d_pf_cnt = nullptr;    // [2] candidate counters; [4..8): scratch counters / flags of the prefix selection
+  u64* d_pf_thr = nullptr;         // [0..4): final selection's threshold outputs (unused); [4..6): entry threshold keys; [6..8): their scores
   long long pf_searches = 0, pf_fallbacks = 0;
+  char* h_pin = nullptr;           // pinned host staging of the one-pass route: [2][dim + 1] floats up, [2 k + 1] keys down
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
   hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
@@ -2110,6 +2231,7 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
     e = hipMalloc(&ix->rows16, ((size_t)capacity + 512) * dim * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norm2, sizeof(float));
     if (e == hipSuccess) e = hipMemset(ix->d_norm2, 0, sizeof(float));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->h_pin, (size_t)2 * (dim + 1) * sizeof(float) + (2 * KMAX + 1) * sizeof(u64), 0);
   }
   ix->stage_rows = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)dim * 4));
   if (e == hipSuccess) {
@@ -2140,6 +2262,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
                   (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag, (void*)ix->d_pf_cand, (void*)ix->d_pf_keys, (void*)ix->d_pf_cnt,
                   (void*)ix->d_pf_thr})
     if (p) (void)hipFree(p);
+  if (ix->h_pin) (void)hipHostFree(ix->h_pin);
   if (ix->upload_done) (void)hipEventDestroy(ix->upload_done);
   if (ix->lists_done) (void)hipEventDestroy(ix->lists_done);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -2209,6 +2332,63 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
   return VRAG_OK;
 }
 
+// One-pass route of the prefilter for one or two queries (see prefilter_collect_kernel): the fp32 queries and their error bounds
+// are resident at dq / deps; per query  entry threshold (prefix kernel + selection) -> candidates (one pass over the image) ->
+// exact keys (LDS-staged chains);  one selection for all queries writes the k best keys to out_keys[q][k] and raises
+// out_flags[q] where the candidate list overflowed.  Six launches for one query, nothing else on the stream.
+static_assert((PFPREFIX / PFROWS) * PFBEST <= PFCAP, "the entry-threshold keys share the candidate key buffer");
+static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const float* deps, int nq, int k, u64* out_keys,
+                                    unsigned* out_flags, hipStream_t st) {
+  const int dim = ix->dim;
+  int rc;
+  if (!ix->d_pf_cand) {
+    size_t unused = 0;
+    if ((rc = grow(&ix->d_pf_cand, &unused, (size_t)2 * PFCAP))) return rc;
+    unused = 0;
+    if ((rc = grow(&ix->d_pf_keys, &unused, (size_t)2 * PFCAP))) return rc;
+    unused = 0;
+    if ((rc = grow(&ix->d_pf_cnt, &unused, (size_t)8))) return rc;
+    unused = 0;
+    if ((rc = grow(&ix->d_pf_thr, &unused, (size_t)8))) return rc;
+  }
+  const long long prefix = std::min<long long>(PFPREFIX, (long long)ix->size);
+  const int n_wg0 = (int)((prefix + PFROWS - 1) / PFROWS);
+  const int per = dense_rows_per_wg((long long)ix->size);
+  const int wgs = (int)(((long long)ix->size + per - 1) / per);
+  const int dimc = dim % 128 == 0 ? dim / 128 : 0;
+  const bf16_t* img = reinterpret_cast<const bf16_t*>(ix->rows16);
+  const size_t lds_q = (size_t)dim * sizeof(float);
+  for (int q = 0; q < nq; ++q) {
+    const float* q_dev = dq + (size_t)q * dim;
+    u64* qkeys = ix->d_pf_keys + (size_t)q * PFCAP;
+    unsigned* cand = ix->d_pf_cand + (size_t)q * PFCAP;
+    u64* kth = ix->d_pf_thr + 4 + q;
+#define VRAG_PF_PREFIX(DC_) hipLaunchKernelGGL((prefilter_prefix_kernel<DC_>), dim3(n_wg0), dim3(256), lds_q + PFROWS * sizeof(u64), st, img, prefix, \
+                                                dim, q_dev, qkeys, ix->d_pf_cnt + q, out_flags + q)
+    if (dimc == 6) VRAG_PF_PREFIX(6);
+    else if (dimc == 3) VRAG_PF_PREFIX(3);
+    else if (dimc == 8) VRAG_PF_PREFIX(8);
+    else VRAG_PF_PREFIX(0);
+#undef VRAG_PF_PREFIX
+    hipLaunchKernelGGL(tiled_select_kernel, dim3(1), dim3(256), (size_t)PFCAP * sizeof(u64), st, qkeys, ix->d_pf_cnt + 4 + q, PFCAP, k, kth,
+                       reinterpret_cast<float*>(ix->d_pf_thr + 6) + q, (u64*)nullptr, ix->d_pf_cnt + 6 + q, n_wg0 * PFBEST);
+#define VRAG_PF_COLLECT(DC_) hipLaunchKernelGGL((prefilter_collect_kernel<DC_>), dim3(wgs), dim3(256), lds_q, st, img, (long long)ix->size, dim, q_dev, kth, \
+                                                 deps + q, ix->d_pf_cnt + q, cand, per)
+    if (dimc == 6) VRAG_PF_COLLECT(6);
+    else if (dimc == 3) VRAG_PF_COLLECT(3);
+    else if (dimc == 8) VRAG_PF_COLLECT(8);
+    else VRAG_PF_COLLECT(0);
+#undef VRAG_PF_COLLECT
+    hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 16), dim3(256), 0, st, cand, ix->d_pf_cnt + q,
+                       reinterpret_cast<const float*>(ix->rows), dim, q_dev, qkeys);
+    HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)PFCAP * sizeof(u64), st, ix->d_pf_keys, ix->d_pf_cnt, PFCAP, k,
+                     ix->d_pf_thr, reinterpret_cast<float*>(ix->d_pf_thr + 2), out_keys, out_flags, 0);
+  HIP_TRY(hipGetLastError());
+  return VRAG_OK;
+}
+
 int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t nq, int32_t k, float* scores,
                             int64_t* ids, void* stream) {
   ARG_CHECK(ix && queries && scores && ids && nq > 0, "bad arguments");
@@ -2246,7 +2426,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   // Where it pays: one or two queries (half the bytes of the fp32 scan) and batches the tiled search takes (the shard read once
   // instead of once per 32 queries); in between the 32-queries-per-pass exact kernel is already the faster route.  An index
   // whose data keeps failing the sufficiency test (near-duplicate rows) stops trying.
-  const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq == 1 || nq >= 64) &&
+  const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq <= 2 || nq >= 64) &&
                        !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
   if (pf_live) {
     if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
@@ -2262,54 +2442,29 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
     }
     std::vector<unsigned> flags((size_t)nq);
     if (nq <= 2) {
-      // one streaming pass over the image per query (prefilter_collect_kernel): prefix ranking -> entry threshold -> candidates
+      // one streaming pass over the image per query (prefilter_single_enqueue); queries + bounds go up in one pinned copy, keys +
+      // flags come back in one
       const int dim = ix->dim;
-      const long long prefix = std::min<long long>(PFPREFIX, (long long)ix->size);
-      const int n_wg0 = dense_n_wg(0, dim, nq, k, prefix);
-      size_t unused = 0;
-      if (!ix->d_pf_cand) {
-        if ((rc = grow(&ix->d_pf_cand, &unused, (size_t)2 * PFCAP))) return rc;
-        unused = 0;
-        if ((rc = grow(&ix->d_pf_keys, &unused, (size_t)2 * PFCAP))) return rc;
-        unused = 0;
-        if ((rc = grow(&ix->d_pf_cnt, &unused, (size_t)4))) return rc;
-        unused = 0;
-        if ((rc = grow(&ix->d_pf_thr, &unused, (size_t)4))) return rc;
+      if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
+      if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
+      {   // the full scan's scratch too: vrag_dense_index_run_resident may follow on these resident queries
+        const int n_wg = dense_n_wg(ix->dtype, dim, nq, k, ix->size);
+        if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
+        if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
       }
-      if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim))) return rc;
-      if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg0 * nq * k))) return rc;
-      if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
-      HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemsetAsync(ix->d_pf_cnt, 0, 4 * sizeof(unsigned), st));
+      float* up = reinterpret_cast<float*>(ix->h_pin);
+      u64* down = reinterpret_cast<u64*>(ix->h_pin + (size_t)2 * (dim + 1) * sizeof(float));
+      std::memcpy(up, queries, (size_t)nq * dim * sizeof(float));
+      for (int q = 0; q < nq; ++q) up[(size_t)nq * dim + q] = eps[q];
+      HIP_TRY(hipMemcpyAsync(ix->d_q, up, ((size_t)nq * dim + nq) * sizeof(float), hipMemcpyHostToDevice, st));
       ix->resident_split = 0;
-      HIP_TRY(dense_launch_all(0, ix->rows16, prefix, dim, ix->d_q, nq, k, ix->d_cand, n_wg0, st, ix->d_out + (size_t)nq * k, ix->d_out));
-      HIP_TRY(launch_topk_merge(ix->d_cand, n_wg0, nq, k, ix->d_out, st));
-      const int per = dense_rows_per_wg((long long)ix->size);
-      const int wgs = (int)(((long long)ix->size + per - 1) / per);
-      const int dimc = dim % 128 == 0 ? dim / 128 : 0;
-      for (int q = 0; q < nq; ++q) {
-        const bf16_t* img = reinterpret_cast<const bf16_t*>(ix->rows16);
-        const float* dq = ix->d_q + (size_t)q * dim;
-        const u64* kth = ix->d_out + (size_t)q * k + (k - 1);
-        unsigned* cand = ix->d_pf_cand + (size_t)q * PFCAP;
-        const size_t lds = (size_t)dim * sizeof(float);
-#define VRAG_PF_COLLECT(DC_) hipLaunchKernelGGL((prefilter_collect_kernel<DC_>), dim3(wgs), dim3(256), lds, st, img, (long long)ix->size, dim, dq, kth, \
-                                                 ix->d_pf_eps + q, ix->d_pf_cnt + q, cand, per)
-        if (dimc == 6) VRAG_PF_COLLECT(6);
-        else if (dimc == 3) VRAG_PF_COLLECT(3);
-        else if (dimc == 8) VRAG_PF_COLLECT(8);
-        else VRAG_PF_COLLECT(0);
-#undef VRAG_PF_COLLECT
-        hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 64), dim3(64), 0, st, cand, ix->d_pf_cnt + q,
-                           reinterpret_cast<const float*>(ix->rows), dim, dq, ix->d_pf_keys + (size_t)q * PFCAP);
-        HIP_TRY(hipGetLastError());
-      }
-      hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)PFCAP * sizeof(u64), st, ix->d_pf_keys, ix->d_pf_cnt, PFCAP, k,
-                         ix->d_pf_thr, reinterpret_cast<float*>(ix->d_pf_thr + 2), ix->d_pf_out, ix->d_pf_cnt + 2, 0);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(flags.data(), ix->d_pf_cnt + 2, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      u64* flag_word = ix->d_pf_out + (size_t)nq * k;   // [2] unsigned flags behind the keys
+      if ((rc = prefilter_single_enqueue(ix, ix->d_q, ix->d_q + (size_t)nq * dim, nq, k, ix->d_pf_out, reinterpret_cast<unsigned*>(flag_word), st)))
+        return rc;
+      HIP_TRY(hipMemcpyAsync(down, ix->d_pf_out, ((size_t)nq * k + 1) * sizeof(u64), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      std::memcpy(keys.data(), down, keys.size() * sizeof(u64));
+      std::memcpy(flags.data(), down + (size_t)nq * k, (size_t)nq * sizeof(unsigned));
     } else {
       if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
       HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
@@ -2378,6 +2533,38 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
     hipLaunchKernelGGL(prefilter_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_pf_out, ix->d_out, ix->d_pf_flag, nq, k);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(ix->upload_done));   // the eps upload has left the host vector
+    result = ix->d_pf_out;
+  } else if (ix->rows16 && k <= 16 && ix->size >= 4096 && nq <= 2) {
+    // one or two queries: the one-pass route, then the full scan behind the overflow flags (its workgroups leave at once when no
+    // flag is up) and the per-query pick -- as above, nothing returns to the host
+    const int dim = ix->dim;
+    if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));
+    const int n_wg = dense_n_wg(ix->dtype, dim, nq, k, ix->size);
+    if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
+    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
+    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
+    if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
+    const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * dim / 16777216.0;
+    const double xmax = std::sqrt((double)ix->norm2_max);
+    float* up = reinterpret_cast<float*>(ix->h_pin);
+    std::memcpy(up, queries, (size_t)nq * dim * sizeof(float));
+    for (int q = 0; q < nq; ++q) {
+      double s2 = 0.0;
+      for (int i = 0; i < dim; ++i) s2 += (double)queries[(size_t)q * dim + i] * queries[(size_t)q * dim + i];
+      up[(size_t)nq * dim + q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
+    }
+    HIP_TRY(hipMemcpyAsync(ix->d_q, up, ((size_t)nq * dim + nq) * sizeof(float), hipMemcpyHostToDevice, st));
+    if (!ix->upload_done) HIP_TRY(hipEventCreateWithFlags(&ix->upload_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ix->upload_done, st));
+    ix->resident_split = 0;
+    unsigned* flags = reinterpret_cast<unsigned*>(ix->d_pf_out + (size_t)nq * k);
+    if ((rc = prefilter_single_enqueue(ix, ix->d_q, ix->d_q + (size_t)nq * dim, nq, k, ix->d_pf_out, flags, st))) return rc;
+    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, 0, flags));
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
+    hipLaunchKernelGGL(prefilter_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_pf_out, ix->d_out, flags, nq, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(ix->upload_done));   // the pinned staging is free for the next call
     result = ix->d_pf_out;
   } else {
     if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;

@@ -666,29 +666,77 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           for (int r = 0; r < 4; ++r) any |= (acc[nj][rt][r] >= thr[nj][r]);
         }
       }
-    if (any) {
-      auto offer = [&](float score, int query, int row) {
-        if (row >= p.M || query >= p.topk_nq) return;   // padding rows of the last tile hold whatever the allocation does
-        const unsigned long long key = make_key(score, p.topk_row_base + (unsigned)row);
-        if (key <= p.topk_thr_key[query]) return;
-        const unsigned slot = p.topk_direct ? (unsigned)row : atomicAdd(p.topk_cnt + query, 1u);
-        if (slot < (unsigned)p.topk_cap) p.topk_buf[(size_t)query * p.topk_cap + slot] = key;
-      };
+    if (any && p.topk_direct) {
+      // first stage: slot = row, no counters
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row = mw + rt * 16 + l15, n = nw + nj * 16 + 4 * q;
-          if (p.topk_pairs) {
-            const float s0 = acc[nj][rt][0] + acc[nj][rt][1], s1 = acc[nj][rt][2] + acc[nj][rt][3];
-            if (s0 >= thr[nj][0]) offer(s0, n >> 1, row);
-            if (s1 >= thr[nj][2]) offer(s1, (n >> 1) + 1, row);
-          } else {
+          if (row >= p.M) continue;   // padding rows of the last tile hold whatever the allocation does
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (acc[nj][rt][r] >= thr[nj][r]) offer(acc[nj][rt][r], n + r, row);
+          for (int r = 0; r < 4; ++r) {
+            if (p.topk_pairs && (r & 1)) continue;
+            const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][r + 1] : acc[nj][rt][r];
+            const int query = p.topk_pairs ? (n + r) >> 1 : n + r;
+            if (!(sc >= thr[nj][r]) || query >= p.topk_nq) continue;
+            p.topk_buf[(size_t)query * p.topk_cap + row] = make_key(sc, p.topk_row_base + (unsigned)row);
           }
         }
+    } else if (any) {
+      // Three straight-line passes instead of one branch per accumulator: a branch that holds an atomic with a returned slot and a
+      // store is a memory round trip per branch a wave enters, and with k (ratio - 1) candidates per query and stage a wave entered
+      // tens of its 128 branches one after the other.  (a) per (lane, query column): rows above the threshold score counted, ONE
+      // atomic reserves their slots -- all of a lane's atomics are in flight together; per column tile: (b) the threshold keys
+      // of its columns, (c) the keys go out; a reserved slot whose key fails the key test (equal score, higher row) is written as "no key".
+      unsigned base[16];
+      unsigned have = 0u;
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = nj * 4 + r;
+          base[j] = 0u;
+          if (p.topk_pairs && (r & 1)) continue;
+          unsigned c = 0u;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][(r + 1) & 3] : acc[nj][rt][r];
+            c += (mw + rt * 16 + l15 < p.M && sc >= thr[nj][r]) ? 1u : 0u;
+          }
+          const int n = nw + nj * 16 + 4 * q + r, query = p.topk_pairs ? n >> 1 : n;
+          if (c > 0u && query < p.topk_nq) {
+            base[j] = atomicAdd(p.topk_cnt + query, c);
+            have |= 1u << j;
+          }
+        }
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        if (!((have >> (nj * 4)) & 15u)) continue;
+        unsigned long long tk[4];   // per column tile: four keys in flight, 8 registers (all 16 at once cost scratch at 256 x 256)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nw + nj * 16 + 4 * q + r, query = p.topk_pairs ? n >> 1 : n;
+          tk[r] = (have >> (nj * 4 + r)) & 1u ? p.topk_thr_key[query] : ~0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = nj * 4 + r;
+          if (!((have >> j) & 1u)) continue;
+          const int n = nw + nj * 16 + 4 * q + r, query = p.topk_pairs ? n >> 1 : n;
+          unsigned slot = base[j];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int row = mw + rt * 16 + l15;
+            const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][(r + 1) & 3] : acc[nj][rt][r];
+            if (row < p.M && sc >= thr[nj][r]) {
+              const unsigned long long key = make_key(sc, p.topk_row_base + (unsigned)row);
+              if (slot < (unsigned)p.topk_cap) p.topk_buf[(size_t)query * p.topk_cap + slot] = key > tk[r] ? key : 0ull;
+              ++slot;
+            }
+          }
+        }
+      }
     }
   }
 }

@@ -1115,7 +1115,8 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
 // query alone -- exactness never depends on the order of the rows.
 constexpr int TCAP = 2048;        // candidate slots per query and stage
 constexpr int TSTAGE0 = 256;      // rows of the first stage (every row is a candidate: one key per row, no counters)
-constexpr int TRATIO = 16;        // growth of the rows seen per stage
+constexpr int TRATIO = 16;        // growth of the rows seen per stage (k <= 16)
+constexpr int TRATIO_WIDE = 4;    // the same for longer lists
 
 // fp32 queries -> the GEMM's W operand [n_cols_pad, dim] bf16.  pairs: rows (2q, 2q + 1) = (bf16(q), bf16(q - bf16(q)));
 // rows beyond the queries are zero.
@@ -2121,6 +2122,11 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
                                 TCAP * (int)sizeof(u64)));
     attr = true;
   }
+  // Rows seen grow by `ratio` per stage, and a stage admits ~k (ratio - 1) candidates per query, each one an atomic append on its
+  // query's counter: at k = 64 (the prefilter's candidate lists) a ratio of 16 made the appends, not the row stream, the cost of
+  // every stage (960 per query and stage)
+  static const int ratio_env = getenv("VRAG_TOPK_STAGE_RATIO") ? atoi(getenv("VRAG_TOPK_STAGE_RATIO")) : 0;
+  const int ratio = ratio_env >= 2 ? ratio_env : (k > 16 ? TRATIO_WIDE : TRATIO);
   long long lo = 0, hi = std::min<long long>(n, TSTAGE0);
   for (int stage = 0; lo < n; ++stage) {
     GemmParams g{};
@@ -2146,7 +2152,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
                        ix->d_tthr, ix->d_tthrs, last ? ix->d_out : (u64*)nullptr, ovf, stage == 0 ? (int)(hi - lo) : 0);
     HIP_TRY(hipGetLastError());
     lo = hi;
-    hi = std::min<long long>(n, hi * TRATIO);
+    hi = std::min<long long>(n, hi * ratio);
   }
   const size_t lds = (size_t)dim * sizeof(float) + (size_t)16 * k * sizeof(u64);
   hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n, dim,
@@ -2158,8 +2164,10 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
 // One device pass (k <= KMAX) of a dense search: uploads the queries, runs phase 1 + the per-query merge and leaves the
 // [nq, k] keys in ix->d_out.  Returns once the query upload has been consumed (the caller's buffer may be reused); the
 // kernels are only enqueued.  Caller holds ix->mu and has set the device.
-int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, bool image = false) {
-  // image: rank the bf16 prefilter image of an fp32 index instead of its rows (the approximate pass of the prefilter route)
+int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, int image = 0) {
+  // image: rank the bf16 prefilter image of an fp32 index instead of its rows (the approximate pass of the prefilter route);
+  // 2 = with the queries rounded to bf16 instead of riding as (value, remainder) column pairs -- half the GEMM columns, the
+  // rounding is part of the caller's error bound
   const int dtype = image ? 0 : ix->dtype;
   const void* rows = image ? ix->rows16 : ix->rows;
   const int n_wg = dense_n_wg(dtype, ix->dim, nq, k, ix->size);
@@ -2178,7 +2186,7 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   // Recorded for whatever kernel family serves these queries now or in a later run_resident with another (nq, k).
   static const bool no_split = getenv("VRAG_TOPK_NO_SPLIT") != nullptr;
   ix->resident_split = 0;
-  if (!no_split && dtype == 0) {
+  if (!no_split && dtype == 0 && image != 2) {
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(queries);
     const size_t n_el = (size_t)nq * ix->dim;
     for (size_t i = 0; i < n_el; ++i)
@@ -2332,6 +2340,42 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
   return VRAG_OK;
 }
 
+// Batch route of the prefilter (nq >= 64) without a host decision: tiled search of the image with bf16-rounded queries -> 64
+// candidates per query -> sufficiency test + exact re-score; then the full scan behind the per-query flags (groups of 32 queries
+// without a flag leave at once) and a per-query pick.  Leaves the [nq, k] keys in ix->d_pf_out and the flags in ix->d_pf_flag.
+// Worst case (every query flagged: bunched scores) = the full scan plus the tiled pass.  The bound with rounded queries:
+// |a_r - e_r| <= (2^-9 |x~ - x| term + 2^-9 (1 + 2^-9) |q~ - q| term + 4 dim 2^-24 accumulation) max||x|| ||q||.
+static int prefilter_batch_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st) {
+  int rc;
+  if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
+  if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
+  if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
+  const double c = 1.0 / 512 + (1.0 / 512) * (1.0 + 1.0 / 512) + 4.0 * ix->dim / 16777216.0;
+  const double xmax = std::sqrt((double)ix->norm2_max);
+  std::vector<float> eps((size_t)nq);
+  for (int q = 0; q < nq; ++q) {
+    double s2 = 0.0;
+    for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
+    eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
+  }
+  if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/2))) return rc;
+  HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(ix->upload_done, st));
+  hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
+                     ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
+  HIP_TRY(hipGetLastError());
+  const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
+  if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
+  HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                           ix->d_out + (size_t)nq * k, ix->d_out, nullptr, 0, ix->d_pf_flag));
+  HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));   // lists of unflagged queries: whatever the scratch held -- never picked
+  const long long n = (long long)nq * k;
+  hipLaunchKernelGGL(prefilter_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_pf_out, ix->d_out, ix->d_pf_flag, nq, k);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventSynchronize(ix->upload_done));   // the eps upload has left the host vector
+  return VRAG_OK;
+}
+
 // One-pass route of the prefilter for one or two queries (see prefilter_collect_kernel): the fp32 queries and their error bounds
 // are resident at dq / deps; per query  entry threshold (prefix kernel + selection) -> candidates (one pass over the image) ->
 // exact keys (LDS-staged chains);  one selection for all queries writes the k best keys to out_keys[q][k] and raises
@@ -2429,22 +2473,19 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq <= 2 || nq >= 64) &&
                        !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
   if (pf_live) {
-    if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
-    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k))) return rc;
-    if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
-    const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * ix->dim / 16777216.0;
-    const double xmax = std::sqrt((double)ix->norm2_max);
-    std::vector<float> eps((size_t)nq);
-    for (int q = 0; q < nq; ++q) {
-      double s2 = 0.0;
-      for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
-      eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
-    }
     std::vector<unsigned> flags((size_t)nq);
     if (nq <= 2) {
       // one streaming pass over the image per query (prefilter_single_enqueue); queries + bounds go up in one pinned copy, keys +
       // flags come back in one
       const int dim = ix->dim;
+      const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * dim / 16777216.0;   // fp32 queries against the image: no query rounding term
+      const double xmax = std::sqrt((double)ix->norm2_max);
+      float eps[2];
+      for (int q = 0; q < nq; ++q) {
+        double s2 = 0.0;
+        for (int i = 0; i < dim; ++i) s2 += (double)queries[(size_t)q * dim + i] * queries[(size_t)q * dim + i];
+        eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
+      }
       if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
       if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
       {   // the full scan's scratch too: vrag_dense_index_run_resident may follow on these resident queries
@@ -2466,13 +2507,18 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       std::memcpy(keys.data(), down, keys.size() * sizeof(u64));
       std::memcpy(flags.data(), down + (size_t)nq * k, (size_t)nq * sizeof(unsigned));
     } else {
-      if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
-      HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
-                         ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
-      HIP_TRY(hipGetLastError());
+      // batches: no host decision -- flagged queries are re-answered by the full scan enqueued behind their flags (groups of 32
+      // without a flag leave at once), so one bunched query costs one pass, not the batch's
+      if ((rc = prefilter_batch_enqueue(ix, queries, nq, k, st))) return rc;
       HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_pf_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(flags.data(), ix->d_pf_flag, flags.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      ++ix->pf_searches;
+      size_t n_bad = 0;
+      for (unsigned f : flags) n_bad += f != 0u ? 1 : 0;
+      if (n_bad * 4 > flags.size()) ++ix->pf_fallbacks;   // a quarter of the batch re-scanned: counts against the route
+      decode_keys(keys, nq, k, 0, nullptr, scores, ids);
+      return VRAG_OK;
     }
     HIP_TRY(hipStreamSynchronize(st));   // also retires the query / eps uploads before the host buffers go out of scope
     ++ix->pf_searches;
@@ -2505,34 +2551,8 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
   const long long n = (long long)nq * k;
   const u64* result = nullptr;
   if (ix->rows16 && k <= 16 && ix->size >= 4096 && nq >= 64) {
-    // fp32 rows with a prefilter image, batch route, no host round trip: tiled search of the image -> 64 candidates -> sufficiency
-    // test + exact re-score; then the full scan behind the per-query flags (groups of 32 queries without a flag leave at once) and
-    // a per-query pick.  Worst case (every query flagged: bunched scores) = the full scan plus the tiled pass.
-    if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
-    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k))) return rc;
-    if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
-    const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * ix->dim / 16777216.0;
-    const double xmax = std::sqrt((double)ix->norm2_max);
-    std::vector<float> eps((size_t)nq);
-    for (int q = 0; q < nq; ++q) {
-      double s2 = 0.0;
-      for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
-      eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
-    }
-    if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/true))) return rc;
-    HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(ix->upload_done, st));
-    hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
-                       ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
-    HIP_TRY(hipGetLastError());
-    const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
-    if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
-    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
-                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, 0, ix->d_pf_flag));
-    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));   // lists of unflagged queries: whatever the scratch held -- never picked
-    hipLaunchKernelGGL(prefilter_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_pf_out, ix->d_out, ix->d_pf_flag, nq, k);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventSynchronize(ix->upload_done));   // the eps upload has left the host vector
+    // fp32 rows with a prefilter image, batch route (prefilter_batch_enqueue): nothing returns to the host
+    if ((rc = prefilter_batch_enqueue(ix, queries, nq, k, st))) return rc;
     result = ix->d_pf_out;
   } else if (ix->rows16 && k <= 16 && ix->size >= 4096 && nq <= 2) {
     // one or two queries: the one-pass route, then the full scan behind the overflow flags (its workgroups leave at once when no

@@ -664,3 +664,51 @@ def test_one_and_two_queries_over_fp32_rows_take_the_one_pass_route_host_and_dev
             sh.close()
             if copies:
                 assert ri[0, 0] == 7 and (np.diff(ri[0]) > 0).all()     # the copies tie: ascending ids
+
+
+def test_prefilter_bound_holds_where_bf16_rounding_is_worst_case():
+    """The image's error bound is the MEASURED max ||bf16(x) - x|| (csrc/topk.hip prefilter_image_kernel / prefilter_eps), not a
+    constant: bf16 keeps 8 significant bits, so a row of halfway values (1 + 2^-8 -> 1.0) loses 2^-8 of its norm, all of it along
+    the query.  Ten such rows T (exact score S (1 + 2^-8), image score S) sit behind the ranked prefix; forty decoys in the prefix
+    use the other half of the coordinates with values just above a halfway point of the binade below (image 1.0, exact 1 - 2^-9)
+    and a query weight 1.485 * 2^-8 higher: image scores ABOVE T's by 1.485 * 2^-8 S, exact scores BELOW T's.  A bound of 2^-9 per
+    element (what the first form of the route assumed) puts T outside t0 - 2 eps and returns the decoys; the measured bound keeps T."""
+    import torch
+
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    rng = np.random.default_rng(61)
+    n, dim, k = 50_000, 128, 10       # 128: the accumulation slack of the bound (4 dim 2^-24) is small against the rounding term
+    h = dim // 2
+    X = (0.01 * rng.standard_normal((n, dim))).astype(np.float32)
+    decoys = rng.choice(np.arange(100, 30_000), size=40, replace=False)
+    truth = np.sort(rng.choice(np.arange(40_000, n), size=k, replace=False))
+    X[decoys] = 0.0
+    X[decoys, h:] = np.float32(1.0 - 2.0 ** -9 + 2.0 ** -20)
+    X[truth] = 0.0
+    X[truth, :h] = np.float32(1.0 + 2.0 ** -8)
+    Q = np.ones((2, dim), dtype=np.float32)
+    Q[0, h:] = np.float32(1.0 + 1.485 * 2.0 ** -8)
+    Q[1] = rng.standard_normal(dim).astype(np.float32)
+    rs, ri = T.dense_topk(X, Q, k)
+    assert np.array_equal(ri[0], truth)                       # the construction: exact top-k = the T rows, ids ascending
+    img = X.astype(np.float32).view(np.uint32)
+    img = (((img + 0x7FFF + ((img >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)).view(np.float32)   # bf16 image, round to nearest even
+    a = img.astype(np.float64) @ Q[0].astype(np.float64)
+    old_eps = (2.0 ** -9 + 2.0 ** -16 + 4 * dim * 2.0 ** -24) * 1.001 * np.linalg.norm(X, axis=1).max() * np.linalg.norm(Q[0])
+    assert a[decoys].min() - a[truth].max() > 2 * old_eps     # ... and the 2^-9 bound (with all its slack) would have dropped them
+    sh = DenseShard(dim, n, "f32")
+    sh.add(X)
+    for nq in (1, 2):
+        s, i = sh.search(Q[:nq], k)
+        assert np.array_equal(i, ri[:nq]) and np.array_equal(s, rs[:nq]), nq
+        d_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        d_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        sh.search_device(Q[:nq], k, d_s.data_ptr(), d_i.data_ptr(), stream=None)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_i.cpu().numpy(), ri[:nq]) and np.array_equal(d_s.cpu().numpy(), rs[:nq]), nq
+    Qb = np.repeat(Q[:1], 70, axis=0) * np.linspace(0.5, 2.0, 70, dtype=np.float32)[:, None]      # the batch route on the same rows
+    s, i = sh.search(Qb, k)
+    rs, ri = T.dense_topk(X, Qb, k, blocked=True)
+    assert np.array_equal(i, ri) and np.array_equal(s, rs)
+    sh.close()

@@ -1227,25 +1227,29 @@ __global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* _
 // The store's default rows are fp32 and its contract bit-exact (scores = the oracle's sequential fmaf chain), which costs a
 // full 4-byte-per-element scan per query batch (1.03 ms for one query over 1.25 M x 768 rows).  With a bf16 image of the rows
 // beside them (dtype 2) a search first ranks the IMAGE -- half the bytes, and the batched routes above -- for the 64 best
-// approximate scores a_r per query, then re-scores those 64 rows exactly.  Why that is still exact: bf16 rounding moves every
-// element by at most 2^-9 of itself, so  |a_r - e_r| <= eps = (2^-9 + 2^-16 + 4 dim 2^-24) max||x|| ||q||  (Cauchy-Schwarz; the
-// second term is the query's (value, remainder) pair in the batched routes, the third two generous fp32 accumulation terms).
+// approximate scores a_r per query, then re-scores those 64 rows exactly.  Why that is still exact: the image row x~_r differs
+// from x_r by a vector whose norm is MEASURED when the image is built (E = max_r ||x~_r - x_r||, prefilter_image_kernel; bf16
+// keeps 8 significant bits, so E <= 2^-8 max||x|| in the worst case and about 0.45 of that on ordinary data), hence
+//     |a_r - e_r| <= eps = E ||q|| + Dq max||x~|| + 4 dim 2^-24 max||x|| ||q||
+// (Cauchy-Schwarz; Dq = the norm of what the query loses on its way into the pass: 0 for the fp32 query of the one-pass route,
+// ||q~ - q|| measured on the host for the bf16-rounded queries of the batch route; the last term covers the fp32 accumulation
+// of a_r and of the oracle's chain e_r with a factor 2 to spare).
 // Every row outside the 64 has a_r <= a_64, hence e_r <= a_64 + eps; the k best approximate rows have e_r >= a_k - eps.  If
 //     a_64 + eps < a_k - eps
 // every outside row is strictly below k candidates in exact score, so the exact top-k lies inside the 64 -- found by the exact
 // chain on 64 rows.  If the inequality fails for a query (scores bunched within 2 eps: near-duplicate rows) its flag is set and
-// the caller re-answers the batch with the full fp32 scan: correctness never rests on the data.
+// the full fp32 scan re-answers it: correctness never rests on the data.
 constexpr int PFK = 64;   // candidates per query of a batch (the tiled search delivers 64 at no extra cost)
 
 // fp32 rows -> bf16 image + the maximum squared row norm (one wave per row)
 __global__ __launch_bounds__(256) void prefilter_image_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n_rows,
-                                                               int dim, float* __restrict__ norm2_max) {
+                                                               int dim, float* __restrict__ stats /*[0] max ||x||^2, [1] max ||x~ - x||^2*/) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= n_rows) return;
   const float* x = src + (size_t)r * dim;
   bf16_t* y = dst + (size_t)r * dim;
-  float s2 = 0.f;
+  float s2 = 0.f, d2 = 0.f;
   for (int c = lane * 4; c < dim; c += 256) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
     bf16x4 o;
@@ -1253,11 +1257,15 @@ __global__ __launch_bounds__(256) void prefilter_image_kernel(const float* __res
     for (int j = 0; j < 4; ++j) {
       o[j] = (bf16_t)v[j];
       s2 = fmaf(v[j], v[j], s2);
+      const float d = v[j] - (float)o[j];   // exact in fp32: the two are within a factor two of each other
+      d2 = fmaf(d, d, d2);
     }
     *reinterpret_cast<bf16x4*>(y + c) = o;
   }
-  s2 = wave_sum(s2) * 1.0001f;   // the sum's own rounding
-  if (lane == 0 && s2 == s2) atomicMax(reinterpret_cast<unsigned*>(norm2_max), __builtin_bit_cast(unsigned, s2));
+  s2 = wave_sum(s2) * 1.0001f;   // the sums' own rounding
+  d2 = wave_sum(d2) * 1.0001f;
+  if (lane == 0 && s2 == s2) atomicMax(reinterpret_cast<unsigned*>(stats), __builtin_bit_cast(unsigned, s2));
+  if (lane == 0 && d2 == d2) atomicMax(reinterpret_cast<unsigned*>(stats) + 1, __builtin_bit_cast(unsigned, d2));
 }
 
 // The oracle's chain  acc = fmaf(x[c], q[c], acc), c ascending from acc = 0,  for one row per lane.  The chain itself is serial;
@@ -1981,8 +1989,8 @@ struct vrag_dense_index {
   size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0;
   // fp32 rows with a bf16 prefilter copy (dtype 2 at creation; `dtype` stays 1: the contract is the fp32 rows')
   void* rows16 = nullptr;          // bf16 image of `rows`
-  float* d_norm2 = nullptr;        // device scalar: max squared row norm (bits ordered as unsigned: norms are >= 0)
-  float norm2_max = 0.f;           // its host copy, refreshed by add()
+  float* d_norm2 = nullptr;        // device [2]: max squared row norm, max squared image error ||x~ - x||^2 (bits ordered as unsigned: both >= 0)
+  float pf_stats[2] = {0.f, 0.f};  // their host copies, refreshed by add()
   float* d_pf_eps = nullptr;       // [nq] per-query error bound of the approximate scores
   u64* d_pf_out = nullptr;         // [nq][k] exact keys of the rescored candidates
   unsigned* d_pf_flag = nullptr;   // [nq] 1 = the candidates do not provably contain the exact top-k
@@ -2237,8 +2245,8 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
   if (e == hipSuccess && prefilter && dim % 4 == 0) {
     e = hipMalloc(&ix->rows16, ((size_t)capacity + 512) * dim * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norm2, sizeof(float));
-    if (e == hipSuccess) e = hipMemset(ix->d_norm2, 0, sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norm2, 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(ix->d_norm2, 0, 2 * sizeof(float));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ix->h_pin, (size_t)2 * (dim + 1) * sizeof(float) + (2 * KMAX + 1) * sizeof(u64), 0);
   }
   ix->stage_rows = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)dim * 4));
@@ -2309,7 +2317,7 @@ int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
     }
   }
   ix->size += n;
-  if (ix->rows16) HIP_TRY(hipMemcpy(&ix->norm2_max, ix->d_norm2, sizeof(float), hipMemcpyDeviceToHost));
+  if (ix->rows16) HIP_TRY(hipMemcpy(ix->pf_stats, ix->d_norm2, 2 * sizeof(float), hipMemcpyDeviceToHost));
   return VRAG_OK;
 }
 
@@ -2329,7 +2337,7 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
       hipLaunchKernelGGL(prefilter_image_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, rows,
                          reinterpret_cast<bf16_t*>(ix->rows16) + off, (long long)n, (int)dim, ix->d_norm2);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(&ix->norm2_max, ix->d_norm2, sizeof(float), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ix->pf_stats, ix->d_norm2, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
     }
   } else {
     hipLaunchKernelGGL(cvt_f32_bf16_flat, dim3(2048), dim3(256), 0, st, rows, reinterpret_cast<bf16_t*>(ix->rows) + off, cnt);
@@ -2344,21 +2352,36 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
 // candidates per query -> sufficiency test + exact re-score; then the full scan behind the per-query flags (groups of 32 queries
 // without a flag leave at once) and a per-query pick.  Leaves the [nq, k] keys in ix->d_pf_out and the flags in ix->d_pf_flag.
 // Worst case (every query flagged: bunched scores) = the full scan plus the tiled pass.  The bound with rounded queries:
-// |a_r - e_r| <= (2^-9 |x~ - x| term + 2^-9 (1 + 2^-9) |q~ - q| term + 4 dim 2^-24 accumulation) max||x|| ||q||.
+// (prefilter_eps with the rounded-query term).
+// Per-query error bound of the image scores (see "fp32 rows, bf16 prefilter"): E ||q|| + Dq max||x~|| + 4 dim 2^-24 max||x|| ||q||,
+// Dq = ||bf16(q) - q|| when the pass runs on rounded queries, else 0.  Host arithmetic in double, rounded up.
+static float prefilter_eps(const vrag_dense_index* ix, const float* q, bool rounded_query) {
+  double q2 = 0.0, dq2 = 0.0;
+  for (int i = 0; i < ix->dim; ++i) {
+    q2 += (double)q[i] * q[i];
+    if (rounded_query) {
+      uint32_t b;
+      std::memcpy(&b, &q[i], 4);
+      b = (b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u;   // round to nearest even on 16 bits, as the device conversion does
+      float r;
+      std::memcpy(&r, &b, 4);
+      const double d = (double)r - (double)q[i];
+      dq2 += d * d;
+    }
+  }
+  const double xmax = std::sqrt((double)ix->pf_stats[0]), emax = std::sqrt((double)ix->pf_stats[1]);
+  const double e = emax * std::sqrt(q2) + std::sqrt(dq2) * (xmax + emax) + 4.0 * ix->dim / 16777216.0 * xmax * std::sqrt(q2);
+  return (float)(e * 1.001 + 1e-30);
+}
+
 static int prefilter_rescan_enqueue(vrag_dense_index* ix, int nq, int k, hipStream_t st);
 static int prefilter_batch_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, bool rescan = true) {
   int rc;
   if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
   if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
   if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
-  const double c = 1.0 / 512 + (1.0 / 512) * (1.0 + 1.0 / 512) + 4.0 * ix->dim / 16777216.0;
-  const double xmax = std::sqrt((double)ix->norm2_max);
   std::vector<float> eps((size_t)nq);
-  for (int q = 0; q < nq; ++q) {
-    double s2 = 0.0;
-    for (int i = 0; i < ix->dim; ++i) s2 += (double)queries[(size_t)q * ix->dim + i] * queries[(size_t)q * ix->dim + i];
-    eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
-  }
+  for (int q = 0; q < nq; ++q) eps[q] = prefilter_eps(ix, queries + (size_t)q * ix->dim, /*rounded_query=*/true);
   if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/2))) return rc;
   HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(ix->upload_done, st));
@@ -2487,14 +2510,8 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       // one streaming pass over the image per query (prefilter_single_enqueue); queries + bounds go up in one pinned copy, keys +
       // flags come back in one
       const int dim = ix->dim;
-      const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * dim / 16777216.0;   // fp32 queries against the image: no query rounding term
-      const double xmax = std::sqrt((double)ix->norm2_max);
       float eps[2];
-      for (int q = 0; q < nq; ++q) {
-        double s2 = 0.0;
-        for (int i = 0; i < dim; ++i) s2 += (double)queries[(size_t)q * dim + i] * queries[(size_t)q * dim + i];
-        eps[q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
-      }
+      for (int q = 0; q < nq; ++q) eps[q] = prefilter_eps(ix, queries + (size_t)q * dim, /*rounded_query=*/false);   // fp32 query against the image
       if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
       if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
       {   // the full scan's scratch too: vrag_dense_index_run_resident may follow on these resident queries
@@ -2578,15 +2595,9 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
     if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
     if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
     if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
-    const double c = 1.0 / 512 + 1.0 / 65536 + 4.0 * dim / 16777216.0;
-    const double xmax = std::sqrt((double)ix->norm2_max);
     float* up = reinterpret_cast<float*>(ix->h_pin);
     std::memcpy(up, queries, (size_t)nq * dim * sizeof(float));
-    for (int q = 0; q < nq; ++q) {
-      double s2 = 0.0;
-      for (int i = 0; i < dim; ++i) s2 += (double)queries[(size_t)q * dim + i] * queries[(size_t)q * dim + i];
-      up[(size_t)nq * dim + q] = (float)(c * xmax * std::sqrt(s2) * 1.001 + 1e-30);
-    }
+    for (int q = 0; q < nq; ++q) up[(size_t)nq * dim + q] = prefilter_eps(ix, queries + (size_t)q * dim, /*rounded_query=*/false);
     HIP_TRY(hipMemcpyAsync(ix->d_q, up, ((size_t)nq * dim + nq) * sizeof(float), hipMemcpyHostToDevice, st));
     if (!ix->upload_done) HIP_TRY(hipEventCreateWithFlags(&ix->upload_done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ix->upload_done, st));

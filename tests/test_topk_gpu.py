@@ -712,3 +712,27 @@ def test_prefilter_bound_holds_where_bf16_rounding_is_worst_case():
     rs, ri = T.dense_topk(X, Qb, k, blocked=True)
     assert np.array_equal(i, ri) and np.array_equal(s, rs)
     sh.close()
+
+
+def test_device_bf16_conversion_rounds_to_nearest_even():
+    """`prefilter_eps` (csrc/topk.hip) measures ||bf16(q) - q|| on the HOST for the batch route's rounded queries, assuming the
+    device's `(bf16_t)` cast rounds to nearest even like its own bit arithmetic.  Pinned here on the cast as the bf16 ingest kernel
+    compiles it: one value per row, query = e_0, so the returned score IS the stored bf16 value."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    vals = np.array([1 + 2.0 ** -8, 1 + 3 * 2.0 ** -8, 1 + 2.0 ** -8 + 2.0 ** -20, 1 + 2.0 ** -8 - 2.0 ** -20, -(1 + 2.0 ** -8),
+                     1 - 2.0 ** -9, 1 - 2.0 ** -9 + 2.0 ** -20, 1 - 2.0 ** -9 - 2.0 ** -20, 3.0e38, 1.0e-30, 0.1, -0.3, 255.5, 257.0,
+                     65535.0, 1.99609375 + 2.0 ** -9], dtype=np.float32)
+    bits = vals.view(np.uint32).astype(np.uint64)
+    want = (((bits + 0x7FFF + ((bits >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)).view(np.float32)
+    X = np.zeros((len(vals), 8), dtype=np.float32)
+    X[:, 0] = vals
+    q = np.zeros((1, 8), dtype=np.float32)
+    q[0, 0] = 1.0
+    sh = DenseShard(8, len(vals), "bf16")
+    sh.add(X)
+    s, i = sh.search(q, len(vals))
+    sh.close()
+    got = np.empty(len(vals), dtype=np.float32)
+    got[i[0]] = s[0]
+    assert np.array_equal(got, want), (got, want)

@@ -159,7 +159,8 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* enc, const float* dense_w /*[H,H]
                                  const float* norm_w /*[H]*/, const float* norm_b /*[H]*/,
                                  const float* decoder_w /*[V,H] or NULL*/, const float* decoder_b /*[V]*/);
 
-/* Operand precision of the MLM / SPLADE head GEMMs, to be chosen BEFORE vrag_encoder_set_mlm_head*: split_operands != 0
+/* Operand precision of the MLM / SPLADE head GEMMs; takes effect at the NEXT vrag_encoder_set_mlm_head* (which may be called
+ * again on a handle: the previous head's images are released and rebuilt in the chosen form): split_operands != 0
  * (the default) carries activations and weights as (value, remainder) pairs of the operand type -- the dense layer as
  * three accumulating GEMMs, the decoder as one GEMM over K = 3H -- so that every SPLADE weight max_s log1p(relu(logit))
  * stays within 2e-3 of the fp32 arithmetic of SparseEncoder.encode (embedding_providers.py:127-166; nothing averages

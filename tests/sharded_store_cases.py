@@ -12,7 +12,7 @@ from verbatim_rag_amd import vector_stores as vs
 class CpuDense:
     """Stand-in for `DenseShard` on boxes without a GPU: answers from the exact CPU oracle (tests only)."""
 
-    def __init__(self, dim, capacity, dtype="f32", device=0):
+    def __init__(self, dim, capacity, dtype="f32", device=0, prefilter=True):
         self.rows = np.zeros((0, dim), np.float32)
 
     def add(self, rows):

@@ -106,9 +106,17 @@ def test_configs3_dense_shard_1_25m_rows(dtype):
         for nq in nqs:
             t0 = time.perf_counter()
             s, i = sh.search(Q[:nq], k)
-            _note(f"dense_{dtype}_{nq}_queries_search_s", time.perf_counter() - t0)
+            # the FIRST call of this shape on the index (scratch sized and every route run once at ingest, csrc/topk.hip
+            # dense_warm_query_path; round 5 paid 58 ms here for 256 fp32 queries) and a repeat, which is what profiles/README quotes
+            _note(f"dense_{dtype}_{nq}_queries_first_call_s", time.perf_counter() - t0)
             assert np.array_equal(i, ri[:nq]), (dtype, nq)
             assert np.array_equal(s, rs[:nq]), (dtype, nq)
+            t0 = time.perf_counter()
+            s2, i2 = sh.search(Q[:nq], k)
+            _note(f"dense_{dtype}_{nq}_queries_search_s", time.perf_counter() - t0)
+            assert np.array_equal(i2, i) and np.array_equal(s2, s)
+            if nq <= 256:
+                assert time.perf_counter() - t0 < 0.02, "a repeated <= 256-query search takes milliseconds"
     finally:
         sh.close()
         del X

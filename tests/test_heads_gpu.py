@@ -284,3 +284,23 @@ def test_fp16_operands_report_saturation_instead_of_returning_clamped_logits(tmp
     assert got == ext_bf.extract_spans("Where is the tower?", results)
     for e in ext16.engines + ext_bf.engines:
         e.close()
+
+
+def test_mlm_head_can_be_set_again_in_either_operand_form(setup):
+    """`set_mlm_head` on an engine that already has a head (a BertEncoderEngine whose constructor attached the
+    checkpoint's, or a caller swapping heads) must work -- the C setter releases the previous decoder images and rebuilds
+    them in the form `vrag_encoder_set_head_precision` chose last (include/vrag_amd.h)."""
+    cfg, w, z, eng = setup
+    seqs = [z["ids_64"]]
+    eng.load_batch(seqs)
+    eng.run()
+    eng.run_splade()
+    first = eng.read_splade().copy()
+    args = (z["mlm_head.dense.weight"], z["mlm_head.norm.weight"], z["mlm_decoder.bias"])
+    eng.set_mlm_head(*args, split_operands=False)          # plain operands: ~1e-2 from the split form, not equal
+    eng.run_splade()
+    plain = eng.read_splade().copy()
+    assert np.abs(plain - first).max() < 3e-2 and not np.array_equal(plain, first)
+    eng.set_mlm_head(*args, split_operands=True)           # back: the same bits as the first head
+    eng.run_splade()
+    assert np.array_equal(eng.read_splade(), first)

@@ -383,6 +383,20 @@ int dev_alloc(vrag_encoder* e, T** out, size_t count, bool zero = true) {
   return VRAG_OK;
 }
 
+// frees one tracked device allocation (a head that is set again) and clears the pointer
+template <typename T>
+void dev_release(vrag_encoder* e, T** ptr) {
+  if (!*ptr) return;
+  void* p = reinterpret_cast<void*>(*ptr);
+  for (size_t i = 0; i < e->dev_allocs.size(); ++i)
+    if (e->dev_allocs[i] == p) {
+      e->dev_allocs.erase(e->dev_allocs.begin() + (long)i);
+      (void)hipFree(p);
+      break;
+    }
+  *ptr = nullptr;
+}
+
 template <typename T>
 int host_alloc(vrag_encoder* e, T** out, size_t count) {
   void* p = nullptr;
@@ -1383,6 +1397,15 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* e, const float* dense_w, const fl
   const int vpad = (int)align_up(V, 256);  // whole 256-wide GEMM tiles
   const size_t stage_elems = std::max<size_t>((size_t)H * H, (size_t)1 << 22);
   float* stage = nullptr;
+  // setting the head again (another checkpoint's, or the other operand form): the previous decoder images go first
+  HIP_TRY(hipDeviceSynchronize());
+  dev_release(e, &e->mlm_dec);
+  dev_release(e, &e->mlm_dec3);
+  dev_release(e, &e->splade_a3);
+  dev_release(e, &e->mlm_dense_lo);
+  dev_release(e, &e->mlm_dense);
+  dev_release(e, &e->mlm_bias);
+  dev_release(e, &e->d_splade);
   int rc = dev_alloc(e, &stage, stage_elems, false);
   if (rc) return rc;
   if ((rc = upload_bf16(e, &e->mlm_dense, dense_w, H, H, H, 0, stage, stage_elems, nullptr, nullptr,
@@ -1422,13 +1445,16 @@ int vrag_encoder_set_mlm_head_ex(vrag_encoder* e, const float* dense_w, const fl
   if (decoder_b) HIP_TRY(hipMemcpy(e->mlm_bias, decoder_b, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
   if ((rc = dev_alloc(e, &e->d_splade, (size_t)e->cfg.max_seqs * vpad))) return rc;
   e->vpad = vpad;
+  HIP_TRY(hipDeviceSynchronize());
+  dev_release(e, &stage);
   return VRAG_OK;
 }
 
 int vrag_encoder_set_head_precision(vrag_encoder* e, int32_t split_operands) {
   ARG_CHECK(e, "null handle");
   std::lock_guard<std::recursive_mutex> lk(e->mu);
-  ARG_CHECK(e->mlm_dec == nullptr && e->mlm_dec3 == nullptr, "set the head precision before the MLM head (vrag_encoder_set_mlm_head*)");
+  // A head that exists keeps its form until it is set again: vrag_encoder_set_mlm_head* rebuilds the decoder images for the
+  // mode chosen here (and releases the other form's), so the setter is legal at any time.
   e->mlm_split = split_operands != 0;
   return VRAG_OK;
 }

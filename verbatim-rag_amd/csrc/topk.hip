@@ -2004,7 +2004,20 @@ struct vrag_dense_index {
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
   hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
+  bool warmed = false;                // dense_warm_query_path has run (first add that brought the shard to >= 4096 rows)
 };
+
+// May a search of `nq` queries take the prefilter-image route of an fp32 index?  The route's fallback -- the full fp32 scan
+// behind the per-query flags -- is gated only in the exact kernels (dense_topk_exact*_kernel): where those do not run
+// (dim > 768, dim % 32 != 0, VRAG_TOPK_NO_EXACT) the scan would answer EVERY query again, image pass on top.  Batches rank the
+// image with the tiled search, which wants dim % 64 == 0; other dims would rank it on the scalar 4-queries-per-pass kernel.
+// Both cases keep the plain fp32 search (same bits, the faster route there).
+static bool prefilter_route_ok(const vrag_dense_index* ix, int nq, int k) {
+  if (!ix->rows16 || k > 16 || ix->size < 4096 || !(nq <= 2 || nq >= 64)) return false;
+  if (!dense_use_exact(1, ix->dim, k)) return false;                                     // the gated fallback scan exists in the exact kernels only
+  if (nq >= 64 && !dense_use_tiled(0, ix->dim, nq, PFK, (long long)ix->size)) return false;   // batches rank the image with the tiled search
+  return true;
+}
 
 struct vrag_sparse_index {
   int vocab = 0, device = 0;
@@ -2287,8 +2300,36 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
 
 int64_t vrag_dense_index_size(vrag_dense_index* ix) { return ix ? ix->size : -1; }
 
+// No first-call cost on the query path (the first 256-query batch of an index took 58 ms -- scratch hipMallocs,
+// hipFuncSetAttribute and the first load of every kernel of the route inside the search): the ingest call that brings a shard to
+// >= 4096 rows sizes the query-side scratch for batches of 256 x k = 16 and runs each route once (1, 2, 32 and 256 synthetic
+// queries: one-pass prefilter / single-query kernels, the 32-query passes, the tiled search).  Ingest pays for it once per index
+// (a few shard scans; kernel loading once per process); larger batches still grow the scratch on their first call.
+static void dense_warm_query_path(vrag_dense_index* ix) {
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->warmed || ix->size < 4096) return;
+    ix->warmed = true;
+  }
+  const int dim = ix->dim, k = 16, nq_max = 256;
+  std::vector<float> q((size_t)nq_max * dim);
+  unsigned h = 2463534242u;
+  for (float& v : q) {   // xorshift: distinct, non-bf16-exact query values (the (value, remainder) route is warmed too)
+    h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+    v = ((float)(h >> 8) / 16777216.0f - 0.5f) * 0.125f;
+  }
+  std::vector<float> sc((size_t)nq_max * k);
+  std::vector<int64_t> id((size_t)nq_max * k);
+  const long long s0 = ix->pf_searches, f0 = ix->pf_fallbacks;
+  for (int nq : {1, 2, 32, nq_max}) (void)vrag_dense_index_search(ix, q.data(), nq, k, sc.data(), id.data(), nullptr);
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->pf_searches = s0;      // synthetic queries say nothing about how this index's data behaves under the prefilter
+  ix->pf_fallbacks = f0;
+}
+
 int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
   ARG_CHECK(ix && rows && n > 0, "bad arguments");
+  {
   std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->size + n > ix->capacity) {
     set_error("dense index full: %lld + %lld > capacity %lld", (long long)ix->size, (long long)n,
@@ -2318,11 +2359,14 @@ int vrag_dense_index_add(vrag_dense_index* ix, const float* rows, int64_t n) {
   }
   ix->size += n;
   if (ix->rows16) HIP_TRY(hipMemcpy(ix->pf_stats, ix->d_norm2, 2 * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  dense_warm_query_path(ix);
   return VRAG_OK;
 }
 
 int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t n, void* stream) {
   ARG_CHECK(ix && rows && n > 0, "bad arguments");
+  {
   std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->size + n > ix->capacity) {
     set_error("dense index full: %lld + %lld > capacity %lld", (long long)ix->size, (long long)n, (long long)ix->capacity);
@@ -2345,6 +2389,8 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
   }
   HIP_TRY(hipStreamSynchronize(st));   // ingest is not the hot path: searches on any stream may follow at once
   ix->size += n;
+  }
+  dense_warm_query_path(ix);
   return VRAG_OK;
 }
 
@@ -2502,8 +2548,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   // Where it pays: one or two queries (half the bytes of the fp32 scan) and batches the tiled search takes (the shard read once
   // instead of once per 32 queries); in between the 32-queries-per-pass exact kernel is already the faster route.  An index
   // whose data keeps failing the sufficiency test (near-duplicate rows) stops trying.
-  const bool pf_live = ix->rows16 && k <= 16 && ix->size >= 4096 && (nq <= 2 || nq >= 64) &&
-                       !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
+  const bool pf_live = prefilter_route_ok(ix, nq, k) && !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
   if (pf_live) {
     std::vector<unsigned> flags((size_t)nq);
     if (nq <= 2) {
@@ -2581,11 +2626,11 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
   int rc;
   const long long n = (long long)nq * k;
   const u64* result = nullptr;
-  if (ix->rows16 && k <= 16 && ix->size >= 4096 && nq >= 64) {
+  if (nq >= 64 && prefilter_route_ok(ix, nq, k)) {
     // fp32 rows with a prefilter image, batch route (prefilter_batch_enqueue): nothing returns to the host
     if ((rc = prefilter_batch_enqueue(ix, queries, nq, k, st))) return rc;
     result = ix->d_pf_out;
-  } else if (ix->rows16 && k <= 16 && ix->size >= 4096 && nq <= 2) {
+  } else if (nq <= 2 && prefilter_route_ok(ix, nq, k)) {
     // one or two queries: the one-pass route, then the full scan behind the overflow flags (its workgroups leave at once when no
     // flag is up) and the per-query pick -- as above, nothing returns to the host
     const int dim = ix->dim;

@@ -83,7 +83,10 @@ class ShardComm:
         self.device = device
         self._merge = merge
         self._vcomm = None          # vrag_comm handle: the library's own RCCL communicator (include/vrag_amd.h)
-        if self.backend == "nccl" and merge is None and os.environ.get("VRAG_COMM", "") != "torch":
+        self._bufs = {}             # exchange buffers by (Q, k_in, k_out): allocated once, reused by every search of that shape
+        if self.backend == "nccl" and merge is None:
+            # every rank enters (the steps inside are collective); a rank that asks for torch's communicator (VRAG_COMM=torch) or
+            # cannot load RCCL votes "no" in the preflight and ALL ranks keep torch's communicator
             self._vcomm = self._create_library_comm(dist, group)
 
     def _create_library_comm(self, dist, group):
@@ -95,17 +98,31 @@ class ShardComm:
 
         lib = _lib.load()
         dev = torch.device("cuda", self.device)
-        # Every step below is collective, so no rank may leave it alone: a failure anywhere (RCCL not loadable, ncclCommInitRank
-        # refusing) is agreed on by all ranks, which then keep torch's communicator for the exchange -- never a rank waiting in a
-        # broadcast its peer has abandoned.
+        # Every step below is collective, so no rank may leave it alone.  PREFLIGHT first: everything that can fail on ONE rank
+        # only -- this rank wants torch's communicator (VRAG_COMM=torch), RCCL is not loadable here (vrag_comm_get_unique_id binds
+        # it) -- is agreed on by all ranks (MIN) BEFORE anybody enters the blocking ncclCommInitRank; after the preflight the only
+        # failures left are collective ones (ncclCommInitRank refusing), which every rank sees.
+        buf = (C.c_uint8 * 128)()
+        local_ok = 1
+        if os.environ.get("VRAG_COMM", "") == "torch":
+            local_ok = 0
+            self._vcomm_error = "VRAG_COMM=torch"
+        elif lib.vrag_comm_get_unique_id(buf) != 0:
+            local_ok = 0
+            self._vcomm_error = _lib.last_error()
+        pre = torch.tensor([local_ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN, group=group)
+        if int(pre.item()) != 1:
+            if getattr(self, "_vcomm_error", "") != "VRAG_COMM=torch":
+                import logging
+
+                logging.getLogger(__name__).warning("library RCCL communicator unavailable (%s): the exchange uses torch.distributed",
+                                                    getattr(self, "_vcomm_error", "a peer rank voted no"))
+            return None
         ident = torch.zeros(129, dtype=torch.uint8, device=dev)            # [128 id bytes | 1 = valid]
         if self.rank == 0:
-            buf = (C.c_uint8 * 128)()
-            if lib.vrag_comm_get_unique_id(buf) == 0:
-                ident[:128].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-                ident[128] = 1
-            else:
-                self._vcomm_error = _lib.last_error()
+            ident[:128].copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            ident[128] = 1
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(ident, src=src, group=group)
         host = ident.cpu().numpy()
@@ -135,17 +152,14 @@ class ShardComm:
         return "torch.distributed" if self.on_gpu else "host"
 
     def close(self) -> None:
+        """Destroys the library's communicator (collective-free, but call it on every rank BEFORE torch's process group is
+        torn down: `GpuVectorStore.close` does).  Not left to `__del__`: at interpreter exit torch may already be gone."""
+        self._bufs = {}
         if getattr(self, "_vcomm", None) is not None:
             from . import _lib
 
             _lib.load().vrag_comm_destroy(self._vcomm)
             self._vcomm = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
     @property
     def on_gpu(self) -> bool:
@@ -185,12 +199,30 @@ class ShardComm:
     def exchange_buffers(self, Q: int, k: int):
         """Device payload of one exchange: (uint8 tensor, ids pointer, scores pointer).  The local search writes its
         `[Q, k]` global ids / scores straight into it (`vrag_*_index_search_device`)."""
+        payload = self._exchange_set(Q, k, k)[0]
+        base = payload.data_ptr()
+        return payload, base, base + Q * k * 8
+
+    def _exchange_set(self, Q: int, kk: int, k: int):
+        """(payload, gathered, merged scores, merged ids) for one exchange shape -- allocated once per shape and reused: every
+        use is ordered on torch's current stream and the merged lists are copied to the host before the call returns."""
         import torch
 
-        n = Q * k
-        payload = torch.empty(self.payload_bytes(n), dtype=torch.uint8, device=torch.device("cuda", self.device))
-        base = payload.data_ptr()
-        return payload, base, base + n * 8
+        key = (Q, kk)
+        got = self._bufs.get(key)
+        if got is None:
+            if len(self._bufs) >= 16:
+                self._bufs.clear()
+            dev = torch.device("cuda", self.device)
+            nbytes = self.payload_bytes(Q * kk)
+            got = [torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(self.world * nbytes, dtype=torch.uint8, device=dev), {}]
+            self._bufs[key] = got
+        outs = got[2].get(k)
+        if outs is None:
+            dev = got[0].device
+            outs = (torch.empty((Q, k), dtype=torch.float32, device=dev), torch.empty((Q, k), dtype=torch.int64, device=dev))
+            got[2][k] = outs
+        return got[0], got[1], outs[0], outs[1]
 
     def allgather_merge_device(self, payload, Q: int, kk: int, k: int) -> Tuple[np.ndarray, np.ndarray]:
         """`payload` (from `exchange_buffers`, filled on torch's current stream) of every rank -> merged `[Q, k]` on the
@@ -203,9 +235,7 @@ class ShardComm:
         lib = _lib.load()
         n = Q * kk
         nbytes = self.payload_bytes(n)
-        flat = torch.empty(self.world * nbytes, dtype=torch.uint8, device=payload.device)
-        d_out_s = torch.empty((Q, k), dtype=torch.float32, device=payload.device)
-        d_out_i = torch.empty((Q, k), dtype=torch.int64, device=payload.device)
+        _, flat, d_out_s, d_out_i = self._exchange_set(Q, kk, k)
         base = flat.data_ptr()
         stream = torch.cuda.current_stream(payload.device).cuda_stream
         if self._vcomm is not None:      # THE collective of the retrieval path, behind the C ABI: ncclAllGather + merge on `stream`

@@ -731,9 +731,21 @@ class GpuVectorStore(VectorStore):
     DEVICE_K = 64           # longest list the device-resident exchange carries (one device pass)
     SPARSE_TAIL_MIN = 65536  # rows a sparse tail segment may always hold before it is folded into the main image
 
+    def _use_prefilter(self) -> bool:
+        if self.dense_dtype != "f32" or self.dense_prefilter is False:
+            return False
+        if self.dense_prefilter is True:
+            return True
+        return self.dense_dim is not None and self.dense_dim % 64 == 0 and self.dense_dim <= 768
+
     def __init__(self, dense_dim: Optional[int] = 384, sparse_vocab: Optional[int] = 30522, enable_dense: bool = True,
                  enable_sparse: bool = True, dense_dtype: str = "f32", device: int = 0, distributed: bool = False,
-                 group=None, comm=None, payload: str = "sharded", dense_headroom: float = 1.5):
+                 group=None, comm=None, payload: str = "sharded", dense_headroom: float = 1.5,
+                 dense_prefilter="auto"):
+        """`dense_prefilter` (fp32 rows only): keep a bf16 image of the rows beside them so that one or two queries and
+        batches >= 64 stream half / a fraction of the bytes (same bits as the full fp32 scan, `DenseShard`).  It costs
+        +50 % of the dense rows' HBM.  "auto" (default) = on where the image route exists (dim % 64 == 0 and <= 768,
+        csrc/topk.hip `prefilter_route_ok`), True / False force it; the choice is kept in a saved store's manifest."""
         self._lib = _lib.load()
         _lib.require_gpu()
         if dense_dtype not in ("f32", "bf16"):
@@ -743,11 +755,16 @@ class GpuVectorStore(VectorStore):
         self.enable_dense, self.enable_sparse = enable_dense, enable_sparse
         self.dense_dim, self.sparse_vocab, self.dense_dtype, self.device = dense_dim, sparse_vocab, dense_dtype, device
         self.dense_headroom = max(1.0, float(dense_headroom))
+        if dense_prefilter not in ("auto", True, False):
+            raise ValueError(f"dense_prefilter must be 'auto', True or False (got {dense_prefilter!r})")
+        self.dense_prefilter = dense_prefilter
         self._comm = comm
+        self._owns_comm = False
         if comm is None and distributed:
             from .distributed import ShardComm
 
             self._comm = ShardComm(group, device)
+            self._owns_comm = True
         self._rank = self._comm.rank if self._comm is not None else 0
         self._world = self._comm.world if self._comm is not None else 1
         self._payload_sharded = self._world > 1 and payload == "sharded"
@@ -786,6 +803,20 @@ class GpuVectorStore(VectorStore):
 
     def __len__(self) -> int:
         return len(self._ids)
+
+    def close(self) -> None:
+        """Drops the resident shards and, when the store created its own `ShardComm`, the library's RCCL communicator -- call
+        it on every rank before `torch.distributed.destroy_process_group()` (a communicator left to the garbage collector may
+        be destroyed after torch's process group is gone).  The store is empty afterwards."""
+        with self._mu:
+            self._subsets.clear()
+            self._dense = None              # released by their last user (DenseShard / SparseShard.__del__)
+            self._sparse_parts = []
+            self._owned_dev = None
+            self._dense_flushed = self._sparse_flushed = 0
+            self._dirty = True
+            if self._comm is not None and self._owns_comm:
+                self._comm.close()
 
     # -------------------------------------------------------------- ingest
     def add_vectors(self, ids, dense_vectors, sparse_vectors, texts, enhanced_texts, metadatas):
@@ -908,7 +939,7 @@ class GpuVectorStore(VectorStore):
                     # (re)build with head-room so later inserts append instead of re-uploading every row
                     self._dense = None                  # released now unless a search on another thread still holds it
                     self._dense_cap = max(1024, int(n * self.dense_headroom))
-                    dense = DenseShard(self.dense_dim, self._dense_cap, self.dense_dtype, self.device)
+                    dense = DenseShard(self.dense_dim, self._dense_cap, self.dense_dtype, self.device, prefilter=self._use_prefilter())
                     dense.add(rows)
                     self._dense = dense
                 else:
@@ -1116,7 +1147,7 @@ class GpuVectorStore(VectorStore):
                 local = np.nonzero(known & mask[np.where(known, owned, 0)])[0] if len(owned) else np.zeros(0, np.int64)
                 shard = None
                 if len(local) and kind == "dense":
-                    shard = DenseShard(self.dense_dim, len(local), self.dense_dtype, self.device)
+                    shard = DenseShard(self.dense_dim, len(local), self.dense_dtype, self.device, prefilter=self._use_prefilter())
                     shard.add(self._dense_rows.data[local])
                 elif len(local):
                     shard = SparseShard(self.sparse_vocab, *csr_take_rows(self._sp_ptr.data, self._sp_idx.data, self._sp_val.data, local),
@@ -1387,7 +1418,7 @@ class GpuVectorStore(VectorStore):
                 metas = {"empty_rows": len(metas)}                             # nothing to store per row
             head = {"format": self.FORMAT, "world": self._world, "dense_dim": self.dense_dim, "sparse_vocab": self.sparse_vocab,
                     "enable_dense": self.enable_dense, "enable_sparse": self.enable_sparse, "dense_dtype": self.dense_dtype,
-                    "rows": len(ids), "documents": list(self._documents.values())}
+                    "dense_prefilter": self.dense_prefilter, "rows": len(ids), "documents": list(self._documents.values())}
             r = self._rank
 
             def put_arrays(tmp):
@@ -1455,7 +1486,8 @@ class GpuVectorStore(VectorStore):
         head, ids, shards = cls._read_saved(path)
         st = cls(dense_dim=head["dense_dim"], sparse_vocab=head["sparse_vocab"], enable_dense=head["enable_dense"],
                  enable_sparse=head["enable_sparse"], dense_dtype=head["dense_dtype"], device=device,
-                 distributed=distributed, group=group, comm=comm, payload=payload)
+                 distributed=distributed, group=group, comm=comm, payload=payload,
+                 dense_prefilter=head.get("dense_prefilter", "auto"))
         n = len(ids)
         for owned, *_ in shards:
             if len(owned) and (owned.min() < 0 or owned.max() >= n):

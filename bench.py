@@ -731,9 +731,10 @@ def main() -> None:
                          "qkv_attn_local": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + M_mb * Hs * 2,
                          "gemm_qkv": M_mb * Hs * 2 + 3 * Hs * Hs * 2 + 3 * M_mb * Hs * 2,
                          "gemm_wi": M_mb * Hs * 2 + 2 * Is * Hs * 2 + M_mb * Is * 2,
-                         # residual GEMMs, split stream (round 4): A operand + weights + two 16-bit planes in and out (8 B per element)
-                         "gemm_wo": M_mb * Hs * 2 + Hs * Hs * 2 + 2 * M_mb * Hs * 4,
-                         "gemm_wo_mlp": M_mb * Is * 2 + Hs * Is * 2 + 2 * M_mb * Hs * 4}
+                         # residual GEMMs, split stream: A operand + weights + the operand plane and the byte remainder plane in and
+                         # out (round 6: 6 B per element; round 4's fp16 remainder plane: 8)
+                         "gemm_wo": M_mb * Hs * 2 + Hs * Hs * 2 + 2 * M_mb * Hs * 3,
+                         "gemm_wo_mlp": M_mb * Is * 2 + Hs * Is * 2 + 2 * M_mb * Hs * 3}
             dom_bytes = float(np.mean([alg_bytes[k] for k in classes[dom]]))
             gbps = dom_bytes / (t["avg_launch_ms"] * 1e-3) / 1e9
             frac_mfma, frac_hbm = t["tflops"] / PEAK_BF16_TFLOPS, gbps / PEAK_HBM_GBPS
@@ -793,7 +794,7 @@ def main() -> None:
             "config": {"workload": ("BASELINE configs[1]: ModernBERT-base span extractor, batch 256 chunks x 512 tok, single query, 16 sentences/chunk" if args.model == "base" else "ModernBERT-large geometry (BASELINE configs[4] extractor), batch 256 chunks x 512 tok, 16 sentences/chunk"),
                        "chunks_per_gpu_per_step": n_chunks, "seq_len": SEQ, "sentences_per_chunk": N_SENT,
                        "micro_batch_tokens": args.micro_batch_tokens, "parallelism": f"dp{world} (independent chunks, no collective)",
-                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), {args.operand_dtype} MFMA operands, fp32 accumulate / LayerNorm / softmax / heads; residual stream between sub-layers as two 16-bit planes (operand copy + fp16 remainder, 19+ significant bits)"},
+                       "weights": f"random-init ModernBERT-{args.model} (seed 1234), {args.operand_dtype} MFMA operands, fp32 accumulate / LayerNorm / softmax / heads; residual stream between sub-layers as the operand copy + one remainder byte per element (16 significant bits with bf16 operands, 19 with fp16)"},
             "sentence_classifications_per_s": value * N_SENT,
             "model_tflops": value * chunk_flops(shape) / 1e12,
             "model_mfma_frac": value * chunk_flops(shape) / 1e12 / (PEAK_BF16_TFLOPS * world),

@@ -34,7 +34,7 @@ def main(pmc_path, bench_path):
     H, I = 768, 1152
     # residual GEMMs (round 4): the stream arrives and leaves as two 16-bit planes -- 4 B read + 4 B written per element, the
     # written high plane being the next GEMM's operand copy (round 3: 8 B of fp32 read-modify-write + a 2 B copy)
-    stream = 2 * rows * H * 4
+    stream = 2 * rows * H * 3   # operand plane + byte remainder plane, in and out (round 6; 8 B per element in rounds 4-5)
     alg = {
         "gemm_qkv": rows * H * 2 + 3 * H * H * 2 + 3 * rows * H * 2,
         "gemm_wi": rows * H * 2 + 2 * I * H * 2 + rows * I * 2,

@@ -296,7 +296,7 @@ struct vrag_encoder {
   float *st_part = nullptr, *ln_mu = nullptr, *ln_rstd = nullptr;  // folded-LayerNorm row statistics (ln_mu relative to ln_shift's previous value)
   float* ln_shift = nullptr;                                        // absolute row means = the next residual epilogue's shift
   float* ln_shift_prev = nullptr;                                   // the shift before the last advance: what the split planes in HBM are relative to
-  f16_t* lo16 = nullptr;                                            // [cap_rows, H] low plane of the split residual stream (gemm_bf16.h)
+  unsigned char* lo8 = nullptr;                                     // [cap_rows * H] byte remainder plane of the split residual stream (gemm_bf16.h: 64 x 64 blocks)
   bool split_resid = true;                                          // VRAG_SPLIT_RESID=0: fp32 rows between all sub-layers (A/B)
   int *d_blk_start = nullptr, *d_blk_len = nullptr, *d_blk_q0 = nullptr;     // global-layer q-blocks
   int *d_lblk_start = nullptr, *d_lblk_len = nullptr, *d_lblk_q0 = nullptr;  // banded-layer q-blocks
@@ -708,8 +708,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
           g.ln_shift = e->ln_shift + r0;
           if (split) {   // layers >= 1: the stream arrives split (mlp Wo of the previous layer) and leaves split (this layer's mlp Wo reads it)
-            g.lo_in = e->lo16 + (size_t)r0 * H;
-            g.lo_out = e->lo16 + (size_t)r0 * H;
+            g.lo_in = e->lo8 + (size_t)r0 * H;
+            g.lo_out = e->lo8 + (size_t)r0 * H;
             g.ln_shift_prev = e->ln_shift_prev + r0;
           }
         }
@@ -757,10 +757,10 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           g.resid_bf16 = e->a + (size_t)r0 * H;
           g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
           g.ln_shift = e->ln_shift + r0;
-          if (split) g.lo_out = e->lo16 + (size_t)r0 * H;
+          if (split) g.lo_out = e->lo8 + (size_t)r0 * H;
         }
         if (split && l > 0) {   // this layer's attention Wo left the stream split; the last layer of a run writes the fp32 rows again
-          g.lo_in = e->lo16 + (size_t)r0 * H;
+          g.lo_in = e->lo8 + (size_t)r0 * H;
           g.ln_shift_prev = e->ln_shift_prev + r0;
           if (!g.resid_bf16) g.resid_bf16 = e->a + (size_t)r0 * H;   // the high plane is read from there
         }
@@ -1014,7 +1014,7 @@ int init_workspace(vrag_encoder* e) {
   TRY(dev_alloc(e, &e->ln_rstd, R));
   TRY(dev_alloc(e, &e->ln_shift, R));
   TRY(dev_alloc(e, &e->ln_shift_prev, R));
-  TRY(dev_alloc(e, &e->lo16, (size_t)R * H));
+  TRY(dev_alloc(e, &e->lo8, (size_t)R * H));
   // the six q-block descriptor arrays are slices of ONE buffer (host and device alike): one upload per batch
   TRY(dev_alloc(e, &e->d_blk_start, (size_t)6 * e->cap_blocks));
   e->d_blk_len = e->d_blk_start + e->cap_blocks;

@@ -112,8 +112,8 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
     g.resid_bf16 = (bf16_t*)outb;
     g.stats_part = (float*)q;                                              // Mp * N/64 * 2 floats <= Mp * N * 2 bytes
     if (getenv("VRAG_DEBUG_GEMM_SPLIT")) {   // the split residual stream on both sides (layers >= 1 of the encoder schedule)
-      g.lo_in = (const f16_t*)kk;
-      g.lo_out = (f16_t*)kk;
+      g.lo_in = (const unsigned char*)kk;
+      g.lo_out = (unsigned char*)kk;
       g.ln_shift = (const float*)pos;        // zeros
       g.ln_shift_prev = (float*)pos;
       (void)hipMemset(kk, 0, Mp * N * 2);

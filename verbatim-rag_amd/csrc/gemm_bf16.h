@@ -54,13 +54,16 @@ struct GemmParams {
   const float* ln_shift;  // [Mpad] or null: per-row shift c subtracted before the bf16 copy / the statistics (see the epilogue)
   bf16_t* resid_bf16;     // [Mpad, N] or null  = bf16(updated residual - c)
   float* stats_part;      // [Mpad, N/64, 2] or null
-  // EPI_RESIDUAL, split residual stream (round 4): between two sub-layers the stream is kept as TWO 16-bit planes relative to the
-  // row shift, h = c + float(hi) + float(lo): hi = op16(h - c) is `resid_bf16` -- the very operand copy the next GEMM reads --
-  // and lo = fp16((h - c) - hi) (19-22 significant bits together; the fp32 rows are not written at all).  8 instead of 10 bytes
-  // per element and sub-layer.  lo_in: the stream arrives split (hi is read from resid_bf16, relative to ln_shift_prev);
-  // lo_out: it leaves split (relative to ln_shift).  Both null = the fp32 rows of out_f32 on both sides.
-  const f16_t* lo_in;     // [Mpad, N] or null
-  f16_t* lo_out;          // [Mpad, N] or null (may alias lo_in: every element is read and written by the same lane)
+  // EPI_RESIDUAL, split residual stream (round 4; byte remainders since round 6): between two sub-layers the stream is kept as the
+  // operand plane plus ONE byte per element, h = c + float(hi) * (1 + (byte - 128) * step): hi = op16(h - c) is `resid_bf16` -- the
+  // very operand copy the next GEMM reads -- and the byte carries the next 8 bits of (h - c) / hi (16 significant bits together
+  // for bf16 operands, 19 for fp16; the fp32 rows are not written at all).  6 instead of 10 bytes per element and sub-layer.
+  // lo_in: the stream arrives split (hi is read from resid_bf16, relative to ln_shift_prev); lo_out: it leaves split (relative
+  // to ln_shift).  Both null = the fp32 rows of out_f32 on both sides.  The byte plane's layout is the epilogue's own (64 x 64
+  // blocks of 4 KiB, gemm_bf16.hip lo8_offset); a [Mpad, N]-byte allocation holds it, Mpad % 64 == 0, and the plane of a row range
+  // that starts at a multiple of 64 rows starts at row0 * N bytes.
+  const unsigned char* lo_in;     // [Mpad * N] bytes or null
+  unsigned char* lo_out;          // [Mpad * N] bytes or null (may alias lo_in: every byte is read and written by the same lane)
   float* ln_shift_prev;   // [Mpad]: the shift the arriving planes are relative to (written by whoever advances ln_shift)
   // Consumer-side finalisation of the row statistics, small-row configuration only (gemm_consumer_finalizes()): the LayerNorm-folding GEMM
   // (EPI_QKV_ROPE / EPI_GEGLU / EPI_BF16) finishes the producer's partial statistics itself -- every wave for its own 64 rows,

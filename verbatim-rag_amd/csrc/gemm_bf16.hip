@@ -48,46 +48,75 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 
-// EPI_RESIDUAL with the residual stream split into two 16-bit planes on one or both sides (GemmParams::lo_in / lo_out).
-// Same staging as the fp32 form (a pass = 64 rows x 64 columns of accumulators through the wave's 16 KiB, half-passes of 32
-// rows, the arriving rows of a half prefetched one half ahead), but a lane takes EIGHT consecutive columns of its row, so every
-// plane moves in 16-byte pieces per lane and whole 128-byte lines per 8 lanes: hi in, lo in, hi out, lo out -- four streams of
-// the width the three of the fp32 form have (a first probe of the split stream in round 2 used 8-byte pieces and bought nothing:
-// DESIGN.md section 3).  Arithmetic per element: v = (acc + h_in) + off, off = [c_prev if arriving split] - [c if leaving split];
-// leaving split: hi = op16(v), lo = fp16(v - hi), statistics of v (sum, sum of squares per 64-column slice) as the fp32 form.
-template <int RT, typename T>
-__device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* stg, int lane, int mw, int nw) {
+// EPI_RESIDUAL with the residual stream split into the operand plane and a BYTE remainder plane on one or both sides
+// (GemmParams::lo_in / lo_out).  Same staging as the fp32 form (a pass = 64 rows x 64 columns of accumulators through the wave's
+// 16 KiB, half-passes of 32 rows, the arriving rows of a half prefetched one half ahead); a lane takes EIGHT consecutive columns of
+// its row, so the high plane moves in 16-byte pieces per lane and whole 128-byte lines per 8 lanes.
+// Round 6: the low plane is ONE byte per element, relative to the high plane:  v = hi * (1 + (b - 128) * kLoStep),
+// b = rne(((v / hi) - 1) / kLoStep) + 128 saturated to [0, 255]  (|v / hi - 1| <= 2^-8 for bf16, 2^-11 for fp16: 16 / 19
+// significant bits together; hi = 0 decodes to 0 whatever the byte).  One v_cvt_f32_ubyteN + one packed FMA + one packed
+// multiply to decode two elements, one v_rcp + one multiply + one FMA + one v_cvt_pk_u8_f32 to encode one.  The byte plane is
+// touched by this epilogue only, so its layout is the epilogue's own (lo8_offset below): per 64 x 64 block of the stream 4 KiB,
+// and inside it the 16 bytes a lane needs for TWO consecutive instructions of a half-pass are contiguous -- every access to the
+// plane is a 16-byte access of a lane-linear 1 KiB run.  (Round 4 probed a byte plane twice and dropped it: with 8 columns per
+// lane in row-major order its accesses are 8-byte pieces, which cost the memory pipeline what 16-byte pieces cost, and the
+// bit-field packing took ~20 integer instructions per element: profiles/r04_split_lo8_*_probe.txt.)
+// Arithmetic per element: v = (acc + h_in) + off, off = [c_prev if arriving split] - [c if leaving split];
+// leaving split: hi = op16(v), byte as above, statistics of v (sum, sum of squares per 64-column slice) as the fp32 form.
+template <typename T> struct LoStep;
+template <> struct LoStep<bf16_t> { static constexpr float step = 1.0f / 32768.0f, inv = 32768.0f; };      // 2^-15: 2^-8 / 128
+template <> struct LoStep<f16_t> { static constexpr float step = 1.0f / 262144.0f, inv = 262144.0f; };    // 2^-18: 2^-11 / 128
+
+// byte offset of the 16-byte piece of (64 x 64 block at rows rb64 * 64, columns cb64 * 64; half-pass half; instruction pair ip; lane)
+__device__ __forceinline__ size_t lo8_offset(int rb64, int cb64, int n_cb, int half, int ip, int lane) {
+  return ((size_t)rb64 * n_cb + cb64) * 4096 + (size_t)(half * 2048 + ip * 1024 + lane * 16);
+}
+
+// The optional sides (arriving split, leaving split, row statistics) are wave-uniform launch parameters: the body is compiled per
+// combination and entered through ONE dispatch per tile (residual_split_epilogue below).  Left as run-time tests inside the body
+// the compiler merges the two arms' loads into one load with a run-time destination slot -- the prefetch sets then live in
+// scratch, every load followed by s_waitcnt vmcnt(0) and a scratch store.
+template <int RT, typename T, bool in_split, bool out_split, bool STATS>
+__device__ __forceinline__ void residual_split_body(const GemmParams& p, f32x4 (&acc)[4][RT], char* stg, int lane, int mw, int nw) {
   typedef typename Op<T>::v8 V8;
   constexpr int NI = 4;   // instructions per half-pass: 8 rows x (8 lanes x 8 columns)
+  constexpr float kStep = LoStep<T>::step, kInv = LoStep<T>::inv;
   const int q = lane >> 4, l15 = lane & 15, gq = lane >> 3, l7 = lane & 7;
-  const bool in_split = p.lo_in != nullptr, out_split = p.lo_out != nullptr;
   float off[RT / 4];   // lane L: the offset of row ps * 64 + L
 #pragma unroll
   for (int ps = 0; ps < RT / 4; ++ps) {
     const int row = mw + ps * 64 + lane;
     off[ps] = (in_split ? p.ln_shift_prev[row] : 0.f) - (out_split ? p.ln_shift[row] : 0.f);
   }
+  // per half-pass and set: four 16-byte pieces of the high plane (or eight of the fp32 rows) + two of the byte plane
   f32x4 hA[NI][2], hB[NI][2];
   // addresses as (wave-uniform row base) + (one 32-bit lane offset): a 64-bit lane address per plane and instruction would cost
   // the epilogue the registers its two prefetch sets need
   unsigned loff = (unsigned)(gq * p.N + 8 * l7);   // elements, inside the 8-row group of an instruction
+  unsigned boff = (unsigned)(lane * 16);           // bytes, inside the 1 KiB run of an instruction pair
   asm volatile("" : "+v"(loff));
+  asm volatile("" : "+v"(boff));
+  const int n_cb = p.N >> 6;
   auto row_base = [&](int hp, int i) {   // uniform: first element of the instruction's first row
     return ((size_t)(mw + (hp >> 1) * 64 + (hp & 1) * 32 + i * 8)) * p.N + nw;
+  };
+  auto byte_base = [&](int hp, int ip) {   // uniform: first byte of the pair's 1 KiB run
+    return lo8_offset((mw >> 6) + (hp >> 1), nw >> 6, n_cb, hp & 1, ip, 0);
   };
   auto prefetch = [&](f32x4 (&dst)[NI][2], int hp) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const size_t rb = row_base(hp, i);
-      if (in_split) {
+      if constexpr (in_split) {
         dst[i][0] = load16_nt(p.resid_bf16 + rb + loff);
-        dst[i][1] = load16_nt(p.lo_in + rb + loff);
+        if ((i & 1) == 0) dst[i >> 1][1] = load16_nt(p.lo_in + byte_base(hp, i >> 1) + boff);   // bytes of instructions i and i + 1
       } else {
         dst[i][0] = load16_nt(p.out_f32 + rb + loff);
         dst[i][1] = load16_nt(p.out_f32 + rb + loff + 4);
       }
     }
   };
+  unsigned pk0 = 0u, pk1 = 0u;   // the bytes of an even instruction, waiting for its odd partner's
   auto finish_half = [&](const f32x4 (&hv)[NI][2], int hp) {
     const int ps = hp >> 1;
 #pragma unroll
@@ -98,11 +127,18 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
       const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rowp << 2, __builtin_bit_cast(int, off[ps])));
       // the additions and the statistics as packed fp32 (two columns per issue slot)
       f32x2 v[4] = {{a0[0], a0[1]}, {a0[2], a0[3]}, {a1[0], a1[1]}, {a1[2], a1[3]}};
-      if (in_split) {
+      if constexpr (in_split) {
         const V8 hi = __builtin_bit_cast(V8, hv[i][0]);
-        const f16x8 lo = __builtin_bit_cast(f16x8, hv[i][1]);
+        const f32x4 bytes = hv[i >> 1][1];
+        const unsigned w_lo = f2u((i & 1) ? bytes[2] : bytes[0]), w_hi = f2u((i & 1) ? bytes[3] : bytes[1]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += f32x2{(float)hi[2 * j], (float)hi[2 * j + 1]} + f32x2{(float)lo[2 * j], (float)lo[2 * j + 1]};
+        for (int j = 0; j < 4; ++j) {
+          const unsigned ww = j < 2 ? w_lo : w_hi;
+          const int sh = (j & 1) * 16;
+          const f32x2 b = {(float)((ww >> sh) & 0xffu), (float)((ww >> (sh + 8)) & 0xffu)};   // v_cvt_f32_ubyteN
+          const f32x2 m = pk_fma(b, splat2(kStep), splat2(1.0f - 128.0f * kStep));
+          v[j] = pk_fma(f32x2{(float)hi[2 * j], (float)hi[2 * j + 1]}, m, v[j]);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -113,21 +149,28 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += o;
       const size_t rb = row_base(hp, i);
-      if (out_split) {
+      if constexpr (out_split) {
         V8 ho;
-        f16x8 lw;
+        unsigned w0 = 0u, w1 = 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          ho[j] = Op<T>::to(v[j >> 1][j & 1]);
-          // fp16 operands: hi clamps at +-65504, so the remainder of an outlier beyond ~131 000 would overflow the fp16 low plane
-          // to inf and poison the stream -- clamp it too (and raise the saturation flag); bf16 hi never leaves a remainder
-          // above 2^-8 |v|, the plain conversion is exact enough there and costs nothing
-          if constexpr (std::is_same<T, f16_t>::value) lw[j] = Op<f16_t>::to(v[j >> 1][j & 1] - (float)ho[j]);
-          else lw[j] = (f16_t)(v[j >> 1][j & 1] - (float)ho[j]);
+          const float x = v[j >> 1][j & 1];
+          ho[j] = Op<T>::to(x);
+          // (x / hi - 1) / step + 128; hi = 0 (x = 0, or an fp16 underflow): 0 * inf = NaN -> byte 0 -> decodes to hi * (...) = 0;
+          // an fp16 hi clamped at +-65504 saturates the byte (and Op<T>::to has raised the saturation flag)
+          const float t = fmaf(x * __builtin_amdgcn_rcpf((float)ho[j]), kInv, 128.0f - kInv);
+          if (j < 4) w0 = __builtin_amdgcn_cvt_pk_u8_f32(t, (unsigned)j, w0);
+          else w1 = __builtin_amdgcn_cvt_pk_u8_f32(t, (unsigned)(j - 4), w1);
         }
         store16_nt(p.resid_bf16 + rb + loff, __builtin_bit_cast(f32x4, ho));
-        store16_nt(p.lo_out + rb + loff, __builtin_bit_cast(f32x4, lw));
-        if (p.stats_part) {
+        if (i & 1) {
+          store16_nt(p.lo_out + byte_base(hp, i >> 1) + boff, f32x4{__builtin_bit_cast(float, pk0), __builtin_bit_cast(float, pk1),
+                                                                    __builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1)});
+        } else {
+          pk0 = w0;
+          pk1 = w1;
+        }
+        if constexpr (STATS) {
           const f32x2 t1 = (v[0] + v[1]) + (v[2] + v[3]);
           const f32x2 t2 = pk_fma(v[3], v[3], pk_fma(v[2], v[2], pk_fma(v[1], v[1], v[0] * v[0])));
           float s1 = t1[0] + t1[1], s2 = t2[0] + t2[1];
@@ -158,6 +201,20 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
     finish_half(hA, 2 * ps);
     if (ps + 1 < RT / 4) prefetch(hA, 2 * ps + 2);
     finish_half(hB, 2 * ps + 1);
+  }
+}
+
+template <int RT, typename T>
+__device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* stg, int lane, int mw, int nw) {
+  const bool in_split = p.lo_in != nullptr, out_split = p.lo_out != nullptr, stats = p.stats_part != nullptr;
+  if (in_split && out_split) {            // layers >= 1 of the ModernBERT schedule
+    if (stats) residual_split_body<RT, T, true, true, true>(p, acc, stg, lane, mw, nw);
+    else residual_split_body<RT, T, true, true, false>(p, acc, stg, lane, mw, nw);
+  } else if (out_split) {                 // layer 0's mlp Wo: fp32 rows in, planes out
+    if (stats) residual_split_body<RT, T, false, true, true>(p, acc, stg, lane, mw, nw);
+    else residual_split_body<RT, T, false, true, false>(p, acc, stg, lane, mw, nw);
+  } else {                                // the last sub-layer of a run: planes in, fp32 rows out
+    residual_split_body<RT, T, true, false, false>(p, acc, stg, lane, mw, nw);
   }
 }
 

@@ -313,6 +313,117 @@ def api_leg(eng, shape, n_chunks: int, steps: int):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def e2e_text_leg(shape, weights, qa_w, qa_b, device: int, n_docs: int = 1_000_000, n_queries: int = 1000, k: int = 5):
+    """BASELINE configs[2] composed with TEXT queries (reference path verbatim_rag/index.py:592-655 ->
+    vector_stores/milvus_base.py:250-259 -> core.py:237-277): `n_queries` question texts -> GpuSpladeProvider.embed_queries (the
+    QUERY-side encoder forward on the GPU: BERT-base shape, 12 layers, V = 30 522, fp16 operands + split-operand SPLADE head,
+    the provider's defaults) -> exact sparse top-k over a 10^6-document SELL index -> extract_spans_batch over the top-5 chunks of
+    every question (ModernBERT-base sentence classifier, cross-query batching).  Synthetic everything: Zipf corpus generated on
+    the GPU, seeded random-init encoders; the random-init head's active terms are mapped onto the corpus' Zipf distribution on the
+    host (a trained SPLADE model's query terms follow it by themselves) and its decoder bias is calibrated to ~32 active terms
+    per question.  Parity of the same composition: tests/test_e2e_text_in_gpu.py.  Host-inclusive wall time.  Never raises."""
+    try:
+        import gc
+        import types
+
+        import torch
+        from tokenizers import Tokenizer
+
+        from verbatim_rag_amd.embedding_providers import GpuSpladeProvider
+        from verbatim_rag_amd.engine import BertEncoderEngine, BertShape, EncoderEngine
+        from verbatim_rag_amd.extractors import GpuModelSpanExtractor
+        from verbatim_rag_amd.vector_stores import SparseShard
+        from verbatim_rag_amd.weights import random_init_bert
+
+        V = 30522
+        dev = torch.device("cuda", device)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        t0 = time.perf_counter()
+        nnz = torch.poisson(torch.full((n_docs,), 128.0, device=dev), generator=g).clamp_(min=1).to(torch.int64)
+        indptr = torch.zeros(n_docs + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nnz, 0, out=indptr[1:])
+        total = int(indptr[-1])
+        p = 1.0 / torch.arange(1, V + 1, device=dev, dtype=torch.float64)
+        cdf = torch.cumsum(p / p.sum(), 0).to(torch.float32)
+        idx = torch.searchsorted(cdf, torch.rand(total, device=dev, generator=g)).clamp_(max=V - 1).to(torch.int32)
+        val = (torch.randint(1, 193, (total,), device=dev, generator=g).to(torch.float32) / 64.0)
+        shard = SparseShard(V, indptr.cpu().numpy(), idx.cpu().numpy(), val.cpu().numpy())
+        zipf_map = torch.searchsorted(cdf, torch.rand(V, device=dev, generator=g)).clamp_(max=V - 1).cpu().numpy()   # term id -> Zipf-distributed id
+        del nnz, indptr, idx, val
+        t_index = time.perf_counter() - t0
+
+        tok = Tokenizer.from_file(os.path.join(ROOT, "tests", "golden", "tokenizer.json"))
+        words = [w for w, _i in sorted(tok.get_vocab().items(), key=lambda kv: kv[1]) if w.isalpha() and len(w) > 2]
+        rng = np.random.default_rng(2024)
+        pool = []
+        for _ in range(2048):                      # chunk texts: 12 sentences of 8-15 words, tokenised once (ingest-time work)
+            sents = [" ".join(rng.choice(words, int(rng.integers(8, 16))).tolist()).capitalize() + "." for _s in range(12)]
+            pool.append(" ".join(sents))
+        questions = ["Where is the " + " ".join(rng.choice(words, int(rng.integers(4, 9))).tolist()) + "?" for _ in range(n_queries)]
+
+        bshape = BertShape.bert_base()
+        W = random_init_bert(bshape, seed=1234)
+        emb = BertEncoderEngine(bshape, {k_: v for k_, v in W.items() if not k_.startswith("mlm.")}, max_tokens=32768, max_seqs=2048,
+                                max_seq_len=128, max_ranges=2048, device=device, operand_dtype="f16")
+        head = (W["mlm.dense.w"], W["mlm.dense.b"], W["mlm.ln.w"], W["mlm.ln.b"])
+        emb.set_mlm_head_ex(*head, np.zeros(V, np.float32), W.get("mlm.dec.w"))
+        prov = GpuSpladeProvider(emb, tok, max_length=128, sparse_cap=4096)
+        rows = prov._rows(questions[:64])          # calibration: decoder bias for ~32 active terms per question
+        raw = np.where(rows > 0, np.expm1(rows), 0.0)          # relu(logit) back from log1p
+        thr = float(np.quantile(raw, 1.0 - 32.0 / V))
+        emb.set_mlm_head_ex(*head, np.full(V, -thr, np.float32), W.get("mlm.dec.w"))
+
+        ext_eng = EncoderEngine(shape, weights, max_tokens=131072, max_seqs=2048, max_seq_len=SEQ, max_ranges=32768,
+                                micro_batch_tokens=65536, device=device)
+        ext_eng.set_qa_head(qa_w, qa_b)
+        ext = GpuModelSpanExtractor(engine=ext_eng, tokenizer=tok, threshold=0.5)
+        ext.prepare_chunks(pool)
+
+        def run():
+            t = {}
+            a = time.perf_counter()
+            dicts = prov.embed_queries(questions)                                   # query-side encoder + SPLADE head on the GPU
+            queries = []
+            for d in dicts:                                                         # synthetic-data plumbing: ids onto the corpus' Zipf law
+                q = {}
+                for term, w_ in d.items():
+                    z = int(zipf_map[term])
+                    q[z] = max(q.get(z, 0.0), w_)
+                queries.append(q or {0: 1.0})
+            t["embed_s"] = time.perf_counter() - a
+            a = time.perf_counter()
+            _scores, ids = shard.search(queries, k)
+            t["search_s"] = time.perf_counter() - a
+            a = time.perf_counter()
+            results = [[types.SimpleNamespace(text=pool[int(i) % len(pool)]) for i in row if i >= 0] for row in ids]
+            spans = ext.extract_spans_batch(questions, results)
+            t["extract_s"] = time.perf_counter() - a
+            return t, ids, spans, queries
+
+        run()
+        gc.collect()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        t, ids, spans, queries = run()
+        torch.cuda.synchronize()
+        total_s = time.perf_counter() - a
+        n_pairs = int((ids >= 0).sum())
+        out = {"e2e_queries_per_s": n_queries / total_s, "total_s": total_s, "embed_s": t["embed_s"], "search_s": t["search_s"],
+               "extract_s": t["extract_s"], "pairs": n_pairs, "index_build_s": t_index,
+               "mean_query_terms": float(np.mean([len(q) for q in queries])),
+               "spans_returned": int(sum(len(v) for d in spans for v in d.values())),
+               "what": f"{n_queries} question texts -> SPLADE query encoder on the GPU (BERT-base shape, V = {V}, fp16 operands, split head) -> "
+                       f"exact sparse top-{k} over {n_docs} docs ({total} nnz) -> extract_spans_batch over the top-{k} chunks "
+                       "(ModernBERT-base sentence classifier); host-inclusive wall time, one process"}
+        shard.close()
+        emb.close()
+        ext_eng.close()
+        return out
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def token_head_f16_leg(shape, weights, seqs, micro_batch_tokens: int, device: int, steps: int):
     """The reference's DEFAULT extractor (v2 highlighter, extractors.py:203-228) runs the token-classification head; here
     with fp16 MFMA operands (what keeps per-token logits within 1e-3) + the split-operand head, same 256 x 512 batch,
@@ -763,7 +874,7 @@ def main() -> None:
                     "classes": {c: {"tflops": v["tflops"], "frac": v["tflops"] / PEAK_BF16_TFLOPS,
                                     "avg_launch_ms": v["avg_launch_ms"]} for c, v in iso_cls.items()},
                     "breakdown_ms_per_step": {k: v[0] / 2 for k, v in iso.items() if v[1] > 0}}
-        cpu, parity, recall, api, tok16, ragged, parity_rel, parity_prob = None, None, None, None, None, None, None, None
+        cpu, parity, recall, api, tok16, ragged, parity_rel, parity_prob, e2e = None, None, None, None, None, None, None, None, None
         if world == 1 and args.cpu_budget > 0:
             if roof is not None:
                 roof.update(power_limited_rate(shape, min(args.micro_batch_tokens or n_chunks * SEQ, n_chunks * SEQ), local_rank, value))
@@ -778,6 +889,7 @@ def main() -> None:
                                                if k in ragged_best}
             tok16 = token_head_f16_leg(shape, weights, seqs, args.micro_batch_tokens, local_rank, steps=max(3, args.steps))
             recall = topk_recall_check()
+            e2e = e2e_text_leg(shape, weights, qa_w, qa_b, local_rank)
             cpu, ref_logits = cpu_baseline(shape, weights, qa_w, qa_b, seqs, bounds, args.cpu_budget)
             ref = np.concatenate(ref_logits, axis=0)
             got = logits[: ref.shape[0]]
@@ -804,6 +916,7 @@ def main() -> None:
             "topk_recall_vs_cpu_ref": recall,
             "sharded_queries_per_s": None, "sharded_topk": None,
             "api_chunks_per_s": api.get("api_chunks_per_s") if api else None, "api_leg": api, "token_head_f16": tok16,
+            "e2e_queries_per_s": e2e.get("e2e_queries_per_s") if e2e else None, "e2e_text_leg": e2e,
             "breakdown": breakdown,
         }
     else:

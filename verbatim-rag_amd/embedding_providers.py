@@ -51,12 +51,37 @@ class SparseEmbeddingProvider(ABC):
 
 
 class _EncoderProvider:
+    """`from_directory` builds the engine with **fp16 MFMA operands** (11 significant bits at the bf16 rate): embeddings feed an
+    index whose top-k is held to bit-exactness, and nothing averages operand rounding away under SPLADE's max-pool -- measured end
+    to end against the fp32 oracle, BERT-base width: SPLADE weights 1.6e-3 (fp16) vs 1.3e-2 (bf16), dense rows 6e-5 (fp16)
+    (tests/test_splade_real_vocab_gpu.py, tests/test_e2e_text_in_gpu.py).  fp16 saturates at 65504 instead of overflowing: the
+    library reports every clamp, and on the first report the provider rebuilds its engine with bf16 operands (fp32's exponent
+    range) and runs the batch again -- `operand_dtype="bf16"` skips the probe; a provider that was HANDED its engine raises."""
+
     def __init__(self, engine: Any, tokenizer: Any, max_length: int = 512):
         self.engine = engine
         self.tokenizer = tokenizer
         self.max_length = min(max_length, engine.max_seq_len)
         self._tok = TokenizerAdapter.for_model(tokenizer, engine.shape)
         self._lock = getattr(engine, "lock", None) or threading.Lock()   # the handle's own lock: wrappers may share it
+        self._rebuild_bf16 = None      # set by from_directory: () -> a bf16 engine of the same checkpoint
+
+    def _f16_clamped(self) -> bool:
+        """True = the engine was swapped for a bf16 one and the caller must run its batch again (caller holds the lock)."""
+        eng = self.engine
+        if getattr(eng, "operand_dtype", "bf16") != "f16" or not hasattr(eng, "f16_saturated") or not eng.f16_saturated(reset=True):
+            return False
+        if self._rebuild_bf16 is None:
+            raise RuntimeError("fp16 MFMA operands saturated on this checkpoint (activations beyond 65504): "
+                               "build the engine with operand_dtype='bf16'")
+        import logging
+
+        logging.getLogger(__name__).warning("fp16 MFMA operands saturated (activations beyond 65504): switching this provider to bf16 "
+                                            "operands (construct it with operand_dtype='bf16' to skip the probe)")
+        old, self.engine = self.engine, self._rebuild_bf16()
+        self._rebuild_bf16 = None
+        old.close()
+        return True
 
     def _encode(self, texts: Sequence[str]) -> List[List[int]]:
         return [self._tok.ids(t, add_special_tokens=True, max_length=self.max_length) for t in texts]
@@ -76,7 +101,7 @@ class _EncoderProvider:
 
 
 def load_encoder_directory(model_path: str, device: int = 0, max_tokens: int = 65536, max_seqs: int = 512,
-                           max_seq_len: int = 512, splade_split_operands: bool = True, **engine_kw):
+                           max_seq_len: int = 512, splade_split_operands: bool = True, operand_dtype: str = "f16", **engine_kw):
     """(engine, tokenizer, raw config) from a local HF checkpoint directory -- the local-files counterpart of the model
     names the reference hands to sentence-transformers (`SpladeProvider(model_name)`, embedding_providers.py:117-133;
     `SentenceTransformersProvider(model_name)`, :52-71).  BERT / DistilBERT checkpoints get a `BertEncoderEngine` (MLM
@@ -91,7 +116,8 @@ def load_encoder_directory(model_path: str, device: int = 0, max_tokens: int = 6
 
     with open(os.path.join(model_path, "config.json")) as f:
         model_type = json.load(f).get("model_type")
-    kw = dict(max_tokens=max_tokens, max_seqs=max_seqs, max_seq_len=max_seq_len, max_ranges=max(max_seqs, 64), device=device, **engine_kw)
+    kw = dict(max_tokens=max_tokens, max_seqs=max_seqs, max_seq_len=max_seq_len, max_ranges=max(max_seqs, 64), device=device,
+              operand_dtype=operand_dtype, **engine_kw)
     if model_type in ("bert", "distilbert"):
         shape, weights, cfg = load_bert_safetensors_dir(model_path)
         eng = engine_mod.BertEncoderEngine(shape, weights, mlm_split_operands=splade_split_operands, **kw)
@@ -141,20 +167,26 @@ class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
             raise ValueError("engine has no MLM head (EncoderEngine.set_mlm_head)")
 
     @classmethod
-    def from_directory(cls, model_path: str, device: int = 0, max_length: int = 512, **kw) -> "GpuSpladeProvider":
+    def from_directory(cls, model_path: str, device: int = 0, max_length: int = 512, operand_dtype: str = "f16", **kw) -> "GpuSpladeProvider":
         """`SpladeProvider(model_name, device)` (embedding_providers.py:120-133) for a checkpoint on disk."""
-        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length)
-        return cls(engine, tokenizer, max_length=max_length, **kw)
+        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length, operand_dtype=operand_dtype)
+        self = cls(engine, tokenizer, max_length=max_length, **kw)
+        if operand_dtype == "f16":
+            self._rebuild_bf16 = lambda: load_encoder_directory(model_path, device=device, max_seq_len=max_length, operand_dtype="bf16")[0]
+        return self
 
     def _rows(self, texts: Sequence[str]) -> np.ndarray:
         seqs = self._encode(texts)
         out = np.empty((len(seqs), self.engine.shape.vocab_size), np.float32)
         with self._lock:
             for a, b in self._batches(seqs):
-                self.engine.load_batch(seqs[a:b])
-                self.engine.run()
-                self.engine.run_splade()
-                out[a:b] = self.engine.read_splade()
+                while True:
+                    self.engine.load_batch(seqs[a:b])
+                    self.engine.run()
+                    self.engine.run_splade()
+                    out[a:b] = self.engine.read_splade()
+                    if not self._f16_clamped():
+                        break
         return out
 
     def _dicts(self, texts: Sequence[str], threshold: float) -> List[Dict[int, float]]:
@@ -164,21 +196,26 @@ class GpuSpladeProvider(_EncoderProvider, SparseEmbeddingProvider):
         out: List[Dict[int, float]] = []
         with self._lock:
             for a, b in self._batches(seqs):
-                self.engine.load_batch(seqs[a:b])
-                self.engine.run()
-                self.engine.run_splade()
-                try:
-                    counts, idx, val = self.engine.read_splade_sparse(threshold, self.sparse_cap)
-                    for i in range(b - a):
-                        n = int(counts[i])
-                        out.append(dict(zip(idx[i, :n].tolist(), val[i, :n].tolist())))
-                except VragError as exc:
-                    if exc.status != -3:   # VRAG_ERR_CAPACITY
-                        raise
-                    rows = self.engine.read_splade()
-                    for row in rows:
-                        nz = np.nonzero(row > threshold)[0]
-                        out.append({int(i): float(row[i]) for i in nz})
+                while True:
+                    self.engine.load_batch(seqs[a:b])
+                    self.engine.run()
+                    self.engine.run_splade()
+                    part: List[Dict[int, float]] = []
+                    try:
+                        counts, idx, val = self.engine.read_splade_sparse(threshold, self.sparse_cap)
+                        for i in range(b - a):
+                            n = int(counts[i])
+                            part.append(dict(zip(idx[i, :n].tolist(), val[i, :n].tolist())))
+                    except VragError as exc:
+                        if exc.status != -3:   # VRAG_ERR_CAPACITY
+                            raise
+                        rows = self.engine.read_splade()
+                        for row in rows:
+                            nz = np.nonzero(row > threshold)[0]
+                            part.append({int(i): float(row[i]) for i in nz})
+                    if not self._f16_clamped():
+                        break
+                out.extend(part)
         return out
 
     def embed_text(self, text: str) -> Dict[int, float]:
@@ -207,24 +244,30 @@ class GpuDenseProvider(_EncoderProvider, DenseEmbeddingProvider):
 
     @classmethod
     def from_directory(cls, model_path: str, device: int = 0, max_length: int = 512, pooling: Optional[str] = None,
-                       normalize: bool = True) -> "GpuDenseProvider":
+                       normalize: bool = True, operand_dtype: str = "f16") -> "GpuDenseProvider":
         """`SentenceTransformersProvider(model_name, device)` (embedding_providers.py:55-71) for a checkpoint on disk;
         the pooling mode comes from the checkpoint's `1_Pooling/config.json` unless given."""
-        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length)
-        return cls(engine, tokenizer, pooling=pooling or _st_pooling_mode(model_path), normalize=normalize, max_length=max_length)
+        engine, tokenizer, _cfg = load_encoder_directory(model_path, device=device, max_seq_len=max_length, operand_dtype=operand_dtype)
+        self = cls(engine, tokenizer, pooling=pooling or _st_pooling_mode(model_path), normalize=normalize, max_length=max_length)
+        if operand_dtype == "f16":
+            self._rebuild_bf16 = lambda: load_encoder_directory(model_path, device=device, max_seq_len=max_length, operand_dtype="bf16")[0]
+        return self
 
     def _rows(self, texts: Sequence[str]) -> np.ndarray:
         seqs = self._encode(texts)
         out = np.empty((len(seqs), self.engine.shape.hidden_size), np.float32)
         with self._lock:
             for a, b in self._batches(seqs):
-                self.engine.load_batch(seqs[a:b])
-                n = b - a
-                ends = [0] * n if self.pooling == "cls" else [len(s) - 1 for s in seqs[a:b]]
-                self.engine.load_ranges(list(range(n)), [0] * n, ends)
-                self.engine.run()
-                self.engine.run_pool(self.normalize)
-                out[a:b] = self.engine.read_pool()
+                while True:
+                    self.engine.load_batch(seqs[a:b])
+                    n = b - a
+                    ends = [0] * n if self.pooling == "cls" else [len(s) - 1 for s in seqs[a:b]]
+                    self.engine.load_ranges(list(range(n)), [0] * n, ends)
+                    self.engine.run()
+                    self.engine.run_pool(self.normalize)
+                    out[a:b] = self.engine.read_pool()
+                    if not self._f16_clamped():
+                        break
         return out
 
     def embed_text(self, text: str) -> List[float]:

@@ -220,9 +220,11 @@ __device__ __forceinline__ void residual_split_epilogue(const GemmParams& p, f32
 
 // Epilogue shared by the GEMM kernels. `acc[nj][rt]` are this wave's accumulators (swapped layout:
 // lane = token row, registers = 4 consecutive features; un-swapped for the V third of QKV).
-template <int EPI, int RT, int WROWS, typename T, bool SMALL = false>
+// XPREF (GeGLU, 256 x 256 throughput form): the epilogue stages through the UPPER half of the operand ring and calls `mid()`
+// between its arithmetic and its stores -- the kernel issues the NEXT tile's first operand stage into the lower half there.
+template <int EPI, int RT, int WROWS, typename T, bool SMALL = false, bool XPREF = false, typename Mid>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][RT], char* smem, int wave, int lane,
-                                              int mw, int nw, bool v_block) {
+                                              int mw, int nw, bool v_block, Mid&& mid) {
   typedef typename Op<T>::v4 V4;   // 4 operand-type values (8 bytes)
   // The lane index is re-read through an opaque asm: every per-lane address of the epilogue then depends on a value
   // defined inside the tile loop, so none of them is hoisted out of it to sit in (spilled) registers across the K loop.
@@ -455,7 +457,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     // instructions per output).
     const int NO = p.N >> 1;
     const int odd = wave & 1;                               // WN is even: wave parity == column parity of the pair
-    char* stgp = smem + (wave & ~1) * 16384;                // the pair's staging tile (16 KiB of the pair's 32)
+    char* stgp = XPREF ? smem + 65536 + (wave >> 1) * 16384  // the pair's staging tile: upper half of the ring (the lower takes the next tile's stage 0)
+                       : smem + (wave & ~1) * 16384;         // (16 KiB of the pair's 32)
     auto put_pair = [&](int row, int col, const V4& v) {    // col = output feature 0..31 of this wave
       const int c16 = odd * 4 + (col >> 3), half = (col >> 2) & 1;
       *reinterpret_cast<V4*>(stgp + row * 128 + ((c16 ^ (row & 7)) << 4) + (half << 3)) = v;
@@ -497,7 +500,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     };
     if (p.ln_mu) body(std::true_type{});
     else body(std::false_type{});
-    __syncthreads();   // the partner wave's half of every row is staged (workgroup-uniform path: every wave is here)
+    if constexpr (XPREF) {
+      mid();   // LDS-DMA of the next tile's first stage: must stay in flight across the barrier, so no __syncthreads (its fence drains vmcnt)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      __syncthreads();   // the partner wave's half of every row is staged (workgroup-uniform path: every wave is here)
+    }
     const int f0 = ((nw - odd * 64) >> 6) * 32;   // first output feature of the pair
 #pragma unroll
     for (int it = 0; it < WROWS / 16; ++it) {
@@ -848,6 +858,11 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
   const int tq = n_tiles >> 3, tr = n_tiles & 7;
   const int range_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const int range_len = xcd < tr ? tq + 1 : tq;
+  // Cross-tile prefetch (round 6, GeGLU throughput form): the epilogue needs half of the ring, so the next tile's first operand
+  // stage is issued from inside it and lands under its stores and the end-of-tile barrier instead of after them (a tile used to
+  // start with: wait for the store acknowledgements, THEN issue stage 0 and wait for its round trip).
+  constexpr bool XPREF = EPI == EPI_GEGLU && NS == 2 && HW == 0 && BM == 256 && BN == 256;
+  bool stage0_in_flight = false;   // workgroup-uniform
   for (int tix = slot; tix < range_len; tix += per_xcd_wgs) {
   const int b = range_lo + tix;
   const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
@@ -881,6 +896,12 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
     for (int i = 0; i < A_INSTR; ++i) glds16(Ab + soffA[i] + k0, sA + (wave * (RPI * A_INSTR) + i * RPI) * ROWB);
 #pragma unroll
     for (int i = 0; i < W_INSTR; ++i) glds16(Wb + soffW[i] + k0, sW + (wave * (RPI * W_INSTR) + i * RPI) * ROWB);
+  };
+  auto stage0_of = [&](const bf16_t* A_, const bf16_t* W_) {   // XPREF only: stage 0 of ANOTHER tile into slot 0
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) glds16(A_ + soffA[i], smem + (wave * (RPI * A_INSTR) + i * RPI) * ROWB);
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) glds16(W_ + soffW[i], smem + A_BYTES + (wave * (RPI * W_INSTR) + i * RPI) * ROWB);
   };
 
   f32x4 acc[4][RT];
@@ -997,9 +1018,22 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
     }
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
-      if (i < KT) stage(i, i);
-    wait_allow(min(NS - 1, KT) - 1);
-    step_barrier();
+      if (i < KT && !(XPREF && i == 0 && stage0_in_flight)) stage(i, i);
+    bool counted = false;
+    if constexpr (XPREF) counted = stage0_in_flight;
+    if (counted) {
+      // stage 0 was issued from inside the previous tile's epilogue, ahead of that epilogue's WROWS / 16 output stores (the only
+      // vector-memory operations behind it): a counted wait retires the DMA and leaves the stores in flight -- their
+      // acknowledgements are not on this tile's critical path (loads and stores retire in order on this counter: the compiler's
+      // own counted waits in the residual epilogue rely on the same)
+      static_assert(!XPREF || WROWS / 16 == 8, "the GeGLU epilogue's store count");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // raw: __syncthreads' fence would drain the stores after all
+      asm volatile("" ::: "memory");
+    } else {
+      wait_allow(min(NS - 1, KT) - 1);
+      step_barrier();
+    }
     int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
       const int nxt = kt + NS - 1, nbuf = buf == 0 ? NS - 1 : buf - 1;   // the slot read in step kt-1: every wave passed the barrier since
@@ -1014,9 +1048,24 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
   if (v_block) mainloop(std::false_type{});
   else mainloop(std::true_type{});
 
-  if (kg == 0) gemm_epilogue<EPI, RT, WROWS, T, (BM == 128 && BN == 128 && (NS == 4 || HW > 0))>(p, acc, smem, wave, lane, mw, nw, v_block);
+  auto prefetch_next = [&]() {
+    if constexpr (XPREF) {
+      const int ntix = tix + per_xcd_wgs;
+      stage0_in_flight = ntix < range_len;
+      if (stage0_in_flight) {
+        const int nb = range_lo + ntix;
+        stage0_of(p.A + (size_t)((nb / nbn) * BM) * K, p.W + (size_t)((nb % nbn) * BN) * K);
+      }
+    }
+  };
+  if (kg == 0) gemm_epilogue<EPI, RT, WROWS, T, (BM == 128 && BN == 128 && (NS == 4 || HW > 0)), XPREF>(p, acc, smem, wave, lane, mw, nw, v_block, prefetch_next);
   else if constexpr (EPI == EPI_GEGLU) __syncthreads();   // the GeGLU epilogue's pair-staging barrier is a workgroup barrier
-  __syncthreads();  // staging area is reused as operand slots by the next tile
+  if constexpr (XPREF) {   // the next tile's stage 0 is in flight: a raw barrier (the staging reads are in registers: the stores consumed them)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();  // staging area is reused as operand slots by the next tile
+  }
   }  // tile loop
 }
 

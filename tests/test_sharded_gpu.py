@@ -144,13 +144,9 @@ def _extract_worker(rank, world, port, q):
         results = [types.SimpleNamespace(text=t) for t in texts]
         question = fx["extract_e2e"]["runs"][0]["question"]
         out = {}
-        # A rank's share has fewer rows than the whole call, and the launch-bound GEMM configuration (K split over four waves)
-        # sums fp32 partial products in another order than the throughput tiles: a sentence within
-        # rounding of the threshold could flip between world sizes.  Span EQUALITY is therefore asserted with one
-        # configuration pinned for both calls (every tile then accumulates k in ascending order: bit-identical logits whatever
-        # the batch); across configurations logits agree to 16-bit-operand rounding (test_bert_gpu.py, test_extractor_gpu.py).
-        from verbatim_rag_amd import _lib
-        _lib.load().vrag_set_small_batch_rows(0)
+        # A rank's share has fewer rows than the whole call and may take another launch-bound GEMM configuration (K split over
+        # four waves / one-wave tiles): since round 6 these sum in ONE order (csrc/gemm_bf16.hip, KCH), so the logits -- and with
+        # them every threshold decision -- are bit-identical whatever the share (round 5 had to pin one configuration here).
         for n in (len(results), 5, 1):                       # 1 pair over 2 ranks: rank 1's shard is empty
             sharded = extract_spans_sharded(ext, question, results[:n], ShardComm(device=0))
             single = ext.extract_spans(question, results[:n])

@@ -818,8 +818,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // stages, a super-step holds KG landed K-steps, group g computes K-step KG j + g of super-step j, and the groups' partial tiles
 // meet in LDS in group order (group 0 adds groups 1, 2, ...) before group 0 runs the epilogue.  Every wave takes its share of the
 // DMA.  64 x 64 tiles: four single-wave groups on an eight-stage ring; 128 x 128 tiles: two groups of 2 x 2 waves on four stages.
-template <int EPI, int BM, int BN, int WM, int WN, int NS = 2, typename T = bf16_t, int HW = 0>
-__global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const GemmParams p) {
+// KCH (round 6; the launch-bound residual configurations WITHOUT a K-split): the K-steps are visited chain by chain -- first
+// k-steps 0, 4, 8, ..., then 1, 5, 9, ..., ... -- each chain accumulated from zero and the four chain sums added in chain order,
+// i.e. exactly the fp32 operations, in exactly the order, of the four-wave K-split (group g = chain g, group 0 adds 1, 2, 3).
+// A sequence's bits then no longer depend on which launch-bound configuration its batch happened to take (VERDICT r5 item 3:
+// a lone chunk took the K-split, the same chunk inside a few thousand rows the one-wave tiles, and the two summed in different
+// orders).  Costs one more accumulator set (the running sum): these forms take one wave per SIMD, so the registers are there.
+template <int EPI, int BM, int BN, int WM, int WN, int NS = 2, typename T = bf16_t, int HW = 0, bool KCH = false>
+__global__ __launch_bounds__((WM * WN + HW) * 64, KCH ? 1 : 2) void gemm_bf16_kernel(const GemmParams p) {
   typedef typename Op<T>::v8 V8;   // one MFMA operand fragment (8 operand-type values, 16 bytes)
   static_assert(BN == WN * 64, "a wave spans exactly 64 output features (one head / one GeGLU group)");
   static_assert(NS >= 2 && NS <= 8, "LDS stages");
@@ -1016,6 +1022,56 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, 2) void gemm_bf16_kernel(const
       __syncthreads();   // group 0's epilogue stages through the same bytes
       return;
     }
+    if constexpr (KCH) {
+      static_assert(HW == 0 && NS > 2, "chain order: the multi-stage launch-bound forms");
+      struct Cursor {   // visiting order of the K-steps: chain g = k-steps g, g + 4, ...
+        int g, kt;
+        __device__ __forceinline__ void next(int KT_) {
+          kt += 4;
+          while (kt >= KT_ && g < 4) {
+            ++g;
+            kt = g;
+          }
+        }
+      };
+      Cursor cs{0, 0}, cc{0, 0};
+      f32x4 sum[4][RT];
+      int issued = 0;
+#pragma unroll
+      for (int i = 0; i < NS - 1; ++i)
+        if (issued < KT) {
+          stage(cs.kt, i);
+          cs.next(KT);
+          ++issued;
+        }
+      wait_allow(min(NS - 1, KT) - 1);
+      step_barrier();
+      int buf = 0;
+      for (int i = 0; i < KT; ++i) {
+        const int nbuf = buf == 0 ? NS - 1 : buf - 1;
+        if (issued < KT) {
+          stage(cs.kt, nbuf);
+          cs.next(KT);
+          ++issued;
+        }
+        compute(buf);
+        const int g = cc.g;
+        cc.next(KT);
+        if (i + 1 == KT || cc.g != g) {   // chain g is complete (wave-uniform)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < RT; ++c) {
+              sum[a][c] = g == 0 ? acc[a][c] : sum[a][c] + acc[a][c];
+              acc[a][c] = i + 1 == KT ? sum[a][c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        wait_allow(max(0, min(NS - 2, KT - 2 - i)));
+        step_barrier();
+        buf = buf + 1 == NS ? 0 : buf + 1;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
       if (i < KT && !(XPREF && i == 0 && stage0_in_flight)) stage(i, i);
@@ -1076,19 +1132,19 @@ int gemm_small_m_threshold(int set_to) {
 }
 
 // One instantiation: dynamic-LDS attribute on first use, persistent grid of at most `grid_cap` workgroups.
-template <int EPI, int BM, int BN, int WM, int WN, int NS, typename T, int HW = 0>
+template <int EPI, int BM, int BN, int WM, int WN, int NS, typename T, int HW = 0, bool KCH = false>
 static hipError_t launch_cfg(GemmParams p, int grid_cap, hipStream_t stream) {
   constexpr int SMEM = NS * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T, HW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T, HW, KCH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr = true;
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   p.n_tiles = nbm * nbn;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T, HW>), dim3(std::min(nbm * nbn, grid_cap)), dim3((WM * WN + HW) * 64), SMEM,
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, NS, T, HW, KCH>), dim3(std::min(nbm * nbn, grid_cap)), dim3((WM * WN + HW) * 64), SMEM,
                      stream, p);
   return hipGetLastError();
 }
@@ -1107,8 +1163,9 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
         // at most one 64 x 64 tile per CU: four waves split K over an eight-stage ring (see the kernel): 12.4 -> 9.8 us at K = 768,
         // 15.6 -> 11.5 us at K = 1152, extract_spans(question, 5 chunks) 1.68 -> 1.59 ms (profiles/r04_small_gemm_probes.txt)
         if ((int64_t)((p.M + 63) / 64) * (p.N / 64) <= 256) return launch_cfg<EPI, 64, 64, 1, 1, 8, T, 3>(p, 1024, stream);
-        return launch_cfg<EPI, 64, 64, 1, 1, 4, T>(p, 1024, stream);
+        return launch_cfg<EPI, 64, 64, 1, 1, 4, T, 0, true>(p, 1024, stream);   // same summation order as the K-split (KCH)
       }
+      return launch_cfg<EPI, 128, 128, 2, 2, 4, T, 0, true>(p, 256, stream);    // ... and here: one order for every launch-bound residual GEMM
     }
     // (two K-groups of 2 x 2 waves for these 128 x 128 tiles measured SLOWER: extract_spans(question, 5 chunks) 1.71 vs 1.56 ms,
     //  profiles/r04_small_gemm_probes.txt -- eight waves per CU, a 64 KiB reduction and twice the barriers cost more than the

@@ -111,15 +111,15 @@ static void launch_cvt_split3(int op_dtype, hipStream_t st, const float* src, bf
 // with c = shift[r] (the row's previous mean; null = 0):  d = mean(h - c),  var = E[(h-c)^2] - d^2  -- no
 // cancellation however large |mean(h)| is --, mu_rel[r] = d (what the consumer GEMM's fold subtracts from its
 // bf16(h - c) operand), shift[r] <- c + d (the absolute mean: next shift, and the post-LN rebuild's mean).
-__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int np, int H, float eps, int rows,
+__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int ld, int np, int H, float eps, int rows,
                                          float* __restrict__ mu_rel, float* __restrict__ rstd, const float* shift_in,
                                          float* shift_out, float* __restrict__ shift_prev_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float s1 = 0.f, s2 = 0.f;
   for (int i = 0; i < np; ++i) {  // fixed order: deterministic
-    s1 += part[((size_t)r * np + i) * 2];
-    s2 += part[((size_t)r * np + i) * 2 + 1];
+    s1 += part[((size_t)i * ld + r) * 2];      // slice-major partials [np][ld rows][2]: coalesced over the rows of a wave
+    s2 += part[((size_t)i * ld + r) * 2 + 1];
   }
   const float d = s1 / (float)H;
   const float var = fmaxf(s2 / (float)H - d * d, 0.f);
@@ -610,14 +610,15 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         if (consumer_stats && !(for_qkv && fused_attn)) return VRAG_OK;
         ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
         hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st,
-                           e->st_part + (size_t)r0 * (H / 64) * 2, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
+                           e->st_part + (size_t)r0 * 2, e->cap_rows, H / 64, H, c.norm_eps, M, e->ln_mu + r0,
                            e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0, e->ln_shift_prev + r0);
         HIP_TRY(hipGetLastError());
         return VRAG_OK;
       };
       auto stats_for_consumer = [&](GemmParams& g) {
         if (!consumer_stats) return;
-        g.stats_in = e->st_part + (size_t)r0 * (H / 64) * 2;
+        g.stats_in = e->st_part + (size_t)r0 * 2;
+        g.stats_ld = e->cap_rows;
         g.ln_shift = e->ln_shift + r0;
         g.ln_shift_prev = e->ln_shift_prev + r0;
         g.fin_eps = c.norm_eps;
@@ -705,7 +706,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         const bool fold_here = fold && l > 0;
         if (fold_here) {
           g.resid_bf16 = e->a + (size_t)r0 * H;
-          g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+          g.stats_part = e->st_part + (size_t)r0 * 2;
+          g.stats_ld = e->cap_rows;
           g.ln_shift = e->ln_shift + r0;
           if (split) {   // layers >= 1: the stream arrives split (mlp Wo of the previous layer) and leaves split (this layer's mlp Wo reads it)
             g.lo_in = e->lo8 + (size_t)r0 * H;
@@ -755,7 +757,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         g.out_f32 = e->h + (size_t)r0 * H;
         if (fold && more_layers) {  // the next layer's attn_norm is folded into its QKV GEMM
           g.resid_bf16 = e->a + (size_t)r0 * H;
-          g.stats_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+          g.stats_part = e->st_part + (size_t)r0 * 2;
+          g.stats_ld = e->cap_rows;
           g.ln_shift = e->ln_shift + r0;
           if (split) g.lo_out = e->lo8 + (size_t)r0 * H;
         }
@@ -817,10 +820,10 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
                               e->types_loaded ? e->d_types + r0 : nullptr, e->op_dtype));
     }
     const bool fold = e->ln_fold;
-    float* st_part = e->st_part + (size_t)r0 * (H / 64) * 2;
+    float* st_part = e->st_part + (size_t)r0 * 2;
     auto finalize_stats = [&](bool first) -> int {
       ProfScope ps(e, VRAG_PROF_LAYERNORM, st);
-      hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, st_part, H / 64, H, c.norm_eps, M,
+      hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, st_part, e->cap_rows, H / 64, H, c.norm_eps, M,
                          e->ln_mu + r0, e->ln_rstd + r0, first ? (const float*)nullptr : e->ln_shift + r0, e->ln_shift + r0, (float*)nullptr);
       HIP_TRY(hipGetLastError());
       return VRAG_OK;
@@ -894,6 +897,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
         if (fold) {
           g.resid_bf16 = a;
           g.stats_part = st_part;   // no shift here: a post-LN stream is re-centred by every LayerNorm (mean = O(1) sigma)
+          g.stats_ld = e->cap_rows;
         }
         ProfScope ps(e, VRAG_PROF_GEMM_WO, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));
@@ -941,6 +945,7 @@ int run_layers_bert_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
           g.res_b = L.ln1_b;
           g.resid_bf16 = a;
           g.stats_part = st_part;
+          g.stats_ld = e->cap_rows;
         }
         ProfScope ps(e, VRAG_PROF_GEMM_WO_MLP, st);
         HIP_TRY(launch_gemm(EPI_RESIDUAL, g, st));

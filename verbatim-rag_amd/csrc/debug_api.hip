@@ -111,6 +111,7 @@ int vrag_debug_gemm_ms(int32_t epi, int32_t M, int32_t N, int32_t K, int32_t ite
   if (epi == EPI_RESIDUAL && !getenv("VRAG_DEBUG_GEMM_PLAIN_RESID")) {   // as the encoder launches it with the LayerNorm fold
     g.resid_bf16 = (bf16_t*)outb;
     g.stats_part = (float*)q;                                              // Mp * N/64 * 2 floats <= Mp * N * 2 bytes
+    g.stats_ld = (int)Mp;
     if (getenv("VRAG_DEBUG_GEMM_SPLIT")) {   // the split residual stream on both sides (layers >= 1 of the encoder schedule)
       g.lo_in = (const unsigned char*)kk;
       g.lo_out = (unsigned char*)kk;

@@ -53,7 +53,8 @@ struct GemmParams {
   const float* res_b;     // [N] LayerNorm bias
   const float* ln_shift;  // [Mpad] or null: per-row shift c subtracted before the bf16 copy / the statistics (see the epilogue)
   bf16_t* resid_bf16;     // [Mpad, N] or null  = bf16(updated residual - c)
-  float* stats_part;      // [Mpad, N/64, 2] or null
+  float* stats_part;      // [N/64][stats_ld][2] or null: slice-major, so that the rows a store instruction covers are contiguous
+  int stats_ld;           // rows per slice of stats_part / stats_in (the allocation's row count)
   // EPI_RESIDUAL, split residual stream (round 4; byte remainders since round 6): between two sub-layers the stream is kept as the
   // operand plane plus ONE byte per element, h = c + float(hi) * (1 + (byte - 128) * step): hi = op16(h - c) is `resid_bf16` -- the
   // very operand copy the next GEMM reads -- and the byte carries the next 8 bits of (h - c) / hi (16 significant bits together
@@ -69,7 +70,7 @@ struct GemmParams {
   // (EPI_QKV_ROPE / EPI_GEGLU / EPI_BF16) finishes the producer's partial statistics itself -- every wave for its own 64 rows,
   // before its epilogue reads them -- and the wave of column 0 advances ln_shift.  One launch fewer per sub-layer where a
   // launch costs as much as the kernel (a query's handful of chunks).
-  const float* stats_in;  // [Mpad, K/64, 2] or null (then ln_mu / ln_rstd were written by ln_stats_finalize_kernel)
+  const float* stats_in;  // [K/64][stats_ld][2] or null (then ln_mu / ln_rstd were written by ln_stats_finalize_kernel)
   float fin_eps;          // LayerNorm eps of that finalisation
   // EPI_TOPK (csrc/topk.hip, the tiled batched dense search): output column n is query n (topk_pairs: queries ride as
   // (bf16 value, bf16 remainder) column pairs 2q, 2q + 1 and the score is the pair's sum); row m is corpus row topk_row_base + m.

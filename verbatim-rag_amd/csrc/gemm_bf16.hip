@@ -177,7 +177,9 @@ __device__ __forceinline__ void residual_split_body(const GemmParams& p, f32x4 (
           s1 = row8_sum(s1);
           s2 = row8_sum(s2);
           if (l7 == 0) {
-            float* sp = p.stats_part + ((size_t)(mw + ps * 64 + rowp) * (p.N >> 6) + (nw >> 6)) * 2;
+            // slice-major: the 8 rows of an instruction are 64 contiguous bytes (row-major, 8 bytes in each of 8 lines: as many
+            // write requests per instruction as a whole high-plane store, for 1/16 of its bytes)
+            float* sp = p.stats_part + ((size_t)(nw >> 6) * p.stats_ld + (mw + ps * 64 + rowp)) * 2;
             sp[0] = s1;
             sp[1] = s2;
           }
@@ -246,11 +248,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     static_assert(WROWS == 64, "one row per lane");
     if (p.stats_in) {
       const int row = mw + lane, np = p.K >> 6;
-      const float* part = p.stats_in + (size_t)row * np * 2;
+      const float* part = p.stats_in + (size_t)row * 2;
       float s1 = 0.f, s2 = 0.f;
-      for (int i = 0; i < np; ++i) {
-        s1 += part[2 * i];
-        s2 += part[2 * i + 1];
+      for (int i = 0; i < np; ++i) {   // slice-major partials: [K / 64][stats_ld rows][2]
+        s1 += part[(size_t)i * p.stats_ld * 2];
+        s2 += part[(size_t)i * p.stats_ld * 2 + 1];
       }
       const float d = s1 / (float)p.K;
       const float var = fmaxf(s2 / (float)p.K - d * d, 0.f);
@@ -365,7 +367,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             s1 = row16_sum(s1);
             s2 = row16_sum(s2);
             if (c16 == 0) {
-              float* sp = p.stats_part + ((size_t)(mw + ps * 64 + row) * (p.N >> 6) + (nw >> 6)) * 2;
+              float* sp = p.stats_part + ((size_t)(nw >> 6) * p.stats_ld + (mw + ps * 64 + row)) * 2;
               sp[0] = s1;
               sp[1] = s2;
             }
@@ -876,23 +878,30 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, KCH ? 1 : 2) void gemm_bf16_ke
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 
   // LDS-DMA staging: instruction i of this wave fills tile rows wave*RPI*INSTR + i*RPI .. +RPI.
+  // Throughput residual form: the lane index is re-read through an opaque asm per tile, so the ten lane-dependent offsets below
+  // are recomputed per tile (a dozen instructions) instead of being hoisted out of the tile loop as invariants -- hoisted they
+  // are live across the epilogue, which has no register to spare, and were kept in scratch (round 6: 56-108 B -> see
+  // tests/test_kernel_resources.py).
+  int lane_t = lane;
+  if constexpr (EPI == EPI_RESIDUAL && BM == 256 && NS == 2) asm volatile("" : "+v"(lane_t));
   auto swz = [](int row) { return (row >> 1) & 7; };
   int soffA[A_INSTR], soffW[W_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    const int row = wave * (RPI * A_INSTR) + i * RPI + lane / CPR;
-    soffA[i] = row * K + (((lane % CPR) ^ swz(row)) << 3);
+    const int row = wave * (RPI * A_INSTR) + i * RPI + lane_t / CPR;
+    soffA[i] = row * K + (((lane_t % CPR) ^ swz(row)) << 3);
   }
 #pragma unroll
   for (int i = 0; i < W_INSTR; ++i) {
-    const int row = wave * (RPI * W_INSTR) + i * RPI + lane / CPR;
-    soffW[i] = row * K + (((lane % CPR) ^ swz(row)) << 3);
+    const int row = wave * (RPI * W_INSTR) + i * RPI + lane_t / CPR;
+    soffW[i] = row * K + (((lane_t % CPR) ^ swz(row)) << 3);
   }
   // fragment read offsets (bytes inside a 16-row sub-tile): lane = row l15, k-values 32 s + 8 q .. + 8
-  const int sw = swz(l15);
+  const int l15t = lane_t & 15, qt = lane_t >> 4;
+  const int sw = swz(l15t);
   int fo[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) fo[s] = l15 * ROWB + ((((4 * s + q) ^ sw)) << 4);
+  for (int s = 0; s < KS; ++s) fo[s] = l15t * ROWB + ((((4 * s + qt) ^ sw)) << 4);
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE_BYTES;

@@ -68,7 +68,7 @@ def sparse(n=1_000_000, vocab=30522, mean_nnz=128, k=5):
     sh = SparseShard(vocab, indptr, idx, val)
     st = sh.stats()
     out = []
-    qb = 8 if os.environ.get("VRAG_SPARSE_QB8") is not None or vocab * 2 + 16 * 4096 + 16 * 16 * k * 8 > 160 * 1024 else 16   # csrc/topk.hip sparse_multi_fits
+    qb = 8 if vocab * 2 + 16 * 4096 + 16 * 16 * k * 8 > 160 * 1024 else 16   # csrc/topk.hip sparse_multi_fits
     for nq in (1, 8, 16, 64, 1000):
         qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(nq)]
         sh.search(qs, k)

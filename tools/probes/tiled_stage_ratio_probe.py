@@ -1,4 +1,6 @@
-"""Stage growth of the tiled dense search (VRAG_TOPK_STAGE_RATIO) against the time of a batched search: fp32 rows with the prefilter
+"""[Historical probe: the VRAG_TOPK_STAGE_RATIO knob it drove was removed in round 6 once its sweep was recorded in
+profiles/r05_tiled_stage_ratio_probe.txt; re-add `ratio_env` in csrc/topk.hip dense_tiled_search to repeat it.]
+Stage growth of the tiled dense search (VRAG_TOPK_STAGE_RATIO) against the time of a batched search: fp32 rows with the prefilter
 image (64 candidates per query from the image) and bf16 rows (k = 10), 1.25 M x 768, through the public call.
   for r in 4 8 16; do VRAG_TOPK_STAGE_RATIO=$r python tools/probes/tiled_stage_ratio_probe.py; done"""
 import json

@@ -883,7 +883,7 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, KCH ? 1 : 2) void gemm_bf16_ke
   // are live across the epilogue, which has no register to spare, and were kept in scratch (round 6: 56-108 B -> see
   // tests/test_kernel_resources.py).
   int lane_t = lane;
-  if constexpr (EPI == EPI_RESIDUAL && BM == 256 && NS == 2) asm volatile("" : "+v"(lane_t));
+  if constexpr ((EPI == EPI_RESIDUAL || EPI == EPI_QKV_ROPE) && BM == 256 && NS == 2) asm volatile("" : "+v"(lane_t));
   auto swz = [](int row) { return (row >> 1) & 7; };
   int soffA[A_INSTR], soffW[W_INSTR];
 #pragma unroll

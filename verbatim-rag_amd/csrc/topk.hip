@@ -999,8 +999,7 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
       attrx = true;
     }
     const float* r32 = reinterpret_cast<const float*>(rows);
-    static const bool no_regq = getenv("VRAG_TOPK_EXACT_LDSQ") != nullptr;   // tuning: force the queries-in-LDS form
-    const bool regq = !no_regq && (dim == 768 || dim == 384);
+    const bool regq = dim == 768 || dim == 384;   // queries in registers; other dims keep them in LDS
     const size_t lds2 = (size_t)4 * X2SLOTS * 4096 + (size_t)256 * k * 8;
     if (regq) {
       static bool attrx2 = false;
@@ -2146,8 +2145,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   // Rows seen grow by `ratio` per stage, and a stage admits ~k (ratio - 1) candidates per query, each one an atomic append on its
   // query's counter: at k = 64 (the prefilter's candidate lists) a ratio of 16 made the appends, not the row stream, the cost of
   // every stage (960 per query and stage)
-  static const int ratio_env = getenv("VRAG_TOPK_STAGE_RATIO") ? atoi(getenv("VRAG_TOPK_STAGE_RATIO")) : 0;
-  const int ratio = ratio_env >= 2 ? ratio_env : (k > 16 ? TRATIO_WIDE : TRATIO);
+  const int ratio = k > 16 ? TRATIO_WIDE : TRATIO;   // (the sweep behind the two constants: profiles/r05_tiled_stage_ratio_probe.txt)
   long long lo = 0, hi = std::min<long long>(n, TSTAGE0);
   for (int stage = 0; lo < n; ++stage) {
     GemmParams g{};
@@ -2205,9 +2203,8 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   // Batched search over bf16 rows runs on the matrix cores with bf16 query operands: exact when every query element
   // is a bf16 number; otherwise the queries ride as (bf16 part, bf16 remainder) column pairs, 16 queries per pass.
   // Recorded for whatever kernel family serves these queries now or in a later run_resident with another (nq, k).
-  static const bool no_split = getenv("VRAG_TOPK_NO_SPLIT") != nullptr;
   ix->resident_split = 0;
-  if (!no_split && dtype == 0 && image != 2) {
+  if (dtype == 0 && image != 2) {
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(queries);
     const size_t n_el = (size_t)nq * ix->dim;
     for (size_t i = 0; i < n_el; ++i)
@@ -2819,8 +2816,7 @@ static bool sparse_multi_fits(int vocab, int qb, int k) {
   return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024;
 }
 static int sparse_pass_queries(int vocab, int k) {
-  const bool only8 = getenv("VRAG_SPARSE_QB8") != nullptr;   // A/B
-  return (!only8 && sparse_multi_fits(vocab, 16, k)) ? 16 : 8;
+  return sparse_multi_fits(vocab, 16, k) ? 16 : 8;   // (16 vs 8 queries per pass: profiles/r05_sparse_probes.txt)
 }
 
 static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, int* n_wg_out, const u64* bound = nullptr) {
@@ -2895,10 +2891,9 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
   if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k))) return rc;
   // Batched path: two or more queries; per pass of SQB queries the union of their terms gets ids 1 .. SUW-1, the
   // u16 map + weight tables + top-k lists must fit the LDS.
-  static const bool multi_off = getenv("VRAG_SPARSE_SINGLE") != nullptr;   // tuning / tests: force the single-query kernel
   const int vpad = (ix->vocab + 7) & ~7;
   const int QB = sparse_pass_queries(ix->vocab, k);
-  bool multi = !multi_off && nq >= 2 && ix->vocab <= 65535 && sparse_multi_fits(ix->vocab, QB, k);
+  bool multi = nq >= 2 && ix->vocab <= 65535 && sparse_multi_fits(ix->vocab, QB, k);
   for (int q = 0; q < nq; ++q)
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
       ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);

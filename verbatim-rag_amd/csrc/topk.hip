@@ -1101,7 +1101,7 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
 }
 
 // ------------------------------------------------------------------------------------ dense, tiled batched search
-// Q >= 64 queries over bf16 rows (SURVEY 8d "Dense top-k, Q-query batch": MFMA-bound once the batch is large, the shard's
+// Batches over bf16 rows (>= 33 queries, >= 17 when fp32 queries ride as column pairs, >= 3 on the prefilter image of an fp32 index) (SURVEY 8d "Dense top-k, Q-query batch": MFMA-bound once the batch is large, the shard's
 // bytes read ONCE per batch): the scores are a GEMM  rows [N, dim] x queries [Q, dim]^T  on the encoder's own kernel
 // (csrc/gemm_bf16.hip, 256 x 256 tiles) with the EPI_TOPK epilogue -- nothing is stored but the (score, row) keys above each
 // query's entry threshold, appended to a per-query candidate buffer.  The passes of 32 queries above re-stream the shard
@@ -1543,9 +1543,15 @@ __global__ void prefilter_combine_kernel(u64* __restrict__ pf, const u64* __rest
   if (flag[i / k]) pf[i] = exact[i];
 }
 
-static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size) {
+// Smallest batch that takes the tiled search (round 6; profiles/r06_dense_midbatch_probe.txt, 1.25 M x 768 rows):
+//  * the bf16 image of an fp32 index: 3 -- every batch the one-pass route (1-2 queries) does not take.  The 32-queries-per-pass
+//    exact scan costs 0.93-1.02 ms per pass (3-32 queries; 1.96-2.1 ms for 33-63), the image route 0.65-0.81 (0.88-0.95);
+//  * bf16 rows: one pass of the 32-query kernel is 0.44-0.49 ms, the tiled search 0.58 ms for up to 128 query columns -- so a
+//    batch that would need TWO passes (more than 32 queries, or more than 16 when fp32 queries ride as column pairs) is tiled.
+constexpr int kTiledMinImage = 3, kTiledMinBf16 = 33, kTiledMinBf16Pairs = 17;
+static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size, int min_nq = kTiledMinBf16) {
   static const bool off = getenv("VRAG_TOPK_NO_TILED") != nullptr;   // A/B against the 32-query passes
-  return !off && dtype == 0 && dim % 64 == 0 && nq >= 64 && k <= KMAX && size >= 4096;
+  return !off && dtype == 0 && dim % 64 == 0 && nq >= min_nq && k <= KMAX && size >= 4096;
 }
 
 // ------------------------------------------------------------------------------------ sparse
@@ -1980,7 +1986,7 @@ struct vrag_dense_index {
   size_t d_q_elems = 0;
   u64 *d_cand = nullptr, *d_out = nullptr, *d_bound = nullptr;   // d_bound: per-query page bound (k > KMAX)
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
-  // tiled batched search (nq >= 64 over bf16 rows): W operand of the score GEMM, candidate buffers, thresholds, flags
+  // tiled batched search (batches over bf16 rows: kTiledMin*): W operand of the score GEMM, candidate buffers, thresholds, flags
   bf16_t* d_tw = nullptr;
   u64 *d_tbuf = nullptr, *d_tthr = nullptr;
   float* d_tthrs = nullptr;
@@ -2012,9 +2018,9 @@ struct vrag_dense_index {
 // image with the tiled search, which wants dim % 64 == 0; other dims would rank it on the scalar 4-queries-per-pass kernel.
 // Both cases keep the plain fp32 search (same bits, the faster route there).
 static bool prefilter_route_ok(const vrag_dense_index* ix, int nq, int k) {
-  if (!ix->rows16 || k > 16 || ix->size < 4096 || !(nq <= 2 || nq >= 64)) return false;
+  if (!ix->rows16 || k > 16 || ix->size < 4096) return false;
   if (!dense_use_exact(1, ix->dim, k)) return false;                                     // the gated fallback scan exists in the exact kernels only
-  if (nq >= 64 && !dense_use_tiled(0, ix->dim, nq, PFK, (long long)ix->size)) return false;   // batches rank the image with the tiled search
+  if (nq > 2 && !dense_use_tiled(0, ix->dim, nq, PFK, (long long)ix->size, kTiledMinImage)) return false;   // batches rank the image with the tiled search
   return true;
 }
 
@@ -2145,7 +2151,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   // Rows seen grow by `ratio` per stage, and a stage admits ~k (ratio - 1) candidates per query, each one an atomic append on its
   // query's counter: at k = 64 (the prefilter's candidate lists) a ratio of 16 made the appends, not the row stream, the cost of
   // every stage (960 per query and stage)
-  const int ratio = k > 16 ? TRATIO_WIDE : TRATIO;   // (the sweep behind the two constants: profiles/r05_tiled_stage_ratio_probe.txt)
+  const int ratio = k > 16 ? TRATIO_WIDE : TRATIO;   // (the sweeps behind the two constants: profiles/r05_tiled_stage_ratio_probe.txt; small batches too: r06_dense_midbatch_probe.txt)
   long long lo = 0, hi = std::min<long long>(n, TSTAGE0);
   for (int stage = 0; lo < n; ++stage) {
     GemmParams g{};
@@ -2216,7 +2222,7 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   HIP_TRY(hipEventSynchronize(ix->upload_done));
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
-  } else if (dense_use_tiled(dtype, ix->dim, nq, k, (long long)ix->size)) {
+  } else if (dense_use_tiled(dtype, ix->dim, nq, k, (long long)ix->size, image ? kTiledMinImage : (ix->resident_split ? kTiledMinBf16Pairs : kTiledMinBf16))) {
     if ((rc = dense_tiled_search(ix, nq, k, st, image ? rows : nullptr))) return rc;
   } else {
     HIP_TRY(dense_launch_all(dtype, rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
@@ -2391,7 +2397,7 @@ int vrag_dense_index_add_device(vrag_dense_index* ix, const float* rows, int64_t
   return VRAG_OK;
 }
 
-// Batch route of the prefilter (nq >= 64), with `rescan` without a host decision: tiled search of the image with bf16-rounded queries -> 64
+// Batch route of the prefilter (nq >= 3), with `rescan` without a host decision: tiled search of the image with bf16-rounded queries -> 64
 // candidates per query -> sufficiency test + exact re-score; then the full scan behind the per-query flags (groups of 32 queries
 // without a flag leave at once) and a per-query pick.  Leaves the [nq, k] keys in ix->d_pf_out and the flags in ix->d_pf_flag.
 // Worst case (every query flagged: bunched scores) = the full scan plus the tiled pass.  The bound with rounded queries:
@@ -2623,7 +2629,7 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
   int rc;
   const long long n = (long long)nq * k;
   const u64* result = nullptr;
-  if (nq >= 64 && prefilter_route_ok(ix, nq, k)) {
+  if (nq > 2 && prefilter_route_ok(ix, nq, k)) {
     // fp32 rows with a prefilter image, batch route (prefilter_batch_enqueue): nothing returns to the host
     if ((rc = prefilter_batch_enqueue(ix, queries, nq, k, st))) return rc;
     result = ix->d_pf_out;
@@ -2674,7 +2680,7 @@ int vrag_dense_index_run_resident(vrag_dense_index* ix, int32_t nq, int32_t k, v
   ARG_CHECK(ix->d_q && ix->d_q_elems >= (size_t)nq * ix->dim && ix->size > 0, "call vrag_dense_index_search once first");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : ix->stream;
-  if (dense_use_tiled(ix->dtype, ix->dim, nq, k, (long long)ix->size)) {
+  if (dense_use_tiled(ix->dtype, ix->dim, nq, k, (long long)ix->size, ix->resident_split ? kTiledMinBf16Pairs : kTiledMinBf16)) {
     ARG_CHECK(ix->d_out_elems >= (size_t)nq * k, "scratch too small");
     return dense_tiled_search(ix, nq, k, st);
   }

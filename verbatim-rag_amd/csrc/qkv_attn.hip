@@ -194,8 +194,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     __builtin_amdgcn_sched_barrier(0);
     if (mm) {
       // Weight fragments are software-pipelined by hand (the read of block i + 1 sits in front of the four MFMAs of block i),
-      // and the 11 DMA instructions of the next stage are dealt out one per two blocks instead of in one burst after the barrier
-      // (measured inside the bench step: 392 vs 409 us per launch).
+      // and the 11 DMA instructions of the next stage are dealt out one per block behind the barrier, the shared weight rows first
+      // (round 3: dealt out instead of one burst, 392 vs 409 us per launch inside the bench step; round 6: one per block with the
+      // weight rows first instead of one per two blocks with the token rows first, 279.5 -> 274.7 us alone, step +0.5 %,
+      // profiles/r06_fused_dma_order_ab.txt -- a three-slot weight ring issued two stages ahead measured no better than that).
 #pragma unroll
       for (int it = 0; it < 24; ++it) {   // it = 12 s + nj
         const int s2 = it / 12, nj = it % 12;
@@ -208,10 +210,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
           else acc[nj][rt] = Op<T>::mfma16(xf[s2][rt], wa, acc[nj][rt]);          // v: lane = feature, registers = tokens
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more && (it & 1) == 0) {
-          const int slot = it >> 1;   // 0 .. 11
-          if (slot < 8) dma_x(kt + 1, slot);
-          else if (slot < 11) dma_w(kt + 1, (kt + 1) & 1, slot - 8);
+        if (more && it < 11) {   // one DMA instruction per block: the shared weight rows first, then this wave's token rows
+          if (it < 3) dma_w(kt + 1, (kt + 1) & 1, it);
+          else dma_x(kt + 1, it - 3);
         }
         __builtin_amdgcn_sched_barrier(0);
         wa = na;

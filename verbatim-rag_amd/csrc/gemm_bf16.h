@@ -81,7 +81,7 @@ struct GemmParams {
   const unsigned long long* topk_thr_key;
   unsigned* topk_cnt;               // [n queries] candidates appended so far (may exceed topk_cap: the overflow is detected by the selection kernel)
   unsigned long long* topk_buf;     // [n queries][topk_cap]
-  int topk_cap, topk_nq, topk_pairs, topk_direct, topk_tile;   // topk_tile: 1 = 256 x 128 tiles on a three-stage ring (few query columns)
+  int topk_cap, topk_nq, topk_pairs, topk_direct, topk_tile;   // topk_tile: 1 = 256 x 128 tiles on a three-stage ring (<= 128 query columns), 2 = 256 x 64 tiles on a four-stage ring (<= 64)
   unsigned topk_row_base;
   int op_dtype;           // kOpBf16 (0) or kOpF16 (1): what A, W and every 16-bit output hold (pointers stay typed bf16_t*)
   int n_tiles;            // filled by the launcher: output tiles walked by the persistent grid

@@ -1162,6 +1162,12 @@ template <int EPI, typename T>
 hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   // Small batches (a query's handful of chunks): few tiles, so the K loop's chain of memory round trips is the
   // whole kernel -- 128x128 tiles (4x the workgroups) with four LDS stages (three K-steps in flight), 1 workgroup per CU.
+  if constexpr (EPI == EPI_TOPK) {
+    // <= 64 query columns (round 6): 256 x 64 tiles on a FOUR-stage ring -- 96 KB of rows in flight per CU (all 160 KiB of LDS:
+    // the EPI_TOPK epilogue stages nothing), one wave per SIMD with the same 64 x 64 accumulators per wave.  N = 64 has no other
+    // tile, so the first (small) stages of a search take it too; the shard's allocation is padded past the last tile's rows.
+    if (p.topk_tile == 2) return launch_cfg<EPI, 256, 64, 4, 1, 4, T>(p, 256, stream);
+  }
   if (p.M <= gemm_small_m_threshold(-1) && EPI != EPI_NONE) {
     if constexpr (EPI == EPI_RESIDUAL) {
       // N = 768 at ~1 000 rows is 48 tiles of 128 x 128 on 256 CUs, and a K-step there is bound by what ONE CU's LDS-DMA
@@ -1210,7 +1216,7 @@ static hipError_t launch_typed(GemmEpi epi, const GemmParams& p, hipStream_t str
 
 hipError_t launch_gemm(GemmEpi epi, const GemmParams& p, hipStream_t stream) {
   if (p.M <= 0) return hipSuccess;
-  if (p.N % 128 != 0 || p.K % BK != 0) return hipErrorInvalidValue;
+  if ((p.N % 128 != 0 && !(epi == EPI_TOPK && p.topk_tile == 2 && p.N == 64)) || p.K % BK != 0) return hipErrorInvalidValue;
   if ((p.lo_in || p.lo_out) && (epi != EPI_RESIDUAL || p.bias || p.res_mu || !p.resid_bf16 || (p.lo_in && !p.ln_shift_prev) || (p.lo_out && !p.ln_shift)))
     return hipErrorInvalidValue;   // the split stream exists for the pre-LN schedule's plain residual add only
   return p.op_dtype == kOpF16 ? launch_typed<f16_t>(epi, p, stream) : launch_typed<bf16_t>(epi, p, stream);

@@ -2127,8 +2127,10 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   // up to 128 query columns: 256 x 128 tiles on a three-stage ring (64 KB of the row stream in flight per CU instead of 32: 0.63
   // instead of 0.81 ms for 64-128 queries over 1.25 M x 768 rows; from 256 columns on the 256 x 256 tiles win: 0.83 vs 0.91 ms,
   // 8.6 vs 10.4 ms at 4 096 -- tools/probes/tiled_topk_cfg_probe.py)
-  const int tile = n_cols <= 128 ? 1 : 0;
-  const int n_pad = tile == 1 ? 128 : (n_cols + 255) / 256 * 256;
+  // up to 64 columns (round 6): 256 x 64 tiles on a four-stage ring, 96 KB of rows in flight: 64 queries 0.566 -> 0.546 ms, 32 generic
+  // fp32 queries (column pairs) 0.512 -> 0.492 ms (profiles/r06_tiled_tile64_and_stage_plan_ab.txt)
+  const int tile = n_cols <= 64 ? 2 : (n_cols <= 128 ? 1 : 0);
+  const int n_pad = tile == 2 ? 64 : (tile == 1 ? 128 : (n_cols + 255) / 256 * 256);
   int rc;
   if ((rc = grow(&ix->d_tw, &ix->d_tw_elems, (size_t)n_pad * dim))) return rc;
   if ((rc = grow(&ix->d_tbuf, &ix->d_tbuf_elems, (size_t)nq * TCAP))) return rc;
@@ -2152,8 +2154,32 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   // query's counter: at k = 64 (the prefilter's candidate lists) a ratio of 16 made the appends, not the row stream, the cost of
   // every stage (960 per query and stage)
   const int ratio = k > 16 ? TRATIO_WIDE : TRATIO;   // (the sweeps behind the two constants: profiles/r05_tiled_stage_ratio_probe.txt; small batches too: r06_dense_midbatch_probe.txt)
-  long long lo = 0, hi = std::min<long long>(n, TSTAGE0);
-  for (int stage = 0; lo < n; ++stage) {
+  // Stage plan (round 6).  Boundaries grow by `ratio`; the last stage absorbs up to twice that (a launch and a selection fewer:
+  // it admits ~2 k ratio keys per query, far below the buffer), and then every stage of at least one tile ROUND -- 256 persistent
+  // workgroups x one 256-row tile each -- is cut to a whole number of rounds by moving its first row up, the remainder going to
+  // the stage before it (which is a fraction of a round anyway).  1.25 M rows used to run as 256 | 3 840 | 61 440 | 983 040 |
+  // 201 856 rows: the last launch needs 3.08 rounds and takes 4, and the one before it was followed by a selection it did not
+  // need -- 22 rounds; now 256 | 4 560 | 65 536 | 1 179 648: 18 whole rounds + three partial ones (64 queries 0.549 -> 0.526 ms,
+  // 256 queries 0.746 -> 0.719, 32 fp32-row queries 0.807 -> 0.788; profiles/r06_tiled_tile64_and_stage_plan_ab.txt).  The last
+  // stage is widened for batches up to 256 queries only: at 1 024 its extra appends cost what the launch saved (2.10 vs 2.125 ms).
+  std::vector<long long> b = {0, std::min<long long>(n, TSTAGE0)};
+  while (b.back() < n) {
+    long long hi = b.back() * ratio;
+    if (nq <= 256 && hi * 2 >= n) hi = n;
+    b.push_back(std::min<long long>(n, hi));
+  }
+  const int col_tiles = tile == 0 ? n_pad / 256 : 1;
+  if (256 % col_tiles == 0) {
+    const long long R = (long long)(256 / col_tiles) * 256;   // rows of one round of the persistent grid
+    for (size_t i = b.size() - 2; i >= 2; --i) {               // stage i = rows [b[i], b[i + 1])
+      const long long rows = b[i + 1] - b[i];
+      if (rows < R) continue;
+      const long long up = rows - rows / R * R;
+      if (up <= b[i] - b[i - 1]) b[i] += up;                   // the stage before it at most doubles
+    }
+  }
+  for (size_t stage = 0; stage + 1 < b.size(); ++stage) {
+    const long long lo = b[stage], hi = b[stage + 1];
     GemmParams g{};
     g.op_dtype = kOpBf16;
     g.A = reinterpret_cast<const bf16_t*>(rows_bf16) + (size_t)lo * dim;
@@ -2176,8 +2202,6 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
                        ix->d_tthr, ix->d_tthrs, last ? ix->d_out : (u64*)nullptr, ovf, stage == 0 ? (int)(hi - lo) : 0);
     HIP_TRY(hipGetLastError());
-    lo = hi;
-    hi = std::min<long long>(n, hi * ratio);
   }
   const size_t lds = (size_t)dim * sizeof(float) + (size_t)16 * k * sizeof(u64);
   hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n, dim,

@@ -86,7 +86,7 @@ def main():
         # the residual epilogue (almost) alone: one K-step of main loop in front of it -- what does the read-modify-write phase draw?
         ("resid epilogue-only (EPI_RESIDUAL, N=768 K=64)", "gemm", (3, M, H, 64), 2.0 * M * H * 64),
         ("resid plain epilogue-only (no fold outputs, N=768 K=64)", "gemm_plain", (3, M, H, 64), 2.0 * M * H * 64),
-        ("resid split epilogue-only (two 16-bit planes, N=768 K=64)", "gemm_split", (3, M, H, 64), 2.0 * M * H * 64),
+        ("resid split epilogue-only (operand plane + remainder byte, N=768 K=64)", "gemm_split", (3, M, H, 64), 2.0 * M * H * 64),
         ("gemm_wo split (EPI_RESIDUAL, N=768 K=768)", "gemm_split", (3, M, H, H), 2.0 * M * H * H),
         ("gemm_wo_mlp split (EPI_RESIDUAL, N=768 K=1152)", "gemm_split", (3, M, H, I), 2.0 * M * H * I),
         ("geglu epilogue-only (EPI_GEGLU, N=2304 K=64)", "gemm", (4, M, 2 * I, 64), 2.0 * M * 2 * I * 64),

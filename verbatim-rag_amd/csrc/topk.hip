@@ -1649,7 +1649,12 @@ constexpr int SUW = 1024;                   // weight-table stride: union ids 0 
 
 // NW = waves per workgroup (16; an 8-wave form with 256 registers and two 40-term load sets measured 10 % slower for 16 queries:
 // profiles/r05_sparse_probes.txt).
-template <int QB, int NW>
+// PAD (round 6): weight rows at a stride of QB + PAD floats.  PAD = 4 spreads the row starts over all sixteen 4-bank groups instead of
+// four (a row of 16 floats starts on bank 16 (uid % 4)): the ~8 active lanes of a 16-lane read group then collide 2 deep instead of
+// 3-4.  Round 5 measured this as "no gain" when the pass was still bound by its list maintenance and its unbalanced slices; with
+// those gone it is 8 % (1 000 queries 14.95 -> 13.70 ms, 16-query pass 0.264 -> 0.242 ms: profiles/r06_sparse_probes.txt).  Taken
+// for 16-query passes whenever the padded table still fits the LDS beside the term map and the lists.
+template <int QB, int NW, int PAD>
 __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsigned short* __restrict__ cols,
                                                                  const float* __restrict__ vals,
                                                                  const long long* __restrict__ slice_off,
@@ -1661,9 +1666,9 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vpad = (vocab + 7) & ~7;
   unsigned short* tmap = reinterpret_cast<unsigned short*>(smem);                 // [vpad]
-  constexpr int WS = QB;   // weight-row stride in floats (a stride of QB + 4 -- conflict-free row starts -- measured no gain for 16 queries and 20 % slower for 8)
+  constexpr int WS = QB + PAD;   // weight-row stride in floats
   float* tw = reinterpret_cast<float*>(smem + (size_t)vpad * 2);                  // [SUW][WS] (first n_union+1 rows used)
-  u64* lists = reinterpret_cast<u64*>(smem + (size_t)vpad * 2 + (size_t)QB * SUW * 4);   // [NW waves][QB][k]
+  u64* lists = reinterpret_cast<u64*>(smem + (size_t)vpad * 2 + (size_t)WS * SUW * 4);   // [NW waves][QB][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < vpad / 8; i += NW * 64)   // 16-byte copies
     reinterpret_cast<f32x4*>(tmap)[i] = reinterpret_cast<const f32x4*>(qmap)[i];
@@ -1683,8 +1688,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
     f32x2 acc2[QB / 2];
 #pragma unroll
     for (int q = 0; q < QB / 2; ++q) acc2[q] = f32x2{0.f, 0.f};
-    auto term = [&](unsigned t, float v1) {   // acc[q] = fma(v1, W[uid][q], acc[q]) for every query, two per v_pk_fma_f32
-      const unsigned uid = tmap[t];
+    auto term_uid = [&](unsigned uid, float v1) {   // acc[q] = fma(v1, W[uid][q], acc[q]) for every query, two per v_pk_fma_f32
       // Only the lanes whose term is in the pass's union (a few per cent) read weight rows: the other lanes would add
       // v * 0 -- exactly nothing.  The branch is per lane (exec mask); a wave with no hit skips.
       if (uid != 0u) {
@@ -1699,11 +1703,13 @@ __global__ __launch_bounds__(NW * 64) void sparse_topk_multi_kernel(const unsign
       }
     };
     auto consume = [&](const u32x2& cg, const f32x4& vg) {   // the document's term order; weight rows of two terms in flight
-      term(cg[0] & 0xFFFFu, vg[0]);
-      term(cg[0] >> 16, vg[1]);
+      // (the four map reads of a group issued together, ahead of the weight rows: measured equal -- the pass is bound by LDS
+      // throughput, not by the dependent round trips: profiles/r06_sparse_probes.txt)
+      term_uid(tmap[cg[0] & 0xFFFFu], vg[0]);
+      term_uid(tmap[cg[0] >> 16], vg[1]);
       if constexpr (QB > 8 && NW == 16) __builtin_amdgcn_sched_barrier(0);   // 128 registers: weight rows of two terms in flight at most
-      term(cg[1] & 0xFFFFu, vg[2]);
-      term(cg[1] >> 16, vg[3]);
+      term_uid(tmap[cg[1] & 0xFFFFu], vg[2]);
+      term_uid(tmap[cg[1] >> 16], vg[3]);
     };
     // Two register sets of G groups (4 G terms): the loads of step i + 1 are in flight while step i is consumed -- one 16-wave
     // workgroup per CU (the term map fills the LDS), so the bytes in flight per lane are what covers the memory latency.
@@ -2841,10 +2847,11 @@ static int sparse_slices_per_wg(const vrag_sparse_index* ix) {
 // vocabulary at k <= 32), else 8.  (Round 2 measured 16 slower -- 3.7 vs 2.0 ms for 64 queries: its accumulators and 32
 // single-term loads per step did not fit 128 registers.  Round 5: four terms per load pair, two queries per v_pk_fma_f32.)
 constexpr int SQB_MAX = 16;
-static bool sparse_multi_fits(int vocab, int qb, int k) {
+static size_t sparse_multi_lds(int vocab, int qb, int k, int pad) {
   const int vpad = (vocab + 7) & ~7;
-  return (size_t)vpad * 2 + (size_t)qb * SUW * 4 + (size_t)16 * qb * k * sizeof(u64) <= 160 * 1024;
+  return (size_t)vpad * 2 + (size_t)(qb + pad) * SUW * 4 + (size_t)16 * qb * k * sizeof(u64);
 }
+static bool sparse_multi_fits(int vocab, int qb, int k, int pad = 0) { return sparse_multi_lds(vocab, qb, k, pad) <= 160 * 1024; }
 static int sparse_pass_queries(int vocab, int k) {
   return sparse_multi_fits(vocab, 16, k) ? 16 : 8;   // (16 vs 8 queries per pass: profiles/r05_sparse_probes.txt)
 }
@@ -2858,24 +2865,27 @@ static int sparse_launch(vrag_sparse_index* ix, int nq, int k, hipStream_t st, i
     const int vpad = (ix->vocab + 7) & ~7;
     const int QB = ix->pass_qb;
     ARG_CHECK(sparse_multi_fits(ix->vocab, QB, k), "k = %d does not fit the batched pass the resident queries were prepared for", k);
-    const size_t lds = (size_t)vpad * 2 + (size_t)QB * SUW * 4 + (size_t)16 * QB * k * sizeof(u64);
+    const int pad = (QB == 16 && sparse_multi_fits(ix->vocab, QB, k, 4)) ? 4 : 0;   // the kernel's own LDS layout: the tables in HBM do not change
+    const size_t lds = sparse_multi_lds(ix->vocab, QB, k, pad);
     static bool attr_m = false;
     if (!attr_m) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<8, 16, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 16>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 16, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_topk_multi_kernel<16, 16, 4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_m = true;
     }
     for (int q0 = 0, ps = 0; q0 < nq; q0 += QB, ++ps) {
-      if (QB == 16)
-        hipLaunchKernelGGL((sparse_topk_multi_kernel<16, 16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
-      else
-        hipLaunchKernelGGL((sparse_topk_multi_kernel<8, 16>), dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off,
-                           ix->slice_len, ix->n_slices, (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad,
-                           ix->d_qw + (size_t)ps * QB * SUW, ix->vocab, ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(1024), lds, st, ix->cols, ix->vals, ix->slice_off, ix->slice_len, ix->n_slices,
+                           (long long)ix->n_docs, ix->d_qmap + (size_t)ps * vpad, ix->d_qw + (size_t)ps * QB * SUW, ix->vocab,
+                           ix->pass_union[ps], nq, q0, k, slices_per_wg, ix->d_cand, ix->d_docid);
+      };
+      if (QB == 16 && pad == 4) go(&sparse_topk_multi_kernel<16, 16, 4>);
+      else if (QB == 16) go(&sparse_topk_multi_kernel<16, 16, 0>);
+      else go(&sparse_topk_multi_kernel<8, 16, 0>);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));

@@ -245,14 +245,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     // (ln_stats_finalize_kernel's arithmetic, partials in the same fixed order -> the same bits).  Lane L takes row mw + L of
     // the wave's 64; the values go through ln_mu / ln_rstd in global memory (every wave that covers these rows writes the
     // same numbers) and are read back by this wave below: same CU, same L1, ordered by the vmcnt wait.
-    static_assert(WROWS == 64, "one row per lane");
+    static_assert(WROWS == 64 || WROWS == 32, "one row per lane (the first WROWS lanes)");
     if (p.stats_in) {
-      const int row = mw + lane, np = p.K >> 6;
+      const int row = mw + (WROWS == 64 ? lane : (lane & (WROWS - 1))), np = p.K >> 6;   // WROWS = 32: both halves of the wave take the same 32 rows (same values written twice)
       const float* part = p.stats_in + (size_t)row * 2;
       float s1 = 0.f, s2 = 0.f;
-      for (int i = 0; i < np; ++i) {   // slice-major partials: [K / 64][stats_ld rows][2]
-        s1 += part[(size_t)i * p.stats_ld * 2];
-        s2 += part[(size_t)i * p.stats_ld * 2 + 1];
+      // slice-major partials: [K / 64][stats_ld rows][2].  Sixteen slices are fetched per round trip and added in slice order (the
+      // finalize kernel's order: same bits).  The plain loop compiled to load -> s_waitcnt vmcnt(0) -> add per slice, twelve dependent
+      // round trips -- L2 hits, as it turned out: batching them moved the launch by 0.05-0.3 us (round 6).
+      for (int i0 = 0; i0 < np; i0 += 16) {
+        f32x2 pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[u] = *reinterpret_cast<const f32x2*>(part + (size_t)min(i0 + u, np - 1) * p.stats_ld * 2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (i0 + u < np) {
+            s1 += pv[u][0];
+            s2 += pv[u][1];
+          }
       }
       const float d = s1 / (float)p.K;
       const float var = fmaxf(s2 / (float)p.K - d * d, 0.f);
@@ -1185,6 +1195,13 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
     // (two K-groups of 2 x 2 waves for these 128 x 128 tiles measured SLOWER: extract_spans(question, 5 chunks) 1.71 vs 1.56 ms,
     //  profiles/r04_small_gemm_probes.txt -- eight waves per CU, a 64 KiB reduction and twice the barriers cost more than the
     //  halved K-step chain returns; the template keeps the general form)
+    // Round 6: EIGHT waves (4 x 2, 32 x 64 outputs each) on the same 128 x 128 tile and four-stage ring for the Wqkv / GeGLU / bf16-out
+    // GEMMs of a launch-bound batch: a K-step there is a chain -- barrier, fragment reads, 32 MFMAs -- on the one wave a SIMD holds;
+    // with two waves per SIMD one's fragment reads run under the other's MFMAs.  Worth less than the chain suggested: Wqkv 15.3 ->
+    // 15.1 us, GeGLU 14.1 -> 13.5 us per launch at ~1 000 rows, extract_spans(question, 5 chunks) 1.56 -> 1.52 ms
+    // (profiles/r06_latency_kernel_stats.txt); same accumulation order per output element, same bits.
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_GEGLU || EPI == EPI_BF16)
+      return launch_cfg<EPI, 128, 128, 4, 2, 4, T>(p, 256, stream);
     return launch_cfg<EPI, 128, 128, 2, 2, 4, T>(p, 256, stream);
   }
   if constexpr (EPI == EPI_TOPK) {

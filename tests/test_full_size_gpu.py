@@ -113,10 +113,11 @@ def test_configs3_dense_shard_1_25m_rows(dtype):
             assert np.array_equal(s, rs[:nq]), (dtype, nq)
             t0 = time.perf_counter()
             s2, i2 = sh.search(Q[:nq], k)
-            _note(f"dense_{dtype}_{nq}_queries_search_s", time.perf_counter() - t0)
+            dt = time.perf_counter() - t0          # the search alone: the note below is file I/O, the comparisons host work
+            _note(f"dense_{dtype}_{nq}_queries_search_s", dt)
             assert np.array_equal(i2, i) and np.array_equal(s2, s)
             if nq <= 256:
-                assert time.perf_counter() - t0 < 0.02, "a repeated <= 256-query search takes milliseconds"
+                assert dt < 0.02, "a repeated <= 256-query search takes milliseconds"
     finally:
         sh.close()
         del X

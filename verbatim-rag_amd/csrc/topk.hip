@@ -1401,6 +1401,91 @@ __global__ __launch_bounds__(256) void prefilter_collect_kernel(const bf16_t* __
   }
 }
 
+// Two to PFQ queries in ONE streaming pass (round 6; the route above ran once per query: two queries cost two passes, 0.70 ms, and
+// three or four went to the tiled search at 0.61-0.65 ms -- the size a handful of coalesced VerbatimRAG.query calls produces).
+// 32 lanes per row: a lane holds dim / 32 elements of EVERY query in registers (24 per query at dim 768) and fetches its 16-byte
+// pieces of a row at a 512-byte stride; a half-wave takes four rows per step (12 loads in flight per lane), 32 rows per workgroup
+// and step.  The image scores' summation order is free (the bound's accumulation term covers any order).  Same append as the
+// single-query kernel, one counter and one list per query.
+constexpr int PFQ = 4;   // queries the one-pass route takes together
+template <int DIMC32, int QN>   // dim / 256; queries compiled in (2 or 4; slots beyond nq never append)
+__global__ __launch_bounds__(256) void prefilter_collect_multi_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
+                                                                       const float* __restrict__ queries, int nq,
+                                                                       const u64* __restrict__ kth_key, const float* __restrict__ eps,
+                                                                       unsigned* __restrict__ cnt, unsigned* __restrict__ cand_rows,
+                                                                       int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);   // [QN][dim]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, hl = lane & 31;
+  for (int i = tid; i < QN * dim; i += 256) sq[i] = i < nq * dim ? queries[i] : 0.f;
+  __syncthreads();
+  float qreg[QN][DIMC32 * 8];
+#pragma unroll
+  for (int q = 0; q < QN; ++q)
+#pragma unroll
+    for (int i = 0; i < DIMC32; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qreg[q][i * 8 + j] = sq[q * dim + i * 256 + hl * 8 + j];
+  float tau[QN];
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+    tau[q] = INFINITY;   // an unused slot appends nothing
+    if (q < nq) {
+      const u64 kk = kth_key[q];
+      tau[q] = kk ? unorderable((unsigned)(kk >> 32)) - 2.f * eps[q] : -INFINITY;
+    }
+  }
+  constexpr int RPH = 4;   // rows per half-wave and step
+  const long long r_begin = (long long)blockIdx.x * rows_per_wg, r_end = min(n_rows, r_begin + rows_per_wg);
+  for (long long r0 = r_begin + wave * 2 + half; r0 < r_end; r0 += 8 * RPH) {
+    f32x4 raw[RPH][DIMC32];
+#pragma unroll
+    for (int rr = 0; rr < RPH; ++rr) {
+      const long long r = min(r0 + 8 * rr, r_end - 1);   // past the end: a row read again, never appended
+      const char* p = reinterpret_cast<const char*>(rows + (size_t)r * dim) + (size_t)hl * 16;
+#pragma unroll
+      for (int i = 0; i < DIMC32; ++i) raw[rr][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)i * 512));
+    }
+    float acc[QN][RPH];
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+#pragma unroll
+      for (int rr = 0; rr < RPH; ++rr) acc[q][rr] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RPH; ++rr)
+#pragma unroll
+      for (int i = 0; i < DIMC32; ++i) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, raw[rr][i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)a[j];
+#pragma unroll
+          for (int q = 0; q < QN; ++q) acc[q][rr] = fmaf(f, qreg[q][i * 8 + j], acc[q][rr]);
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < QN; ++q)
+#pragma unroll
+      for (int rr = 0; rr < RPH; ++rr) {
+        float v = row16_sum(acc[q][rr]);
+        acc[q][rr] = v + __shfl_xor(v, 16, 64);   // the other 16 lanes of this half-wave
+      }
+    if (hl == 0) {
+#pragma unroll
+      for (int rr = 0; rr < RPH; ++rr) {
+        const long long r = r0 + 8 * rr;
+        if (r >= r_end) continue;
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+          if (acc[q][rr] >= tau[q]) {
+            const unsigned slot = atomicAdd(cnt + q, 1u);
+            if (slot < (unsigned)PFCAP) cand_rows[(size_t)q * PFCAP + slot] = (unsigned)r;
+          }
+      }
+    }
+  }
+}
+
 // Entry threshold of the one-pass route in one launch: 128 prefix rows per workgroup, image scores as in the collect kernel, the
 // two best keys of every workgroup written out.  ANY t0 with at least k rows at a_r >= t0 is a valid threshold (the exact k-th
 // score of the shard is then >= t0 - eps), so the k-th largest of these keys -- the k-th over a SUBSET of the prefix rows -- serves
@@ -1411,11 +1496,15 @@ constexpr int PFBEST = 2;     // keys kept per workgroup
 template <int DIMC>
 __global__ __launch_bounds__(256) void prefilter_prefix_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
                                                                 const float* __restrict__ query, u64* __restrict__ best,
-                                                                unsigned* __restrict__ cnt, unsigned* __restrict__ flag) {
+                                                                unsigned* __restrict__ cnt, unsigned* __restrict__ flag, int best_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);
   u64* keys = reinterpret_cast<u64*>(smem + (size_t)dim * sizeof(float));   // [PFROWS]
   const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
+  query += (size_t)blockIdx.y * dim;   // blockIdx.y = query of a multi-query launch (round 6)
+  best += (size_t)blockIdx.y * best_stride;
+  cnt += blockIdx.y;
+  flag += blockIdx.y;
   if (blockIdx.x == 0 && tid == 0) {
     *cnt = 0u;
     *flag = 0u;
@@ -1496,6 +1585,10 @@ __global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsig
   __shared__ __attribute__((aligned(16))) float sq[RCH];
   __shared__ unsigned srid[16];
   const int tid = threadIdx.x, base = blockIdx.x * 16;
+  cand_rows += (size_t)blockIdx.y * PFCAP;   // blockIdx.y = query of a multi-query launch (round 6)
+  cnt += blockIdx.y;
+  query += (size_t)blockIdx.y * dim;
+  keys += (size_t)blockIdx.y * PFCAP;
   const unsigned n = min(*cnt, (unsigned)PFCAP);
   if ((unsigned)base >= n) {
     if (tid < 16) keys[base + tid] = 0ull;
@@ -2006,12 +2099,12 @@ struct vrag_dense_index {
   u64* d_pf_out = nullptr;         // [nq][k] exact keys of the rescored candidates
   unsigned* d_pf_flag = nullptr;   // [nq] 1 = the candidates do not provably contain the exact top-k
   size_t d_pf_eps_elems = 0, d_pf_out_elems = 0, d_pf_flag_elems = 0;
-  unsigned* d_pf_cand = nullptr;   // [2][PFCAP] candidate rows of the one-pass route (1-2 queries)
-  u64* d_pf_keys = nullptr;        // [2][PFCAP] their exact keys
-  unsigned* d_pf_cnt = nullptr;    // [2] candidate counters; [4..8): scratch counters / flags of the prefix selection
-  u64* d_pf_thr = nullptr;         // [0..4): final selection's threshold outputs (unused); [4..6): entry threshold keys; [6..8): their scores
+  unsigned* d_pf_cand = nullptr;   // [PFQ][PFCAP] candidate rows of the one-pass route (1 .. PFQ queries)
+  u64* d_pf_keys = nullptr;        // [PFQ][PFCAP] their exact keys
+  unsigned* d_pf_cnt = nullptr;    // [PFQ] candidate counters; [PFQ, 3 PFQ): scratch counters / flags of the prefix selection
+  u64* d_pf_thr = nullptr;         // [0, 2 PFQ): final selection's threshold outputs (unused); [2 PFQ, 3 PFQ): entry threshold keys; [3 PFQ, 4 PFQ): their scores
   long long pf_searches = 0, pf_fallbacks = 0;
-  char* h_pin = nullptr;           // pinned host staging of the one-pass route: [2][dim + 1] floats up, [2 k + 1] keys down
+  char* h_pin = nullptr;           // pinned host staging of the one-pass route: [PFQ][dim + 1] floats up, [PFQ k + 2] keys + flags down
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
   hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
@@ -2023,10 +2116,13 @@ struct vrag_dense_index {
 // (dim > 768, dim % 32 != 0, VRAG_TOPK_NO_EXACT) the scan would answer EVERY query again, image pass on top.  Batches rank the
 // image with the tiled search, which wants dim % 64 == 0; other dims would rank it on the scalar 4-queries-per-pass kernel.
 // Both cases keep the plain fp32 search (same bits, the faster route there).
+// Largest batch the one-pass route takes: PFQ queries in one streaming pass where the multi-query collect kernel exists
+// (dim % 256 == 0), else the single-query kernel once per query for one or two.
+static int pf_onepass_max(int dim) { return dim % 256 == 0 ? PFQ : 2; }
 static bool prefilter_route_ok(const vrag_dense_index* ix, int nq, int k) {
   if (!ix->rows16 || k > 16 || ix->size < 4096) return false;
   if (!dense_use_exact(1, ix->dim, k)) return false;                                     // the gated fallback scan exists in the exact kernels only
-  if (nq > 2 && !dense_use_tiled(0, ix->dim, nq, PFK, (long long)ix->size, kTiledMinImage)) return false;   // batches rank the image with the tiled search
+  if (nq > pf_onepass_max(ix->dim) && !dense_use_tiled(0, ix->dim, nq, PFK, (long long)ix->size, kTiledMinImage)) return false;   // batches rank the image with the tiled search
   return true;
 }
 
@@ -2293,7 +2389,7 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
     e = hipMalloc(&ix->rows16, ((size_t)capacity + 512) * dim * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norm2, 2 * sizeof(float));
     if (e == hipSuccess) e = hipMemset(ix->d_norm2, 0, 2 * sizeof(float));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->h_pin, (size_t)2 * (dim + 1) * sizeof(float) + (2 * KMAX + 1) * sizeof(u64), 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->h_pin, (size_t)PFQ * (dim + 1) * sizeof(float) + (PFQ * KMAX + 2) * sizeof(u64), 0);
   }
   ix->stage_rows = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)dim * 4));
   if (e == hipSuccess) {
@@ -2354,7 +2450,7 @@ static void dense_warm_query_path(vrag_dense_index* ix) {
   std::vector<float> sc((size_t)nq_max * k);
   std::vector<int64_t> id((size_t)nq_max * k);
   const long long s0 = ix->pf_searches, f0 = ix->pf_fallbacks;
-  for (int nq : {1, 2, 32, nq_max}) (void)vrag_dense_index_search(ix, q.data(), nq, k, sc.data(), id.data(), nullptr);
+  for (int nq : {1, 2, 4, 32, nq_max}) (void)vrag_dense_index_search(ix, q.data(), nq, k, sc.data(), id.data(), nullptr);
   std::lock_guard<std::mutex> lk(ix->mu);
   ix->pf_searches = s0;      // synthetic queries say nothing about how this index's data behaves under the prefilter
   ix->pf_fallbacks = f0;
@@ -2498,13 +2594,13 @@ static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const
   int rc;
   if (!ix->d_pf_cand) {
     size_t unused = 0;
-    if ((rc = grow(&ix->d_pf_cand, &unused, (size_t)2 * PFCAP))) return rc;
+    if ((rc = grow(&ix->d_pf_cand, &unused, (size_t)PFQ * PFCAP))) return rc;
     unused = 0;
-    if ((rc = grow(&ix->d_pf_keys, &unused, (size_t)2 * PFCAP))) return rc;
+    if ((rc = grow(&ix->d_pf_keys, &unused, (size_t)PFQ * PFCAP))) return rc;
     unused = 0;
-    if ((rc = grow(&ix->d_pf_cnt, &unused, (size_t)8))) return rc;
+    if ((rc = grow(&ix->d_pf_cnt, &unused, (size_t)4 * PFQ))) return rc;
     unused = 0;
-    if ((rc = grow(&ix->d_pf_thr, &unused, (size_t)8))) return rc;
+    if ((rc = grow(&ix->d_pf_thr, &unused, (size_t)4 * PFQ))) return rc;
   }
   const long long prefix = std::min<long long>(PFPREFIX, (long long)ix->size);
   const int n_wg0 = (int)((prefix + PFROWS - 1) / PFROWS);
@@ -2513,33 +2609,69 @@ static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const
   const int dimc = dim % 128 == 0 ? dim / 128 : 0;
   const bf16_t* img = reinterpret_cast<const bf16_t*>(ix->rows16);
   const size_t lds_q = (size_t)dim * sizeof(float);
-  for (int q = 0; q < nq; ++q) {
-    const float* q_dev = dq + (size_t)q * dim;
-    u64* qkeys = ix->d_pf_keys + (size_t)q * PFCAP;
-    unsigned* cand = ix->d_pf_cand + (size_t)q * PFCAP;
-    u64* kth = ix->d_pf_thr + 4 + q;
-#define VRAG_PF_PREFIX(DC_) hipLaunchKernelGGL((prefilter_prefix_kernel<DC_>), dim3(n_wg0), dim3(256), lds_q + PFROWS * sizeof(u64), st, img, prefix, \
-                                                dim, q_dev, qkeys, ix->d_pf_cnt + q, out_flags + q)
-    if (dimc == 6) VRAG_PF_PREFIX(6);
-    else if (dimc == 3) VRAG_PF_PREFIX(3);
-    else if (dimc == 8) VRAG_PF_PREFIX(8);
-    else VRAG_PF_PREFIX(0);
+  // per query q: candidate counter d_pf_cnt[q], the prefix selection's counter / overflow flag behind them, the entry threshold
+  // key d_pf_thr[2 PFQ + q] and its score (float) at d_pf_thr + 3 PFQ
+  unsigned* sel_cnt = ix->d_pf_cnt + PFQ;
+  unsigned* sel_ovf = ix->d_pf_cnt + 2 * PFQ;
+  u64* kth0 = ix->d_pf_thr + 2 * PFQ;
+  float* kth_score0 = reinterpret_cast<float*>(ix->d_pf_thr + 3 * PFQ);
+#define VRAG_PF_PREFIX(DC_, Q0_, NQ_) hipLaunchKernelGGL((prefilter_prefix_kernel<DC_>), dim3(n_wg0, NQ_), dim3(256), lds_q + PFROWS * sizeof(u64), st, img, \
+                                                         prefix, dim, dq + (size_t)(Q0_) * dim, ix->d_pf_keys + (size_t)(Q0_) * PFCAP, ix->d_pf_cnt + (Q0_),  \
+                                                         out_flags + (Q0_), PFCAP)
+  auto prefix_launch = [&](int q0, int n) {
+    if (dimc == 6) VRAG_PF_PREFIX(6, q0, n);
+    else if (dimc == 3) VRAG_PF_PREFIX(3, q0, n);
+    else if (dimc == 8) VRAG_PF_PREFIX(8, q0, n);
+    else VRAG_PF_PREFIX(0, q0, n);
+  };
 #undef VRAG_PF_PREFIX
-    hipLaunchKernelGGL(tiled_select_kernel, dim3(1), dim3(256), (size_t)PFCAP * sizeof(u64), st, qkeys, ix->d_pf_cnt + 4 + q, PFCAP, k, kth,
-                       reinterpret_cast<float*>(ix->d_pf_thr + 6) + q, (u64*)nullptr, ix->d_pf_cnt + 6 + q, n_wg0 * PFBEST);
-#define VRAG_PF_COLLECT(DC_) hipLaunchKernelGGL((prefilter_collect_kernel<DC_>), dim3(wgs), dim3(256), lds_q, st, img, (long long)ix->size, dim, q_dev, kth, \
-                                                 deps + q, ix->d_pf_cnt + q, cand, per)
-    if (dimc == 6) VRAG_PF_COLLECT(6);
-    else if (dimc == 3) VRAG_PF_COLLECT(3);
-    else if (dimc == 8) VRAG_PF_COLLECT(8);
-    else VRAG_PF_COLLECT(0);
-#undef VRAG_PF_COLLECT
-    hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 16), dim3(256), 0, st, cand, ix->d_pf_cnt + q,
-                       reinterpret_cast<const float*>(ix->rows), dim, q_dev, qkeys);
+  if (nq >= 2 && nq <= PFQ && dim % 256 == 0) {
+    // ONE streaming pass for the batch: five launches whatever nq (entry thresholds of all queries, their selection, the collect
+    // pass, the exact re-score of every list, the final selection)
+    prefix_launch(0, nq);
+    hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)PFCAP * sizeof(u64), st, ix->d_pf_keys, sel_cnt, PFCAP, k, kth0, kth_score0,
+                       (u64*)nullptr, sel_ovf, n_wg0 * PFBEST);
+    const size_t lds_m = (size_t)(nq <= 2 ? 2 : 4) * dim * sizeof(float);
+#define VRAG_PF_COLLECT_M(DC_, QN_) hipLaunchKernelGGL((prefilter_collect_multi_kernel<DC_, QN_>), dim3(wgs), dim3(256), lds_m, st, img, (long long)ix->size, dim, dq, \
+                                                       nq, kth0, deps, ix->d_pf_cnt, ix->d_pf_cand, per)
+    const int d32 = dim / 256;
+    if (nq <= 2) {
+      if (d32 == 3) VRAG_PF_COLLECT_M(3, 2);
+      else if (d32 == 2) VRAG_PF_COLLECT_M(2, 2);
+      else if (d32 == 1) VRAG_PF_COLLECT_M(1, 2);
+      else return VRAG_ERR_INVALID;   // prefilter_route_ok admits dim <= 768 only
+    } else {
+      if (d32 == 3) VRAG_PF_COLLECT_M(3, 4);
+      else if (d32 == 2) VRAG_PF_COLLECT_M(2, 4);
+      else if (d32 == 1) VRAG_PF_COLLECT_M(1, 4);
+      else return VRAG_ERR_INVALID;
+    }
+#undef VRAG_PF_COLLECT_M
+    hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 16, nq), dim3(256), 0, st, ix->d_pf_cand, ix->d_pf_cnt,
+                       reinterpret_cast<const float*>(ix->rows), dim, dq, ix->d_pf_keys);
     HIP_TRY(hipGetLastError());
+  } else {
+    for (int q = 0; q < nq; ++q) {
+      const float* q_dev = dq + (size_t)q * dim;
+      u64* qkeys = ix->d_pf_keys + (size_t)q * PFCAP;
+      unsigned* cand = ix->d_pf_cand + (size_t)q * PFCAP;
+      prefix_launch(q, 1);
+      hipLaunchKernelGGL(tiled_select_kernel, dim3(1), dim3(256), (size_t)PFCAP * sizeof(u64), st, qkeys, sel_cnt + q, PFCAP, k, kth0 + q,
+                         kth_score0 + q, (u64*)nullptr, sel_ovf + q, n_wg0 * PFBEST);
+#define VRAG_PF_COLLECT(DC_) hipLaunchKernelGGL((prefilter_collect_kernel<DC_>), dim3(wgs), dim3(256), lds_q, st, img, (long long)ix->size, dim, q_dev, kth0 + q, \
+                                                 deps + q, ix->d_pf_cnt + q, cand, per)
+      if (dimc == 6) VRAG_PF_COLLECT(6);
+      else if (dimc == 3) VRAG_PF_COLLECT(3);
+      else if (dimc == 8) VRAG_PF_COLLECT(8);
+      else VRAG_PF_COLLECT(0);
+#undef VRAG_PF_COLLECT
+      hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 16, 1), dim3(256), 0, st, cand, ix->d_pf_cnt + q,
+                         reinterpret_cast<const float*>(ix->rows), dim, q_dev, qkeys);
+      HIP_TRY(hipGetLastError());
+    }
   }
   hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)PFCAP * sizeof(u64), st, ix->d_pf_keys, ix->d_pf_cnt, PFCAP, k,
-                     ix->d_pf_thr, reinterpret_cast<float*>(ix->d_pf_thr + 2), out_keys, out_flags, 0);
+                     ix->d_pf_thr, reinterpret_cast<float*>(ix->d_pf_thr + PFQ), out_keys, out_flags, 0);
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }
@@ -2584,29 +2716,29 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
   const bool pf_live = prefilter_route_ok(ix, nq, k) && !(ix->pf_searches >= 32 && ix->pf_fallbacks * 4 > ix->pf_searches);
   if (pf_live) {
     std::vector<unsigned> flags((size_t)nq);
-    if (nq <= 2) {
-      // one streaming pass over the image per query (prefilter_single_enqueue); queries + bounds go up in one pinned copy, keys +
-      // flags come back in one
+    if (nq <= pf_onepass_max(ix->dim)) {
+      // one streaming pass over the image (per query, or -- two to PFQ queries, dim % 256 == 0 -- for all of them together:
+      // prefilter_single_enqueue); queries + bounds go up in one pinned copy, keys + flags come back in one
       const int dim = ix->dim;
-      float eps[2];
+      float eps[PFQ];
       for (int q = 0; q < nq; ++q) eps[q] = prefilter_eps(ix, queries + (size_t)q * dim, /*rounded_query=*/false);   // fp32 query against the image
       if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
-      if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
+      if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 2))) return rc;
       {   // the full scan's scratch too: vrag_dense_index_run_resident may follow on these resident queries
         const int n_wg = dense_n_wg(ix->dtype, dim, nq, k, ix->size);
         if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
         if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
       }
       float* up = reinterpret_cast<float*>(ix->h_pin);
-      u64* down = reinterpret_cast<u64*>(ix->h_pin + (size_t)2 * (dim + 1) * sizeof(float));
+      u64* down = reinterpret_cast<u64*>(ix->h_pin + (size_t)PFQ * (dim + 1) * sizeof(float));
       std::memcpy(up, queries, (size_t)nq * dim * sizeof(float));
       for (int q = 0; q < nq; ++q) up[(size_t)nq * dim + q] = eps[q];
       HIP_TRY(hipMemcpyAsync(ix->d_q, up, ((size_t)nq * dim + nq) * sizeof(float), hipMemcpyHostToDevice, st));
       ix->resident_split = 0;
-      u64* flag_word = ix->d_pf_out + (size_t)nq * k;   // [2] unsigned flags behind the keys
+      u64* flag_word = ix->d_pf_out + (size_t)nq * k;   // [PFQ] unsigned flags behind the keys (two words)
       if ((rc = prefilter_single_enqueue(ix, ix->d_q, ix->d_q + (size_t)nq * dim, nq, k, ix->d_pf_out, reinterpret_cast<unsigned*>(flag_word), st)))
         return rc;
-      HIP_TRY(hipMemcpyAsync(down, ix->d_pf_out, ((size_t)nq * k + 1) * sizeof(u64), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(down, ix->d_pf_out, ((size_t)nq * k + 2) * sizeof(u64), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       std::memcpy(keys.data(), down, keys.size() * sizeof(u64));
       std::memcpy(flags.data(), down + (size_t)nq * k, (size_t)nq * sizeof(unsigned));
@@ -2659,18 +2791,18 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
   int rc;
   const long long n = (long long)nq * k;
   const u64* result = nullptr;
-  if (nq > 2 && prefilter_route_ok(ix, nq, k)) {
+  if (nq > pf_onepass_max(ix->dim) && prefilter_route_ok(ix, nq, k)) {
     // fp32 rows with a prefilter image, batch route (prefilter_batch_enqueue): nothing returns to the host
     if ((rc = prefilter_batch_enqueue(ix, queries, nq, k, st))) return rc;
     result = ix->d_pf_out;
-  } else if (nq <= 2 && prefilter_route_ok(ix, nq, k)) {
-    // one or two queries: the one-pass route, then the full scan behind the overflow flags (its workgroups leave at once when no
+  } else if (nq <= pf_onepass_max(ix->dim) && prefilter_route_ok(ix, nq, k)) {
+    // one to PFQ queries: the one-pass route, then the full scan behind the overflow flags (its workgroups leave at once when no
     // flag is up) and the per-query pick -- as above, nothing returns to the host
     const int dim = ix->dim;
     if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));
     const int n_wg = dense_n_wg(ix->dtype, dim, nq, k, ix->size);
     if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
-    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 1))) return rc;
+    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 2))) return rc;
     if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
     if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
     float* up = reinterpret_cast<float*>(ix->h_pin);

@@ -104,7 +104,7 @@ def test_dense_f32_rows_are_bit_exact_on_arbitrary_data(prefilter):
         sh = DenseShard(dim, n, "f32", prefilter=prefilter)
         sh.add(X[: n // 3])
         sh.add(X[n // 3:])                     # appended in two calls
-        for nq in (1, 2, 3, 4, 5, 33, 70):     # 2-4 at dim 768: ONE image pass for the batch (prefilter_collect_multi_kernel, round 6)
+        for nq in (1, 2, 3, 4, 5, 8, 9, 33, 70):     # 2-4 at dim 768: ONE image pass for the batch (prefilter_collect_multi_kernel, round 6); 5 and up: tiled search of the image
             Q = rng.standard_normal((nq, dim)).astype(np.float32)
             Q[0] = X[3] * np.float32(1.7)      # query aligned with the duplicated row
             for k in (1, 10, 16):
@@ -534,7 +534,7 @@ def test_dense_f32_prefilter_falls_back_when_scores_bunch():
     Q[0] = base
     sh = DenseShard(dim, n, "f32")
     sh.add(X)
-    for qs in (Q[:1], Q[:2], Q[:3], Q[:4], Q):     # dim 256: two to four queries share one image pass; query 0 overflows its list there too
+    for qs in (Q[:1], Q[:2], Q[:3], Q[:4], Q[:7], Q[:8], Q):     # dim 256: two to four queries share one image pass (query 0 overflows its list there too); 7, 8: tiled
         s, i = sh.search(qs, 16)
         rs, ri = T.dense_topk(X, qs, 16)
         assert np.array_equal(i, ri) and np.array_equal(s, rs), len(qs)
@@ -632,7 +632,7 @@ def test_device_resident_search_of_fp32_rows_takes_the_prefilter_route_and_its_g
 
 
 def test_one_and_two_queries_over_fp32_rows_take_the_one_pass_route_host_and_device():
-    """1-2 queries over fp32 rows with the prefilter image (csrc/topk.hip prefilter_single_enqueue): entry threshold from the best
+    """1-8 queries (round 6: two to four share ONE pass where dim % 256 == 0; the name is round 5's) over fp32 rows with the prefilter image (csrc/topk.hip prefilter_single_enqueue): entry threshold from the best
     keys of the prefix workgroups, ONE pass over the image for the candidates, exact chains out of LDS, one selection.  Through the
     host call and through vrag_dense_index_search_device (gated full scan behind the overflow flag), on ordinary rows and on a
     shard with 5 000 copies of the best row -- more candidates than the list holds, so the full scan answers; ties by id."""
@@ -644,14 +644,14 @@ def test_one_and_two_queries_over_fp32_rows_take_the_one_pass_route_host_and_dev
     for n, dim in ((40_000, 768), (9_001, 224)):     # 224: no register-resident query form; % 32: the exact full scan
         for copies in (0, 5000):
             X = rng.standard_normal((n, dim)).astype(np.float32)
-            Q = rng.standard_normal((4, dim)).astype(np.float32)
+            Q = rng.standard_normal((8, dim)).astype(np.float32)
             if copies:
                 X[rng.choice(np.arange(10, n), size=copies, replace=False)] = X[7]
                 Q[0] = X[7]
                 Q[3] = X[7] * np.float32(0.5)
             sh = DenseShard(dim, n, "f32")
             sh.add(X)
-            for nq in (1, 2, 3, 4):          # dim 768: 2-4 queries in one pass (two of the four overflow their candidate lists when rows are copied)
+            for nq in (1, 2, 3, 4, 6, 8):    # dim 768: 2-4 queries in one pass (queries 0 and 3 overflow their candidate lists when rows are copied); 6, 8: tiled
                 for k in (1, 10, 16):
                     rs, ri = T.dense_topk(X, Q[:nq], k)
                     s, i = sh.search(Q[:nq], k)

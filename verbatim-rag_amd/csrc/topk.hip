@@ -1323,7 +1323,8 @@ __global__ __launch_bounds__(64) void prefilter_rescore_kernel(const u64* __rest
   if (lane >= n_live && lane < k) out[(size_t)q * k + lane] = 0ull;   // fewer rows than k
 }
 
-// One or two queries: ONE streaming pass over the image collects every row that can be in the exact top-k.  A prefix of the
+// One query (two to four: prefilter_collect_multi_kernel below, one pass for all of them): ONE streaming pass over the image collects
+// every row that can be in the exact top-k.  A prefix of the
 // shard is ranked first (exact top-k of the IMAGE scores over the first rows: t0 = its k-th score).  The exact k-th score over
 // the whole shard is at least the exact k-th over the prefix, which is at least t0 - eps; so a row of the exact top-k has
 // e_r >= t0 - eps, hence a_r >= t0 - 2 eps: the pass appends exactly the rows with a_r >= t0 - 2 eps to a candidate list (no
@@ -1407,7 +1408,7 @@ __global__ __launch_bounds__(256) void prefilter_collect_kernel(const bf16_t* __
 // pieces of a row at a 512-byte stride; a half-wave takes four rows per step (12 loads in flight per lane), 32 rows per workgroup
 // and step.  The image scores' summation order is free (the bound's accumulation term covers any order).  Same append as the
 // single-query kernel, one counter and one list per query.
-constexpr int PFQ = 4;   // queries the one-pass route takes together
+constexpr int PFQ = 4;   // queries the one-pass route takes together (eight in one pass -- 192 query registers, two rows per step -- measured 0.60-0.62 ms for 5-8 queries: what the tiled search takes; profiles/r06_onepass_multi_probe.txt)
 template <int DIMC32, int QN>   // dim / 256; queries compiled in (2 or 4; slots beyond nq never append)
 __global__ __launch_bounds__(256) void prefilter_collect_multi_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
                                                                        const float* __restrict__ queries, int nq,
@@ -2104,7 +2105,7 @@ struct vrag_dense_index {
   unsigned* d_pf_cnt = nullptr;    // [PFQ] candidate counters; [PFQ, 3 PFQ): scratch counters / flags of the prefix selection
   u64* d_pf_thr = nullptr;         // [0, 2 PFQ): final selection's threshold outputs (unused); [2 PFQ, 3 PFQ): entry threshold keys; [3 PFQ, 4 PFQ): their scores
   long long pf_searches = 0, pf_fallbacks = 0;
-  char* h_pin = nullptr;           // pinned host staging of the one-pass route: [PFQ][dim + 1] floats up, [PFQ k + 2] keys + flags down
+  char* h_pin = nullptr;           // pinned host staging of the one-pass route: [PFQ][dim + 1] floats up, [PFQ k + PFQ / 2] keys + flags down
   int resident_split = 0;   // the resident queries are not all bf16-exact: batched passes carry (hi, remainder) column pairs
   hipEvent_t upload_done = nullptr;   // recorded behind the query upload: the host buffer is free once it has passed
   hipEvent_t lists_done = nullptr;    // recorded behind a device-resident search: the next search (any stream) waits for it before reusing the scratch
@@ -2389,7 +2390,7 @@ int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_
     e = hipMalloc(&ix->rows16, ((size_t)capacity + 512) * dim * 2);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_norm2, 2 * sizeof(float));
     if (e == hipSuccess) e = hipMemset(ix->d_norm2, 0, 2 * sizeof(float));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->h_pin, (size_t)PFQ * (dim + 1) * sizeof(float) + (PFQ * KMAX + 2) * sizeof(u64), 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->h_pin, (size_t)PFQ * (dim + 1) * sizeof(float) + (PFQ * KMAX + PFQ / 2) * sizeof(u64), 0);
   }
   ix->stage_rows = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)dim * 4));
   if (e == hipSuccess) {
@@ -2723,7 +2724,7 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       float eps[PFQ];
       for (int q = 0; q < nq; ++q) eps[q] = prefilter_eps(ix, queries + (size_t)q * dim, /*rounded_query=*/false);   // fp32 query against the image
       if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
-      if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 2))) return rc;
+      if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + PFQ / 2))) return rc;
       {   // the full scan's scratch too: vrag_dense_index_run_resident may follow on these resident queries
         const int n_wg = dense_n_wg(ix->dtype, dim, nq, k, ix->size);
         if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
@@ -2735,10 +2736,10 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
       for (int q = 0; q < nq; ++q) up[(size_t)nq * dim + q] = eps[q];
       HIP_TRY(hipMemcpyAsync(ix->d_q, up, ((size_t)nq * dim + nq) * sizeof(float), hipMemcpyHostToDevice, st));
       ix->resident_split = 0;
-      u64* flag_word = ix->d_pf_out + (size_t)nq * k;   // [PFQ] unsigned flags behind the keys (two words)
+      u64* flag_word = ix->d_pf_out + (size_t)nq * k;   // [PFQ] unsigned flags behind the keys (PFQ / 2 words)
       if ((rc = prefilter_single_enqueue(ix, ix->d_q, ix->d_q + (size_t)nq * dim, nq, k, ix->d_pf_out, reinterpret_cast<unsigned*>(flag_word), st)))
         return rc;
-      HIP_TRY(hipMemcpyAsync(down, ix->d_pf_out, ((size_t)nq * k + 2) * sizeof(u64), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(down, ix->d_pf_out, ((size_t)nq * k + PFQ / 2) * sizeof(u64), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       std::memcpy(keys.data(), down, keys.size() * sizeof(u64));
       std::memcpy(flags.data(), down + (size_t)nq * k, (size_t)nq * sizeof(unsigned));
@@ -2802,7 +2803,7 @@ int vrag_dense_index_search_device(vrag_dense_index* ix, const float* queries, i
     if (ix->lists_done) HIP_TRY(hipStreamWaitEvent(st, ix->lists_done, 0));
     const int n_wg = dense_n_wg(ix->dtype, dim, nq, k, ix->size);
     if ((rc = grow(&ix->d_q, &ix->d_q_elems, (size_t)nq * dim + nq))) return rc;
-    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + 2))) return rc;
+    if ((rc = grow(&ix->d_pf_out, &ix->d_pf_out_elems, (size_t)nq * k + PFQ / 2))) return rc;
     if ((rc = grow(&ix->d_cand, &ix->d_cand_elems, (size_t)n_wg * nq * k))) return rc;
     if ((rc = grow(&ix->d_out, &ix->d_out_elems, (size_t)nq * k + nq))) return rc;
     float* up = reinterpret_cast<float*>(ix->h_pin);

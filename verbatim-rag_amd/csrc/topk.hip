@@ -1579,6 +1579,9 @@ __global__ __launch_bounds__(256) void prefilter_prefix_kernel(const bf16_t* __r
 // query through LDS, then 16 lanes run one chain each out of LDS (row stride 516 words: the 16 b128 reads of a step fall in
 // 16 different bank quartets).  One lane walking its 3 KB row alone took 24 us for a few hundred candidates; this form 8.
 constexpr int RCH = 512;   // columns staged per round
+// FROM_KEYS (round 6, the batch collect route): the candidates are the approximate KEYS the score GEMM's epilogue appended to
+// keys[] itself (row = the key's low word, complemented); the exact keys replace them in place.
+template <bool FROM_KEYS>
 __global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsigned* __restrict__ cand_rows, const unsigned* __restrict__ cnt,
                                                                        const float* __restrict__ rows, int dim,
                                                                        const float* __restrict__ query, u64* __restrict__ keys) {
@@ -1586,7 +1589,7 @@ __global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsig
   __shared__ __attribute__((aligned(16))) float sq[RCH];
   __shared__ unsigned srid[16];
   const int tid = threadIdx.x, base = blockIdx.x * 16;
-  cand_rows += (size_t)blockIdx.y * PFCAP;   // blockIdx.y = query of a multi-query launch (round 6)
+  if constexpr (!FROM_KEYS) cand_rows += (size_t)blockIdx.y * PFCAP;   // blockIdx.y = query of a multi-query launch (round 6)
   cnt += blockIdx.y;
   query += (size_t)blockIdx.y * dim;
   keys += (size_t)blockIdx.y * PFCAP;
@@ -1595,7 +1598,21 @@ __global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsig
     if (tid < 16) keys[base + tid] = 0ull;
     return;
   }
-  if (tid < 16) srid[tid] = cand_rows[(unsigned)(base + tid) < n ? base + tid : base];
+  if (tid < 16) {
+    const unsigned src = (unsigned)(base + tid) < n ? base + tid : base;
+    if constexpr (FROM_KEYS) {
+      const u64 ak = keys[src];   // 0 = a reserved slot whose key failed the epilogue's key test: row 0 is re-scored, the key dropped below
+      srid[tid] = ak ? 0xFFFFFFFFu - (unsigned)(ak & 0xFFFFFFFFu) : 0xFFFFFFFFu;
+    } else {
+      srid[tid] = cand_rows[src];
+    }
+  }
+  __syncthreads();
+  __shared__ unsigned dead[16];
+  if (tid < 16) {
+    dead[tid] = srid[tid] == 0xFFFFFFFFu ? 1u : 0u;
+    if (dead[tid]) srid[tid] = 0u;
+  }
   __syncthreads();
   float acc = 0.f;
   for (int c0 = 0; c0 < dim; c0 += RCH) {
@@ -1626,7 +1643,7 @@ __global__ __launch_bounds__(256) void prefilter_rescore_list_kernel(const unsig
     }
     __syncthreads();
   }
-  if (tid < 16) keys[base + tid] = (unsigned)(base + tid) < n ? make_key(acc, srid[tid]) : 0ull;
+  if (tid < 16) keys[base + tid] = ((unsigned)(base + tid) < n && !dead[tid]) ? make_key(acc, srid[tid]) : 0ull;
 }
 
 // Device-resident searches cannot fall back through the host: the gated full scan re-answers flagged queries into `exact`, and this
@@ -2092,6 +2109,8 @@ struct vrag_dense_index {
   float* d_tthrs = nullptr;
   unsigned* d_tcnt = nullptr;   // [nq] counters followed by [nq] overflow flags
   size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0;
+  u64* d_pfb = nullptr;            // [nq][PFCAP] candidate keys of the batch collect route (round 6: prefilter_batch_enqueue, <= 64 queries)
+  size_t d_pfb_elems = 0;
   // fp32 rows with a bf16 prefilter copy (dtype 2 at creation; `dtype` stays 1: the contract is the fp32 rows')
   void* rows16 = nullptr;          // bf16 image of `rows`
   float* d_norm2 = nullptr;        // device [2]: max squared row norm, max squared image error ||x~ - x||^2 (bits ordered as unsigned: both >= 0)
@@ -2222,8 +2241,32 @@ __global__ void tiled_init_kernel(int nq, u64* __restrict__ thr_key, float* __re
   cnt_ovf[nq + q] = 0u;
 }
 
+// Collect form of the tiled search (round 6; the prefilter image of an fp32 index, <= 64 queries): instead of ranking the image for
+// 64 candidates per query -- lists of 64 grow 4x per stage: seven stages, their appends and selections -- the staged search runs
+// over a PREFIX of the shard only, with lists of the caller's k (three sub-round stages), its k-th approximate score t1 becomes the
+// entry threshold of ONE pass over the whole shard that appends every row with a'_r >= t1 - 2 eps to the query's candidate list,
+// and the caller re-scores those exactly.  Why that is enough: k prefix rows have a' >= t1, hence exact scores >= t1 - eps, so
+// the exact k-th score of the shard is >= t1 - eps and every row of the exact top-k has a'_r >= e_r - eps >= t1 - 2 eps (eps: the
+// image + rounded-query bound of prefilter_eps).  An overflowing list (cnt > PFCAP) flags its query for the gated full scan.
+struct TiledCollect {
+  const float* eps;   // [nq] device
+  u64* keys;          // [nq][PFCAP] candidate keys out (approximate scores)
+  unsigned* flag;     // [nq] cleared here; raised by the caller's selection on overflow
+};
+constexpr long long TCOLLECT_PREFIX = 65536;   // one tile round of the persistent grid
+
+__global__ void tiled_tau_kernel(int nq, u64* __restrict__ thr_key, float* __restrict__ thr_score, const float* __restrict__ eps,
+                                 unsigned* __restrict__ cnt, unsigned* __restrict__ flag) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  thr_key[q] = 0ull;                              // the key test of the append passes every key
+  thr_score[q] = thr_score[q] - 2.f * eps[q];     // -inf (fewer than k prefix rows) stays -inf: everything is a candidate
+  cnt[q] = 0u;
+  flag[q] = 0u;
+}
+
 // The tiled batched search on the resident queries (ix->d_q, fp32): leaves the [nq, k] keys in ix->d_out.  Kernels only.
-int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, const void* rows_bf16 = nullptr) {
+int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, const void* rows_bf16 = nullptr, const TiledCollect* col = nullptr) {
   const int dim = ix->dim, pairs = ix->resident_split;
   if (!rows_bf16) rows_bf16 = ix->rows;
   const int n_cols = pairs ? 2 * nq : nq;
@@ -2246,11 +2289,12 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   HIP_TRY(hipGetLastError());
   // stage 0 writes slot = row: a NaN score leaves its slot untouched, so the slots start as "no key"
   HIP_TRY(hipMemset2DAsync(ix->d_tbuf, (size_t)TCAP * sizeof(u64), 0, (size_t)TSTAGE0 * sizeof(u64), (size_t)nq, st));
-  const long long n = (long long)ix->size;
+  const long long n_all = (long long)ix->size;
+  const long long n = col ? std::min<long long>(n_all, TCOLLECT_PREFIX) : n_all;   // collect form: the staged search covers a prefix only
   static bool attr = false;
   if (!attr) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tiled_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                TCAP * (int)sizeof(u64)));
+                                PFCAP * (int)sizeof(u64)));   // the largest buffer a selection sorts (PFCAP >= TCAP)
     attr = true;
   }
   // Rows seen grow by `ratio` per stage, and a stage admits ~k (ratio - 1) candidates per query, each one an atomic append on its
@@ -2303,11 +2347,33 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     HIP_TRY(launch_gemm(EPI_TOPK, g, st));
     const bool last = hi >= n;
     hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
-                       ix->d_tthr, ix->d_tthrs, last ? ix->d_out : (u64*)nullptr, ovf, stage == 0 ? (int)(hi - lo) : 0);
+                       ix->d_tthr, ix->d_tthrs, (last && !col) ? ix->d_out : (u64*)nullptr, ovf, stage == 0 ? (int)(hi - lo) : 0);
     HIP_TRY(hipGetLastError());
   }
+  if (col) {
+    hipLaunchKernelGGL(tiled_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nq, ix->d_tthr, ix->d_tthrs, col->eps, ix->d_tcnt, col->flag);
+    GemmParams g{};
+    g.op_dtype = kOpBf16;
+    g.A = reinterpret_cast<const bf16_t*>(rows_bf16);
+    g.W = ix->d_tw;
+    g.M = (int)n_all;
+    g.N = n_pad;
+    g.K = dim;
+    g.topk_thr_score = ix->d_tthrs;
+    g.topk_thr_key = ix->d_tthr;
+    g.topk_cnt = ix->d_tcnt;
+    g.topk_buf = col->keys;
+    g.topk_cap = PFCAP;
+    g.topk_nq = nq;
+    g.topk_pairs = pairs;
+    g.topk_direct = 0;
+    g.topk_row_base = 0u;
+    g.topk_tile = tile;
+    HIP_TRY(launch_gemm(EPI_TOPK, g, st));
+    return VRAG_OK;   // the caller re-scores and selects; overflow = its flag
+  }
   const size_t lds = (size_t)dim * sizeof(float) + (size_t)16 * k * sizeof(u64);
-  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n, dim,
+  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n_all, dim,
                      ix->d_q, k, ovf, ix->d_out);
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
@@ -2316,7 +2382,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
 // One device pass (k <= KMAX) of a dense search: uploads the queries, runs phase 1 + the per-query merge and leaves the
 // [nq, k] keys in ix->d_out.  Returns once the query upload has been consumed (the caller's buffer may be reused); the
 // kernels are only enqueued.  Caller holds ix->mu and has set the device.
-int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, int image = 0) {
+int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, int image = 0, const TiledCollect* col = nullptr) {
   // image: rank the bf16 prefilter image of an fp32 index instead of its rows (the approximate pass of the prefilter route);
   // 2 = with the queries rounded to bf16 instead of riding as (value, remainder) column pairs -- half the GEMM columns, the
   // rounding is part of the caller's error bound
@@ -2350,7 +2416,7 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
   } else if (dense_use_tiled(dtype, ix->dim, nq, k, (long long)ix->size, image ? kTiledMinImage : (ix->resident_split ? kTiledMinBf16Pairs : kTiledMinBf16))) {
-    if ((rc = dense_tiled_search(ix, nq, k, st, image ? rows : nullptr))) return rc;
+    if ((rc = dense_tiled_search(ix, nq, k, st, image ? rows : nullptr, col))) return rc;
   } else {
     HIP_TRY(dense_launch_all(dtype, rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
                              ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
@@ -2417,7 +2483,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
-  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, ix->rows16, (void*)ix->d_norm2,
+  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, (void*)ix->d_pfb, ix->rows16, (void*)ix->d_norm2,
                   (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag, (void*)ix->d_pf_cand, (void*)ix->d_pf_keys, (void*)ix->d_pf_cnt,
                   (void*)ix->d_pf_thr})
     if (p) (void)hipFree(p);
@@ -2551,6 +2617,7 @@ static float prefilter_eps(const vrag_dense_index* ix, const float* q, bool roun
 }
 
 static int prefilter_rescan_enqueue(vrag_dense_index* ix, int nq, int k, hipStream_t st);
+constexpr int kCollectMaxQueries = 64;
 static int prefilter_batch_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, bool rescan = true) {
   int rc;
   if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
@@ -2558,12 +2625,29 @@ static int prefilter_batch_enqueue(vrag_dense_index* ix, const float* queries, i
   if ((rc = grow(&ix->d_pf_flag, &ix->d_pf_flag_elems, (size_t)nq))) return rc;
   std::vector<float> eps((size_t)nq);
   for (int q = 0; q < nq; ++q) eps[q] = prefilter_eps(ix, queries + (size_t)q * ix->dim, /*rounded_query=*/true);
-  if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/2))) return rc;
-  HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipEventRecord(ix->upload_done, st));
-  hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
-                     ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
-  HIP_TRY(hipGetLastError());
+  if (nq <= kCollectMaxQueries) {
+    // up to 64 queries (one 64-column tile): the collect form of the tiled search (TiledCollect above) -- a staged search with lists
+    // of k over a 65 536-row prefix, ONE pass over the shard that appends every row within 2 eps of the prefix's k-th score,
+    // exact re-score of those lists, one selection (32 queries 0.79 -> 0.65 ms, 64: 0.94 -> 0.74; profiles/r06_collect_batch_probe.txt)
+    if ((rc = grow(&ix->d_pfb, &ix->d_pfb_elems, (size_t)nq * PFCAP))) return rc;
+    if (!ix->upload_done) HIP_TRY(hipEventCreateWithFlags(&ix->upload_done, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+    const TiledCollect col{ix->d_pf_eps, ix->d_pfb, ix->d_pf_flag};
+    if ((rc = dense_search_enqueue(ix, queries, nq, k, st, /*image=*/2, &col))) return rc;
+    HIP_TRY(hipEventRecord(ix->upload_done, st));
+    hipLaunchKernelGGL(prefilter_rescore_list_kernel<true>, dim3(PFCAP / 16, nq), dim3(256), 0, st, (const unsigned*)nullptr, ix->d_tcnt,
+                       reinterpret_cast<const float*>(ix->rows), ix->dim, ix->d_q, ix->d_pfb);
+    hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)PFCAP * sizeof(u64), st, ix->d_pfb, ix->d_tcnt, PFCAP, k, ix->d_tthr,
+                       ix->d_tthrs, ix->d_pf_out, ix->d_pf_flag, 0);
+    HIP_TRY(hipGetLastError());
+  } else {
+    if ((rc = dense_search_enqueue(ix, queries, nq, PFK, st, /*image=*/2))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_pf_eps, eps.data(), (size_t)nq * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ix->upload_done, st));
+    hipLaunchKernelGGL(prefilter_rescore_kernel, dim3(nq), dim3(64), 0, st, ix->d_out, reinterpret_cast<const float*>(ix->rows), ix->dim,
+                       ix->d_q, ix->d_pf_eps, k, PFK, ix->d_pf_out, ix->d_pf_flag);
+    HIP_TRY(hipGetLastError());
+  }
   if (rescan && (rc = prefilter_rescan_enqueue(ix, nq, k, st))) return rc;
   HIP_TRY(hipEventSynchronize(ix->upload_done));   // the eps upload has left the host vector
   return VRAG_OK;
@@ -2648,7 +2732,7 @@ static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const
       else return VRAG_ERR_INVALID;
     }
 #undef VRAG_PF_COLLECT_M
-    hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 16, nq), dim3(256), 0, st, ix->d_pf_cand, ix->d_pf_cnt,
+    hipLaunchKernelGGL(prefilter_rescore_list_kernel<false>, dim3(PFCAP / 16, nq), dim3(256), 0, st, ix->d_pf_cand, ix->d_pf_cnt,
                        reinterpret_cast<const float*>(ix->rows), dim, dq, ix->d_pf_keys);
     HIP_TRY(hipGetLastError());
   } else {
@@ -2666,7 +2750,7 @@ static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const
       else if (dimc == 8) VRAG_PF_COLLECT(8);
       else VRAG_PF_COLLECT(0);
 #undef VRAG_PF_COLLECT
-      hipLaunchKernelGGL(prefilter_rescore_list_kernel, dim3(PFCAP / 16, 1), dim3(256), 0, st, cand, ix->d_pf_cnt + q,
+      hipLaunchKernelGGL(prefilter_rescore_list_kernel<false>, dim3(PFCAP / 16, 1), dim3(256), 0, st, cand, ix->d_pf_cnt + q,
                          reinterpret_cast<const float*>(ix->rows), dim, q_dev, qkeys);
       HIP_TRY(hipGetLastError());
     }

@@ -104,7 +104,7 @@ def test_dense_f32_rows_are_bit_exact_on_arbitrary_data(prefilter):
         sh = DenseShard(dim, n, "f32", prefilter=prefilter)
         sh.add(X[: n // 3])
         sh.add(X[n // 3:])                     # appended in two calls
-        for nq in (1, 2, 3, 4, 5, 8, 9, 33, 70):     # 2-4 at dim 768: ONE image pass for the batch (prefilter_collect_multi_kernel, round 6); 5 and up: tiled search of the image
+        for nq in (1, 2, 3, 4, 5, 8, 9, 33, 70, 300):     # 2-4 at dim 768: ONE image pass for the batch (prefilter_collect_multi_kernel, round 6); 5-256: collect form of the tiled search over the image; 300: its 64-candidate form
             Q = rng.standard_normal((nq, dim)).astype(np.float32)
             Q[0] = X[3] * np.float32(1.7)      # query aligned with the duplicated row
             for k in (1, 10, 16):

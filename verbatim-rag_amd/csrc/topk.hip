@@ -2617,7 +2617,7 @@ static float prefilter_eps(const vrag_dense_index* ix, const float* q, bool roun
 }
 
 static int prefilter_rescan_enqueue(vrag_dense_index* ix, int nq, int k, hipStream_t st);
-constexpr int kCollectMaxQueries = 64;
+constexpr int kCollectMaxQueries = 256;   // 128 / 256 queries 0.99 / 1.33 -> 0.87 / 1.20 ms; 512 and 1 024 equal to the 64-candidate route (the exact chains grow with the lists): profiles/r06_collect_batch_probe.txt
 static int prefilter_batch_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, bool rescan = true) {
   int rc;
   if ((rc = grow(&ix->d_pf_eps, &ix->d_pf_eps_elems, (size_t)nq))) return rc;
@@ -2626,7 +2626,7 @@ static int prefilter_batch_enqueue(vrag_dense_index* ix, const float* queries, i
   std::vector<float> eps((size_t)nq);
   for (int q = 0; q < nq; ++q) eps[q] = prefilter_eps(ix, queries + (size_t)q * ix->dim, /*rounded_query=*/true);
   if (nq <= kCollectMaxQueries) {
-    // up to 64 queries (one 64-column tile): the collect form of the tiled search (TiledCollect above) -- a staged search with lists
+    // up to kCollectMaxQueries queries: the collect form of the tiled search (TiledCollect above) -- a staged search with lists
     // of k over a 65 536-row prefix, ONE pass over the shard that appends every row within 2 eps of the prefix's k-th score,
     // exact re-score of those lists, one selection (32 queries 0.79 -> 0.65 ms, 64: 0.94 -> 0.74; profiles/r06_collect_batch_probe.txt)
     if ((rc = grow(&ix->d_pfb, &ix->d_pfb_elems, (size_t)nq * PFCAP))) return rc;

@@ -45,7 +45,7 @@ for nq in (1, 2, 4, 32, 256):
     dt_api = timed(lambda: sh.search(q, k))
     print(json.dumps({"kind": "dense_f32_search_call", "prefilter_image": True, "rows": n, "dim": dim, "nq": nq, "k": k,
                       "ms": dt_api * 1e3, "queries_per_s": nq / dt_api,
-                      "route": "bf16 image, one pass for the batch: prefix thresholds -> candidates -> exact re-score" if nq <= 4 else "bf16 image, tiled search -> 64 candidates -> exact re-score",   # round 6: one to four queries share a pass (dim % 256 == 0), larger batches are tiled (csrc/topk.hip pf_onepass_max)
+                      "route": "bf16 image, one pass for the batch: prefix thresholds -> candidates -> exact re-score" if nq <= 4 else ("bf16 image, tiled search in collect form: prefix thresholds -> one appending pass -> exact re-score" if nq <= 256 else "bf16 image, tiled search -> 64 candidates -> exact re-score"),   # round 6: one to four queries share a pass (dim % 256 == 0), larger batches are tiled (csrc/topk.hip pf_onepass_max)
                       "image_bytes": n * dim * 2}))
 # the device-resident search a rank of the sharded store runs per batch (lists left in HBM, no host round trip): prefilter route with
 # the full scan behind the per-query flags

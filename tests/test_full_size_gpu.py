@@ -359,7 +359,7 @@ def test_configs4_one_gpu_slice_composed_1_25m_hybrid_rows_large_extractor_1024_
     store = GpuVectorStore(dense_dim=DIM, sparse_vocab=VOCAB)
     store.add_vectors([f"c{i}" for i in range(n)], X, (ip, ix, vv), texts, texts,
                       [{"title": f"Doc {i >> 6}", "source": f"s{i >> 6}.md", "document_id": f"d{i >> 6}"} for i in range(n)])
-    del X, ip, ix, vv
+    del X
     gc.collect()
     _note("composed_store_build_1_25m_s", time.perf_counter() - t0)
     Q = S.dense_rows(nq, DIM, seed=53)
@@ -407,9 +407,27 @@ def test_configs4_one_gpu_slice_composed_1_25m_hybrid_rows_large_extractor_1024_
         _note("composed_1024_queries_query_batch_s", t_batch)
         _note("composed_queries_per_s", nq / t_batch)
         assert len(got) == nq and all(1 <= len(r.documents) <= 5 for r in got)
+        # the retrieval both arms below share, against the CPU oracle (it was checked elsewhere only): the hybrid
+        # call the pipeline makes -- exact dense top-10 over the unit rows the index holds, exact sparse top-10, RRF -- for the sample
+        sample = list(range(0, nq, max(1, nq // n_sample)))[:n_sample]
+        qp_s, qi_s, qv_s = [0], [], []
+        for i in sample:
+            qi_s += list(dq[i].keys())
+            qv_s += list(dq[i].values())
+            qp_s.append(len(qi_s))
+        rs_d, ri_d = T.dense_topk(store._dense_rows.data, store._unit_queries(Q[sample]), 10, blocked=True)
+        rs_s, ri_s = T.sparse_topk(ip, ix, vv, VOCAB, np.asarray(qp_s, np.int64), np.asarray(qi_s, np.int32), np.asarray(qv_s, np.float32), 10,
+                                   blocked=True)
+        hyb_rows, hyb_dist = _rrf_expect(ri_d, ri_s, 5)
+        hits = store.query_batch(dense_queries=Q[sample], sparse_queries=[dq[i] for i in sample], search_type="hybrid", top_k=5)
+        for j in range(len(sample)):
+            want = [int(r) for r in hyb_rows[j] if r >= 0]
+            assert [h.id for h in hits[j]] == [f"c{r}" for r in want], sample[j]
+            assert [h.score for h in hits[j]] == [float(v) for v, r in zip(hyb_dist[j], hyb_rows[j]) if r >= 0], sample[j]
+            assert [h.text for h in hits[j]] == [texts[r] for r in want]
+        del ip, ix, vv
         # oracle pass over the sample: probabilities first, then a threshold in the widest gap (the comparison is about
         # arithmetic within 1e-3, not about a sentence that happens to sit on the threshold)
-        sample = list(range(0, nq, max(1, nq // n_sample)))[:n_sample]
         oracle_pipe = StaticVerbatimPipeline(index, OracleExtractor(), k=5)
         t0 = time.perf_counter()
         for i in sample:

@@ -409,7 +409,27 @@ def e2e_text_leg(shape, weights, qa_w, qa_b, device: int, n_docs: int = 1_000_00
         torch.cuda.synchronize()
         total_s = time.perf_counter() - a
         n_pairs = int((ids >= 0).sum())
-        out = {"e2e_queries_per_s": n_queries / total_s, "total_s": total_s, "embed_s": t["embed_s"], "search_s": t["search_s"],
+        # the same chain for ONE question at a time (the reference's VerbatimRAG.query: core.py:237-277), host-inclusive
+        def run_one(qtext):
+            a0 = time.perf_counter()
+            d = prov.embed_queries([qtext])[0]
+            q1 = {}
+            for term, w_ in d.items():
+                z = int(zipf_map[term])
+                q1[z] = max(q1.get(z, 0.0), w_)
+            a1 = time.perf_counter()
+            _s1, ids1 = shard.search([q1 or {0: 1.0}], k)
+            a2 = time.perf_counter()
+            res1 = [types.SimpleNamespace(text=pool[int(i) % len(pool)]) for i in ids1[0] if i >= 0]
+            ext.extract_spans(qtext, res1)
+            a3 = time.perf_counter()
+            return a1 - a0, a2 - a1, a3 - a2
+        for qtext in questions[:8]:
+            run_one(qtext)
+        singles = np.asarray([run_one(qtext) for qtext in questions[8:72]])
+        single = {"ms_per_query_median": float(np.median(singles.sum(axis=1)) * 1e3), "embed_ms": float(np.median(singles[:, 0]) * 1e3),
+                  "search_ms": float(np.median(singles[:, 1]) * 1e3), "extract_ms": float(np.median(singles[:, 2]) * 1e3), "queries": len(singles)}
+        out = {"e2e_queries_per_s": n_queries / total_s, "single_query": single, "total_s": total_s, "embed_s": t["embed_s"], "search_s": t["search_s"],
                "extract_s": t["extract_s"], "pairs": n_pairs, "index_build_s": t_index,
                "mean_query_terms": float(np.mean([len(q) for q in queries])),
                "spans_returned": int(sum(len(v) for d in spans for v in d.values())),

@@ -73,7 +73,7 @@ def sparse(n=1_000_000, vocab=30522, mean_nnz=128, k=5):
         qs = [{int(t): float(v) for t, v in zip(rng.choice(vocab, 32, p=p), rng.integers(1, 193, 32) / 64.0)} for _ in range(nq)]
         sh.search(qs, k)
         dt = timeit(lambda: sh.run_resident(nq, k), 5)
-        per_pass = 1 if nq == 1 else qb   # sparse_topk_kernel / sparse_topk_multi_kernel<8 | 16> (csrc/topk.hip sparse_pass_queries)
+        per_pass = 1 if nq == 1 else (8 if nq <= 8 else qb)   # sparse_topk_kernel / sparse_topk_multi_kernel<8 | 16> (csrc/topk.hip sparse_pass_queries; up to eight queries take the 8-query pass)
         passes = (nq + per_pass - 1) // per_pass
         pass_bytes = st["padded_nnz"] * 6 + (st["n_docs"] // 64 + 1) * 12
         bytes_ = pass_bytes * passes            # a pass reads the shard ONCE for all of its queries

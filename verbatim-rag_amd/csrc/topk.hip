@@ -3149,7 +3149,7 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
   // Batched path: two or more queries; per pass of SQB queries the union of their terms gets ids 1 .. SUW-1, the
   // u16 map + weight tables + top-k lists must fit the LDS.
   const int vpad = (ix->vocab + 7) & ~7;
-  const int QB = sparse_pass_queries(ix->vocab, k);
+  const int QB = nq <= 8 ? 8 : sparse_pass_queries(ix->vocab, k);   // up to eight queries: the 8-query pass reads half the weight-row bytes per term (8 queries 0.183 -> 0.173 ms, 2-4 equal: profiles/r06_sparse_probes.txt)
   bool multi = nq >= 2 && ix->vocab <= 65535 && sparse_multi_fits(ix->vocab, QB, k);
   for (int q = 0; q < nq; ++q)
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)

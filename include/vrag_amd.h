@@ -277,12 +277,14 @@ int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/
  * Dense rows are stored bf16 (dtype 0) or fp32 (dtype 1); COSINE == IP on rows/queries the caller
  * L2-normalised.  ids are row numbers in insertion order (the caller adds its shard base).
  * dtype 2 = fp32 rows (every result bit-identical to dtype 1: scores are the sequential fp32 fmaf chain over the fp32 rows)
- * plus a bf16 prefilter image of them (+50 % memory): vrag_dense_index_search, for k <= 16 and 1-2 or >= 64 queries, ranks
- * the image for 64 candidates per query, proves from the image's error bound that they contain the exact top-k (else it
- * falls back to the full fp32 scan) and re-scores them exactly -- half the bytes for one query, one read of the shard per
- * batch instead of one per 32 queries.  (One or two queries: one pass over the image collects every row within twice the bound
- * of an entry threshold; more than 4096 of them = the full scan.)  vrag_dense_index_search_device takes the same routes with
- * the full scan enqueued behind per-query flags instead of a host decision.
+ * plus a bf16 prefilter image of them (+50 % memory): vrag_dense_index_search, for k <= 16, ranks the image first, proves
+ * from the image's MEASURED error bound that its candidates contain the exact top-k (else the full fp32 scan answers that
+ * query) and re-scores them exactly -- half the bytes for a small batch, one read of the shard per batch instead of one per 32
+ * queries.  Round 6 routes every batch through it: one to four queries share ONE pass over the image that collects every row
+ * within twice the bound of an entry threshold (more than 4096 of them = the full scan); 5 .. 256 queries take the same idea
+ * on the tiled score GEMM (thresholds from a 65 536-row prefix, one appending pass, exact re-score of the lists); larger
+ * batches rank the image for 64 candidates per query with a sufficiency test.  vrag_dense_index_search_device takes the same
+ * routes with the full scan enqueued behind per-query flags instead of a host decision.
  */
 typedef struct vrag_dense_index vrag_dense_index;
 int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_t device, vrag_dense_index** out);

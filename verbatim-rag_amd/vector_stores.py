@@ -742,8 +742,8 @@ class GpuVectorStore(VectorStore):
                  enable_sparse: bool = True, dense_dtype: str = "f32", device: int = 0, distributed: bool = False,
                  group=None, comm=None, payload: str = "sharded", dense_headroom: float = 1.5,
                  dense_prefilter="auto"):
-        """`dense_prefilter` (fp32 rows only): keep a bf16 image of the rows beside them so that one or two queries and
-        batches >= 64 stream half / a fraction of the bytes (same bits as the full fp32 scan, `DenseShard`).  It costs
+        """`dense_prefilter` (fp32 rows only): keep a bf16 image of the rows beside them so that every search streams
+        half (small batches) or a fraction (large ones) of the bytes of the full fp32 scan and returns the same bits (`DenseShard`).  It costs
         +50 % of the dense rows' HBM.  "auto" (default) = on where the image route exists (dim % 64 == 0 and <= 768,
         csrc/topk.hip `prefilter_route_ok`), True / False force it; the choice is kept in a saved store's manifest."""
         self._lib = _lib.load()

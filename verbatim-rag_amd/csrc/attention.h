@@ -25,5 +25,6 @@ int attention_q_block(bool local);  // query rows per work item (256 global / 12
 
 // 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
 unsigned attention_f16_saturated(bool reset);
+unsigned* attention_f16_flag_address();   // device address of this file's flag on the current device (common.h)
 
 }  // namespace vrag

@@ -303,5 +303,6 @@ hipError_t launch_attention(const AttnParams& p, bool local, hipStream_t stream)
 }
 
 unsigned attention_f16_saturated(bool reset) { return f16_sat_take(reset); }
+unsigned* attention_f16_flag_address() { return f16_sat_flag_address(); }
 
 }  // namespace vrag

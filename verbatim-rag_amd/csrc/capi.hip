@@ -257,6 +257,10 @@ struct vrag_encoder {
   int fused_qkv_attn = 1;   // Wqkv GEMM + RoPE + attention in one kernel per (sequence, head) when every sequence of the micro-batch has <= 512 tokens (VRAG_FUSED_QKV_ATTN)
   std::vector<void*> dev_allocs;
   std::vector<void*> host_allocs;
+  // fp16 clamp reports (vrag_encoder_f16_saturated): the device addresses of the five translation units' flags and one pinned,
+  // device-mapped word they are gathered into by one launch
+  unsigned* sat_addr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned *sat_host = nullptr, *sat_host_dev = nullptr;
 
   // weights
   int op_dtype = kOpBf16;   // MFMA operand type of every 16-bit buffer of this handle (cfg.operand_dtype)
@@ -1089,6 +1093,20 @@ int read_rows(vrag_encoder* e, const float* dsrc, int cols, float* out, hipStrea
     o += e->seq_len[s];
   }
   return VRAG_OK;
+}
+
+struct SatFlags {
+  unsigned* a[5];
+};
+// one thread: OR of the translation units' clamp flags into the pinned word; a raised flag is cleared when `reset`
+__global__ void f16_sat_gather_kernel(SatFlags f, int reset, unsigned* __restrict__ out) {
+  unsigned any = 0u;
+  for (int i = 0; i < 5; ++i) {
+    const unsigned v = *f.a[i];
+    any |= v;
+    if (reset && v) *f.a[i] = 0u;
+  }
+  *out = any;
 }
 
 }  // namespace
@@ -2094,7 +2112,37 @@ int vrag_encoder_f16_saturated(vrag_encoder* e, int32_t reset, int32_t* saturate
   std::lock_guard<std::recursive_mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipDeviceSynchronize());
-  unsigned any = f16_sat_take(reset != 0);                 // conversions in this file (weight packing)
+  // One launch + one stream wait instead of five synchronous symbol copies (each ~12 us: 70 us of a single question's 1.35 ms
+  // embedding call sat here, tools/probes/embed_latency_probe.py).  The flags are per device, not per engine, as before.
+  if (!e->sat_host) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        e->host_allocs.push_back(h);
+        e->sat_host = reinterpret_cast<unsigned*>(h);
+        e->sat_host_dev = reinterpret_cast<unsigned*>(d);
+        e->sat_addr[0] = f16_sat_flag_address();   // conversions in this file (weight packing)
+        e->sat_addr[1] = gemm_f16_flag_address();
+        e->sat_addr[2] = attention_f16_flag_address();
+        e->sat_addr[3] = qkv_attn_f16_flag_address();
+        e->sat_addr[4] = norm_heads_f16_flag_address();
+      } else {
+        (void)hipHostFree(h);
+      }
+    }
+    (void)hipGetLastError();
+  }
+  if (e->sat_host && e->sat_addr[0] && e->sat_addr[1] && e->sat_addr[2] && e->sat_addr[3] && e->sat_addr[4]) {
+    SatFlags f;
+    for (int i = 0; i < 5; ++i) f.a[i] = e->sat_addr[i];
+    hipLaunchKernelGGL(f16_sat_gather_kernel, dim3(1), dim3(1), 0, e->own_stream, f, reset != 0 ? 1 : 0, e->sat_host_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->own_stream));
+    *saturated = *reinterpret_cast<volatile unsigned*>(e->sat_host) ? 1 : 0;
+    return VRAG_OK;
+  }
+  unsigned any = f16_sat_take(reset != 0);                 // (no mapped word or no symbol address: the per-file copies)
   any |= gemm_f16_saturated(reset != 0);
   any |= attention_f16_saturated(reset != 0);
   any |= qkv_attn_f16_saturated(reset != 0);

@@ -180,6 +180,15 @@ static inline unsigned f16_sat_take(bool reset) {
   return v;
 }
 
+// Device address of THIS translation unit's vrag_f16_sat_flag on the current device: the encoder gathers the flags of all its
+// translation units with ONE launch into a pinned word (capi.hip: vrag_encoder_f16_saturated) instead of one synchronous
+// symbol copy per file (five ~12 us copies on every fp16 call's read-back path).
+static inline unsigned* f16_sat_flag_address() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(vrag_f16_sat_flag)) != hipSuccess) return nullptr;
+  return reinterpret_cast<unsigned*>(p);
+}
+
 // Top-k candidate keys (csrc/topk.hip; also built by the EPI_TOPK epilogue of csrc/gemm_bf16.hip): one u64
 //   [ orderable(score) : 32 | 0xFFFFFFFF - local_row : 32 ]      (max key == best hit under (score desc, id asc))
 typedef unsigned long long u64;

@@ -101,5 +101,6 @@ bool gemm_consumer_finalizes(int rows);
 
 // 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
 unsigned gemm_f16_saturated(bool reset);
+unsigned* gemm_f16_flag_address();   // device address of this file's flag on the current device (common.h)
 
 }  // namespace vrag

@@ -1253,5 +1253,6 @@ const char* gemm_kernel_name(GemmEpi epi) {
 }
 
 unsigned gemm_f16_saturated(bool reset) { return f16_sat_take(reset); }
+unsigned* gemm_f16_flag_address() { return f16_sat_flag_address(); }
 
 }  // namespace vrag

@@ -47,5 +47,6 @@ hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row,
 
 // 1 if an fp32 -> fp16 operand conversion in this file's kernels clamped since the last reset (common.h).
 unsigned norm_heads_f16_saturated(bool reset);
+unsigned* norm_heads_f16_flag_address();   // device address of this file's flag on the current device (common.h)
 
 }  // namespace vrag

@@ -358,5 +358,6 @@ hipError_t launch_pooler_classifier(const float* h, int H, const int* first_row,
 }
 
 unsigned norm_heads_f16_saturated(bool reset) { return f16_sat_take(reset); }
+unsigned* norm_heads_f16_flag_address() { return f16_sat_flag_address(); }
 
 }  // namespace vrag

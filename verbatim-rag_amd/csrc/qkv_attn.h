@@ -40,5 +40,6 @@ int fused_pack_groups(const int* seq_row, const int* seq_len, int seq0, int seq1
 hipError_t permute_qkv_heads(const bf16_t* w, const float* s, int H, int nh, bf16_t* w_out, float* s_out, hipStream_t stream);
 
 unsigned qkv_attn_f16_saturated(bool reset);
+unsigned* qkv_attn_f16_flag_address();   // device address of this file's flag on the current device (common.h)
 
 }  // namespace vrag

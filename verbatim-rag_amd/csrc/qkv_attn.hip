@@ -557,5 +557,6 @@ int fused_pack_groups(const int* seq_row, const int* seq_len, int seq0, int seq1
 }
 
 unsigned qkv_attn_f16_saturated(bool reset) { return f16_sat_take(reset); }
+unsigned* qkv_attn_f16_flag_address() { return f16_sat_flag_address(); }
 
 }  // namespace vrag

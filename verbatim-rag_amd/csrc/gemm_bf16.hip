@@ -745,8 +745,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           for (int r = 0; r < 4; ++r) any |= (acc[nj][rt][r] >= thr[nj][r]);
         }
       }
-    if (any && p.topk_direct) {
-      // first stage: slot = row, no counters
+    if (p.topk_direct) {
+      // first stage: slot = row, no counters.  EVERY slot of a live row is written -- its key, or "no key" for a score that fails
+      // the threshold test (the stage runs with -inf: a NaN) -- so the buffer needs no clearing in front of the launch
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
@@ -758,8 +759,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             if (p.topk_pairs && (r & 1)) continue;
             const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][r + 1] : acc[nj][rt][r];
             const int query = p.topk_pairs ? (n + r) >> 1 : n + r;
-            if (!(sc >= thr[nj][r]) || query >= p.topk_nq) continue;
-            p.topk_buf[(size_t)query * p.topk_cap + row] = make_key(sc, p.topk_row_base + (unsigned)row);
+            if (query >= p.topk_nq) continue;
+            p.topk_buf[(size_t)query * p.topk_cap + row] = sc >= thr[nj][r] ? make_key(sc, p.topk_row_base + (unsigned)row) : 0ull;
           }
         }
     } else if (any) {

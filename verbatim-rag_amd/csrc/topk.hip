@@ -1113,7 +1113,8 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
 // (rows sorted by similarity to it) is flagged and re-answered by dense_tiled_rescue_kernel, which walks the shard for that
 // query alone -- exactness never depends on the order of the rows.
 constexpr int TCAP = 2048;        // candidate slots per query and stage
-constexpr int TSTAGE0 = 256;      // rows of the first stage (every row is a candidate: one key per row, no counters)
+constexpr int TSTAGE0 = 4096;     // least rows of the first stage (every row is a candidate: one key per row in a buffer of its own, no counters)
+constexpr int TDIRECT_KEYS = 1 << 22;   // budget of that buffer in keys (32 MB): the first stage takes up to min(one tile round, this / queries) rows
 constexpr int TRATIO = 16;        // growth of the rows seen per stage (k <= 16)
 constexpr int TRATIO_WIDE = 4;    // the same for longer lists
 
@@ -1161,6 +1162,88 @@ __global__ __launch_bounds__(256) void tiled_select_kernel(u64* __restrict__ buf
       __syncthreads();
     }
   for (int i = tid; i < k; i += 256) {
+    const u64 v = i < P ? sk[i] : 0ull;
+    mine[i] = v;
+    if (out) out[(size_t)q * k + i] = v;
+  }
+  if (tid == 0) {
+    const bool full = n >= k;
+    cnt[q] = (unsigned)min(n, k);
+    thr_key[q] = full ? sk[k - 1] : 0ull;
+    thr_score[q] = full ? unorderable((unsigned)(sk[k - 1] >> 32)) : -INFINITY;
+  }
+}
+
+// The first stage's selection (round 6): the stage wrote one key per row (0 = no key) into a buffer of its own, `n` keys per query
+// at `src_stride`; the best k go to the front of the query's candidate buffer, the k-th becomes the next entry threshold.  Sorting
+// thousands of keys is slow (a 4 096-key bitonic sort: ~80 us); instead the selection runs the staged search's own idea inside the
+// LDS: the first `s0` keys are sorted, their k-th is a cut, the next window (16x / 4x the keys seen so far) is filtered against the
+// cut -- ~k (growth - 1) survivors with rows in any but an adversarial order -- the survivors are sorted together with the best k,
+// and so on.  The survivors' order of arrival does not matter (the sort orders them); more survivors than the LDS holds flag the
+// query for the rescue pass / the gated full scan, like an overflowing candidate buffer.
+constexpr int TSEL_NT = 1024;   // threads of the first stage's selection: its windows are scanned with sixteen keys per thread in flight
+__global__ __launch_bounds__(TSEL_NT) void tiled_select_direct_kernel(const u64* __restrict__ src, int src_stride, int n, u64* __restrict__ buf,
+                                                                   unsigned* __restrict__ cnt, int cap, int k, u64* __restrict__ thr_key,
+                                                                   float* __restrict__ thr_score, u64* __restrict__ out,
+                                                                   unsigned* __restrict__ ovf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned n_surv;
+  u64* sk = reinterpret_cast<u64*>(smem);   // cap keys
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const u64* in = src + (size_t)q * src_stride;
+  u64* mine = buf + (size_t)q * cap;
+  auto sort_desc = [&](int P) {   // bitonic, P a power of two <= cap
+    for (int size = 2; size <= P; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = tid; i < (P >> 1); i += TSEL_NT) {
+          const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+          const bool desc = (lo & size) == 0;
+          const u64 a = sk[lo], b = sk[hi];
+          if ((a < b) == desc) {
+            sk[lo] = b;
+            sk[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+  };
+  const int growth = k > 16 ? 4 : 16;
+  int seen = min(n, k > 16 ? 1024 : 256), P = 2;
+  while (P < seen) P <<= 1;
+  for (int i = tid; i < P; i += TSEL_NT) sk[i] = i < seen ? in[i] : 0ull;
+  __syncthreads();
+  sort_desc(P);
+  while (seen < n) {
+    const int chunk = min(n - seen, seen * (growth - 1));
+    const u64 cut = P >= k ? sk[k - 1] : 0ull;   // 0: fewer than k keys so far, every key survives
+    if (tid == 0) n_surv = 0u;
+    __syncthreads();
+    // sixteen keys per thread in flight: one dependent load per key made a 65 536-key window a 100 us chain of round trips
+    for (int i0 = seen + tid; i0 < seen + chunk; i0 += TSEL_NT * 16) {
+      u64 kk[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) kk[u] = i0 + u * TSEL_NT < seen + chunk ? __builtin_nontemporal_load(in + i0 + u * TSEL_NT) : 0ull;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (kk[u] > cut) {
+          const unsigned pos = atomicAdd(&n_surv, 1u);
+          if (k + (int)pos < cap) sk[k + pos] = kk[u];
+        }
+    }
+    __syncthreads();
+    const unsigned ns = n_surv;
+    if (ns > (unsigned)(cap - k) && tid == 0) ovf[q] = 1u;
+    const int m = k + (int)min(ns, (unsigned)(cap - k));
+    // slots [min(P, k), k) (a first window shorter than k) hold nothing yet
+    for (int i = P + tid; i < k; i += TSEL_NT) sk[i] = 0ull;
+    P = 2;
+    while (P < m) P <<= 1;
+    for (int i = m + tid; i < P; i += TSEL_NT) sk[i] = 0ull;
+    __syncthreads();
+    sort_desc(P);
+    seen += chunk;
+  }
+  for (int i = tid; i < k; i += TSEL_NT) {
     const u64 v = i < P ? sk[i] : 0ull;
     mine[i] = v;
     if (out) out[(size_t)q * k + i] = v;
@@ -2105,10 +2188,10 @@ struct vrag_dense_index {
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
   // tiled batched search (batches over bf16 rows: kTiledMin*): W operand of the score GEMM, candidate buffers, thresholds, flags
   bf16_t* d_tw = nullptr;
-  u64 *d_tbuf = nullptr, *d_tthr = nullptr;
+  u64 *d_tbuf = nullptr, *d_tthr = nullptr, *d_tdir = nullptr;   // d_tdir: [nq][rows of the first stage] one key per row
   float* d_tthrs = nullptr;
   unsigned* d_tcnt = nullptr;   // [nq] counters followed by [nq] overflow flags
-  size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0;
+  size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0, d_tdir_elems = 0;
   u64* d_pfb = nullptr;            // [nq][PFCAP] candidate keys of the batch collect route (round 6: prefilter_batch_enqueue, <= 64 queries)
   size_t d_pfb_elems = 0;
   // fp32 rows with a bf16 prefilter copy (dtype 2 at creation; `dtype` stays 1: the contract is the fp32 rows')
@@ -2287,8 +2370,6 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   hipLaunchKernelGGL(tiled_queries_kernel, dim3(n_pad), dim3(256), 0, st, ix->d_q, nq, dim, pairs, n_pad, ix->d_tw);
   hipLaunchKernelGGL(tiled_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nq, ix->d_tthr, ix->d_tthrs, ix->d_tcnt);
   HIP_TRY(hipGetLastError());
-  // stage 0 writes slot = row: a NaN score leaves its slot untouched, so the slots start as "no key"
-  HIP_TRY(hipMemset2DAsync(ix->d_tbuf, (size_t)TCAP * sizeof(u64), 0, (size_t)TSTAGE0 * sizeof(u64), (size_t)nq, st));
   const long long n_all = (long long)ix->size;
   const long long n = col ? std::min<long long>(n_all, TCOLLECT_PREFIX) : n_all;   // collect form: the staged search covers a prefix only
   static bool attr = false;
@@ -2301,30 +2382,39 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   // query's counter: at k = 64 (the prefilter's candidate lists) a ratio of 16 made the appends, not the row stream, the cost of
   // every stage (960 per query and stage)
   const int ratio = k > 16 ? TRATIO_WIDE : TRATIO;   // (the sweeps behind the two constants: profiles/r05_tiled_stage_ratio_probe.txt; small batches too: r06_dense_midbatch_probe.txt)
-  // Stage plan (round 6).  Boundaries grow by `ratio`; the last stage absorbs up to twice that (a launch and a selection fewer:
-  // it admits ~2 k ratio keys per query, far below the buffer), and then every stage of at least one tile ROUND -- 256 persistent
-  // workgroups x one 256-row tile each -- is cut to a whole number of rounds by moving its first row up, the remainder going to
-  // the stage before it (which is a fraction of a round anyway).  1.25 M rows used to run as 256 | 3 840 | 61 440 | 983 040 |
-  // 201 856 rows: the last launch needs 3.08 rounds and takes 4, and the one before it was followed by a selection it did not
-  // need -- 22 rounds; now 256 | 4 560 | 65 536 | 1 179 648: 18 whole rounds + three partial ones (64 queries 0.549 -> 0.526 ms,
-  // 256 queries 0.746 -> 0.719, 32 fp32-row queries 0.807 -> 0.788; profiles/r06_tiled_tile64_and_stage_plan_ab.txt).  The last
-  // stage is widened for batches up to 256 queries only: at 1 024 its extra appends cost what the launch saved (2.10 vs 2.125 ms).
-  std::vector<long long> b = {0, std::min<long long>(n, TSTAGE0)};
+  // Stage plan.  A launch costs a tile ROUND -- 256 persistent workgroups x one 256-row tile each -- however few tiles its last
+  // round holds (a lone tile is a chain of memory round trips: ~30 us against ~19 us for a full round inside a long launch), and an
+  // appending stage pays for its ~k (ratio - 1) appends per query as same-address atomics (~0.2 us each, serialised per query:
+  // 30-40 us per stage unless they hide under a long stream; profiles/r06_search_timeline.txt).  So (late round 6):
+  //   * the FIRST stage is as large as it may be for free -- it is a partial round anyway and has no appends (one key per row into
+  //     d_tdir, picked over by tiled_select_direct_kernel): it takes the rows the later stages leave over from whole rounds,
+  //     n mod round, when that is at least TSTAGE0 and fits the key budget (else TSTAGE0 rows, and the last stage ends on a
+  //     partial round); a shard or prefix of at most one round is ONE direct stage;
+  //   * every later stage is a whole number of rounds, boundaries growing by `ratio`; the last stage absorbs up to twice that (a
+  //     launch and a selection fewer: it admits ~2 k ratio keys per query, far below the buffer) for batches up to 256 queries --
+  //     at 1 024 its extra appends cost what the launch saved (2.10 vs 2.125 ms).
+  //   * when the key budget holds a whole round (<= 64 queries) the first stage IS a whole round: the one appending launch left is
+  //     the last, whose appends hide under its stream.
+  // 1.25 M rows: 65 536 | 1 184 464 for <= 64 queries (two launches), 4 816 | 65 536 | 1 179 648 for 65-256 (a partial round + 1 +
+  // 18 whole rounds; rounds 5-6: 256 | 4 560 | 65 536 | 1 179 648 in four launches, the second and third paying ~30 us of atomics each).
+  const int col_tiles = tile == 0 ? n_pad / 256 : 1;
+  const long long R = 256 % col_tiles == 0 ? (long long)(256 / col_tiles) * 256 : 0;   // rows of one round of the persistent grid (0: the column tiles do not divide it)
+  long long c0max = std::min<long long>(R ? R : 65536, (TDIRECT_KEYS / std::max(nq, 1)) / 256 * 256);
+  if (k > 16) c0max = std::min<long long>(c0max, 8192);   // longer lists: the selection's windows grow 4x, keep it short
+  const long long s0min = nq > 1024 ? 512 : TSTAGE0;   // thousands of queries: one key per row and query is 8 B x nq per row
+  c0max = std::max<long long>(c0max, s0min);
+  long long s0 = std::min<long long>(n, s0min);
+  if (n <= c0max) s0 = n;
+  else if (R && c0max >= R) s0 = R;   // the key budget holds a whole round (<= 64 queries): no appending stage below the last one at all
+  else if (R && n % R >= s0min && n % R <= c0max) s0 = n % R;
+  std::vector<long long> b = {0, s0};
   while (b.back() < n) {
     long long hi = b.back() * ratio;
     if (nq <= 256 && hi * 2 >= n) hi = n;
+    if (R && hi < n) hi = b.back() + std::max(R, (hi - b.back()) / R * R);   // whole rounds
     b.push_back(std::min<long long>(n, hi));
   }
-  const int col_tiles = tile == 0 ? n_pad / 256 : 1;
-  if (256 % col_tiles == 0) {
-    const long long R = (long long)(256 / col_tiles) * 256;   // rows of one round of the persistent grid
-    for (size_t i = b.size() - 2; i >= 2; --i) {               // stage i = rows [b[i], b[i + 1])
-      const long long rows = b[i + 1] - b[i];
-      if (rows < R) continue;
-      const long long up = rows - rows / R * R;
-      if (up <= b[i] - b[i - 1]) b[i] += up;                   // the stage before it at most doubles
-    }
-  }
+  if ((rc = grow(&ix->d_tdir, &ix->d_tdir_elems, (size_t)nq * (size_t)s0))) return rc;
   for (size_t stage = 0; stage + 1 < b.size(); ++stage) {
     const long long lo = b[stage], hi = b[stage + 1];
     GemmParams g{};
@@ -2337,8 +2427,8 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     g.topk_thr_score = ix->d_tthrs;
     g.topk_thr_key = ix->d_tthr;
     g.topk_cnt = ix->d_tcnt;
-    g.topk_buf = ix->d_tbuf;
-    g.topk_cap = TCAP;
+    g.topk_buf = stage == 0 ? ix->d_tdir : ix->d_tbuf;
+    g.topk_cap = stage == 0 ? (int)s0 : TCAP;
     g.topk_nq = nq;
     g.topk_pairs = pairs;
     g.topk_direct = stage == 0;
@@ -2346,8 +2436,13 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     g.topk_tile = tile;
     HIP_TRY(launch_gemm(EPI_TOPK, g, st));
     const bool last = hi >= n;
-    hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
-                       ix->d_tthr, ix->d_tthrs, (last && !col) ? ix->d_out : (u64*)nullptr, ovf, stage == 0 ? (int)(hi - lo) : 0);
+    u64* const sel_out = (last && !col) ? ix->d_out : (u64*)nullptr;
+    if (stage == 0)
+      hipLaunchKernelGGL(tiled_select_direct_kernel, dim3(nq), dim3(TSEL_NT), (size_t)TCAP * sizeof(u64), st, ix->d_tdir, (int)s0, (int)s0, ix->d_tbuf,
+                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf);
+    else
+      hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
+                         ix->d_tthr, ix->d_tthrs, sel_out, ovf, 0);
     HIP_TRY(hipGetLastError());
   }
   if (col) {
@@ -2483,7 +2578,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
-  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, (void*)ix->d_pfb, ix->rows16, (void*)ix->d_norm2,
+  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tdir, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, (void*)ix->d_pfb, ix->rows16, (void*)ix->d_norm2,
                   (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag, (void*)ix->d_pf_cand, (void*)ix->d_pf_keys, (void*)ix->d_pf_cnt,
                   (void*)ix->d_pf_thr})
     if (p) (void)hipFree(p);

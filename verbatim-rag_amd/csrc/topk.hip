@@ -1114,7 +1114,7 @@ static hipError_t dense_launch_all(int dtype, const void* rows, long long n, int
 // query alone -- exactness never depends on the order of the rows.
 constexpr int TCAP = 2048;        // candidate slots per query and stage
 constexpr int TSTAGE0 = 4096;     // least rows of the first stage (every row is a candidate: one key per row in a buffer of its own, no counters)
-constexpr int TDIRECT_KEYS = 1 << 22;   // budget of that buffer in keys (32 MB): the first stage takes up to min(one tile round, this / queries) rows
+constexpr int TDIRECT_KEYS = 1 << 24;   // budget of that buffer in keys (128 MB: a whole tile round for every power-of-two batch up to 4 096 queries): the first stage takes up to min(one tile round, this / queries) rows
 constexpr int TRATIO = 16;        // growth of the rows seen per stage (k <= 16)
 constexpr int TRATIO_WIDE = 4;    // the same for longer lists
 
@@ -2393,10 +2393,10 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   //   * every later stage is a whole number of rounds, boundaries growing by `ratio`; the last stage absorbs up to twice that (a
   //     launch and a selection fewer: it admits ~2 k ratio keys per query, far below the buffer) for batches up to 256 queries --
   //     at 1 024 its extra appends cost what the launch saved (2.10 vs 2.125 ms).
-  //   * when the key budget holds a whole round (<= 64 queries) the first stage IS a whole round: the one appending launch left is
-  //     the last, whose appends hide under its stream.
-  // 1.25 M rows: 65 536 | 1 184 464 for <= 64 queries (two launches), 4 816 | 65 536 | 1 179 648 for 65-256 (a partial round + 1 +
-  // 18 whole rounds; rounds 5-6: 256 | 4 560 | 65 536 | 1 179 648 in four launches, the second and third paying ~30 us of atomics each).
+  //   * when the key budget holds a whole round (every power-of-two batch up to 4 096 queries) the first stage IS a whole round: up
+  //     to 256 queries the one appending launch left is the last, whose appends hide under its stream.
+  // 1.25 M rows, <= 256 queries: 65 536 | 1 184 464 (two launches; rounds 5-6: 256 | 4 560 | 65 536 | 1 179 648 in four, the second
+  // and third paying ~30 us of atomics each); where the keys of a round do not fit (or the list is longer than 16): 4 816 | 65 536 | 1 179 648.
   const int col_tiles = tile == 0 ? n_pad / 256 : 1;
   const long long R = 256 % col_tiles == 0 ? (long long)(256 / col_tiles) * 256 : 0;   // rows of one round of the persistent grid (0: the column tiles do not divide it)
   long long c0max = std::min<long long>(R ? R : 65536, (TDIRECT_KEYS / std::max(nq, 1)) / 256 * 256);
@@ -2405,7 +2405,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   c0max = std::max<long long>(c0max, s0min);
   long long s0 = std::min<long long>(n, s0min);
   if (n <= c0max) s0 = n;
-  else if (R && c0max >= R) s0 = R;   // the key budget holds a whole round (<= 64 queries): no appending stage below the last one at all
+  else if (R && c0max >= R) s0 = R;   // the key budget holds a whole round: up to 256 queries no appending stage below the last one at all
   else if (R && n % R >= s0min && n % R <= c0max) s0 = n % R;
   std::vector<long long> b = {0, s0};
   while (b.back() < n) {
@@ -2414,7 +2414,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     if (R && hi < n) hi = b.back() + std::max(R, (hi - b.back()) / R * R);   // whole rounds
     b.push_back(std::min<long long>(n, hi));
   }
-  if ((rc = grow(&ix->d_tdir, &ix->d_tdir_elems, (size_t)nq * (size_t)s0))) return rc;
+  if ((rc = grow(&ix->d_tdir, &ix->d_tdir_elems, (size_t)nq * (size_t)std::max(c0max, s0)))) return rc;   // the batch size's maximum, not this shard size's: no re-allocation on a later search of a grown shard
   for (size_t stage = 0; stage + 1 < b.size(); ++stage) {
     const long long lo = b[stage], hi = b[stage + 1];
     GemmParams g{};

@@ -444,7 +444,11 @@ def test_dense_edges_dim_limits_and_capacity():
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 64, 10), (300_000, 384, 300, 5), (5_000, 128, 100, 16), (200_000, 1024, 257, 64),
-                                         (4_096, 64, 64, 1), (4_353, 256, 65, 7), (1_100_000, 64, 500, 33)])
+                                         (4_096, 64, 64, 1), (4_353, 256, 65, 7), (1_100_000, 64, 500, 33),
+                                         # the first-stage forms of the stage plan (late round 6): a whole round of keys + one appending stage;
+                                         # lists longer than 16 with n mod round inside the key budget (first stage = 5 000 rows); 1 100 queries
+                                         # (column tiles that do not divide the grid, 512-row first stage)
+                                         (140_000, 64, 40, 10), (136_072, 64, 257, 40), (20_000, 64, 1100, 5)])
 def test_dense_topk_tiled_batched_search_exact(n, dim, nq, k):
     """>= 64 queries over >= 4 096 bf16 rows: the shard is read once per batch -- rows x queries on the encoder's GEMM
     kernel, EPI_TOPK epilogue, staged thresholds (csrc/topk.hip).  Dyadic-grid data: ids and scores equal the oracle bit

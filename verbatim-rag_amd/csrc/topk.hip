@@ -2254,6 +2254,12 @@ struct vrag_sparse_index {
   size_t d_cand_elems = 0, d_out_elems = 0, d_bound_elems = 0;
   char* d_qcsr = nullptr;             // single-query kernels: the queries' CSR (indptr | terms | weights) as uploaded, scattered into d_q on the device
   size_t d_qcsr_bytes = 0;
+  // host sources of the query uploads: they live in the handle so that a call need not wait for its own uploads before it launches
+  // (the NEXT call waits for upload_done before it rewrites them; by then the event has long passed)
+  std::vector<char> h_blob;
+  std::vector<unsigned short> h_maps;
+  std::vector<float> h_wts;
+  bool upload_pending = false;
   unsigned short* d_qmap = nullptr;   // batched kernel: [passes][vpad] term -> union id
   float* d_qw = nullptr;              // [passes][SQB][SUW] union id -> weight per query
   size_t d_qmap_elems = 0, d_qw_elems = 0;
@@ -3261,8 +3267,12 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
     for (int64_t j = q_indptr[q]; j < q_indptr[q + 1]; ++j)
       ARG_CHECK(q_indices[j] >= 0 && q_indices[j] < ix->vocab, "query %d: term id %d outside the vocabulary", q, q_indices[j]);
   const int n_pass = (nq + QB - 1) / QB;
-  std::vector<unsigned short> maps;
-  std::vector<float> wts;
+  if (ix->upload_pending) {   // the previous call's uploads read the handle's host buffers
+    HIP_TRY(hipEventSynchronize(ix->upload_done));
+    ix->upload_pending = false;
+  }
+  std::vector<unsigned short>& maps = ix->h_maps;
+  std::vector<float>& wts = ix->h_wts;
   std::vector<int> unions;
   if (multi) {
     maps.assign((size_t)n_pass * vpad, 0);
@@ -3305,7 +3315,7 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
     HIP_TRY(hipMemcpyAsync(ix->d_qmap, maps.data(), maps.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ix->d_qw, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(ix->upload_done, st));
-    HIP_TRY(hipEventSynchronize(ix->upload_done));   // the host tables go out of scope below
+    ix->upload_pending = true;   // the host tables stay in the handle: no wait here
     int nwg3 = 0;
     return sparse_launch(ix, nq, k, st, &nwg3);
   }
@@ -3315,7 +3325,8 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
   // keeps its last value, as the host scatter did).
   const int64_t nnz_q = q_indptr[nq] - q_indptr[0];
   const size_t off_idx = (size_t)(nq + 1) * sizeof(int64_t), off_val = off_idx + (size_t)nnz_q * sizeof(int32_t);
-  std::vector<char> blob(off_val + (size_t)nnz_q * sizeof(float));
+  std::vector<char>& blob = ix->h_blob;
+  blob.resize(off_val + (size_t)nnz_q * sizeof(float));
   {
     int64_t* ip = reinterpret_cast<int64_t*>(blob.data());
     for (int q = 0; q <= nq; ++q) ip[q] = q_indptr[q] - q_indptr[0];
@@ -3332,7 +3343,7 @@ static int sparse_search_enqueue(vrag_sparse_index* ix, const int64_t* q_indptr,
   hipLaunchKernelGGL(sparse_scatter_queries_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, reinterpret_cast<const long long*>(ix->d_qcsr),
                      reinterpret_cast<const int*>(ix->d_qcsr + off_idx), reinterpret_cast<const float*>(ix->d_qcsr + off_val), nq, ix->vocab, ix->d_q);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventSynchronize(ix->upload_done));   // the host blob goes out of scope below
+  ix->upload_pending = true;   // the host blob stays in the handle: no wait here
   int nwg2 = 0;
   return sparse_launch(ix, nq, k, st, &nwg2);
 }

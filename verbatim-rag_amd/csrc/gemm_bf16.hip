@@ -748,19 +748,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     if (p.topk_direct) {
       // first stage: slot = row, no counters.  EVERY slot of a live row is written -- its key, or "no key" for a score that fails
       // the threshold test (the stage runs with -inf: a NaN) -- so the buffer needs no clearing in front of the launch
+      // one 64-bit slot address per (column tile, column) at a time, the row tiles at constant offsets from it: all sixteen
+      // addresses live at once cost the 256 x 256 form two spilled registers (tests/test_kernel_resources.py)
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int row = mw + rt * 16 + l15, n = nw + nj * 16 + 4 * q;
-          if (row >= p.M) continue;   // padding rows of the last tile hold whatever the allocation does
+        for (int r = 0; r < 4; ++r) {
+          if (p.topk_pairs && (r & 1)) continue;
+          const int n = nw + nj * 16 + 4 * q + r;
+          const int query = p.topk_pairs ? n >> 1 : n;
+          if (query >= p.topk_nq) continue;
+          unsigned long long* slot = p.topk_buf + (size_t)query * p.topk_cap + (mw + l15);
+          asm volatile("" : "+v"(slot));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (p.topk_pairs && (r & 1)) continue;
+          for (int rt = 0; rt < RT; ++rt) {
+            const int row = mw + rt * 16 + l15;
+            if (row >= p.M) continue;   // padding rows of the last tile hold whatever the allocation does
             const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][r + 1] : acc[nj][rt][r];
-            const int query = p.topk_pairs ? (n + r) >> 1 : n + r;
-            if (query >= p.topk_nq) continue;
-            p.topk_buf[(size_t)query * p.topk_cap + row] = sc >= thr[nj][r] ? make_key(sc, p.topk_row_base + (unsigned)row) : 0ull;
+            slot[rt * 16] = sc >= thr[nj][r] ? make_key(sc, p.topk_row_base + (unsigned)row) : 0ull;
           }
         }
     } else if (any) {

@@ -807,7 +807,8 @@ int run_layers_locked(vrag_encoder* e, int n_layers, hipStream_t user_st) {
 
 // BERT-family schedule (arch 1).  Post-LN: every sub-layer is  h <- LN(h + f(h) + b),  so the residual
 // GEMM adds the linear bias in its epilogue and is followed by an in-place LayerNorm kernel that also refreshes
-// the bf16 copy the next GEMM reads.  Opt-in (VRAG_BERT_LN_FOLD=1, 2-3 % slower here): no LayerNorm kernels --
+// the bf16 copy the next GEMM reads.  Opt-in (VRAG_BERT_LN_FOLD=1; round 3 measured it 2-3 % slower, on round 6's residual epilogues it is
+// 4.5-6.4 % FASTER at 256 x 512 tokens and 6 % slower for one 20-token question: profiles/r06_embed_latency.txt): no LayerNorm kernels --
 // the stream keeps the pre-LayerNorm sums t, the residual epilogues emit bf16(t) and the row statistics, the
 // consumer GEMMs (gain folded into their weights, W . ln_bias into their biases) normalise in their epilogues,
 // the next residual epilogue rebuilds LN(t) on the fly as its residual input, and only the output of the last
@@ -1251,7 +1252,7 @@ int vrag_bert_encoder_create(const vrag_bert_config* cfg, const vrag_bert_weight
   vrag_encoder* e = new vrag_encoder();
   e->arch = 1;
   e->op_dtype = cfg->operand_dtype;
-  e->ln_fold = false;   // measured 2-3 % slower than the LayerNorm kernels on this family (opt-in: VRAG_BERT_LN_FOLD=1)
+  e->ln_fold = false;   // opt-in (VRAG_BERT_LN_FOLD=1): +4.5-6.4 % texts/s at 256 x 512 tokens, but one question's embedding 1.23 -> 1.30 ms (the consumer GEMMs finalise the statistics); the providers answer single questions, so the LayerNorm kernels stay the default
   if (const char* lf = getenv("VRAG_BERT_LN_FOLD")) e->ln_fold = atoi(lf) != 0;
   e->attn_w = Ha;
   e->q_scale = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;

@@ -111,11 +111,13 @@ def test_configs3_dense_shard_1_25m_rows(dtype):
             _note(f"dense_{dtype}_{nq}_queries_first_call_s", time.perf_counter() - t0)
             assert np.array_equal(i, ri[:nq]), (dtype, nq)
             assert np.array_equal(s, rs[:nq]), (dtype, nq)
-            t0 = time.perf_counter()
-            s2, i2 = sh.search(Q[:nq], k)
-            dt = time.perf_counter() - t0          # the search alone: the note below is file I/O, the comparisons host work
+            dt = float("inf")
+            for _rep in range(3):                  # the best of three: one repeat took 71 ms on a box once (a host hiccup -- the next run
+                t0 = time.perf_counter()           # of the same build was back at 1.1 ms), a per-search allocation would slow all three
+                s2, i2 = sh.search(Q[:nq], k)
+                dt = min(dt, time.perf_counter() - t0)   # the search alone: the note below is file I/O, the comparisons host work
+                assert np.array_equal(i2, i) and np.array_equal(s2, s)
             _note(f"dense_{dtype}_{nq}_queries_search_s", dt)
-            assert np.array_equal(i2, i) and np.array_equal(s2, s)
             if nq <= 256:
                 assert dt < 0.02, "a repeated <= 256-query search takes milliseconds"
     finally:

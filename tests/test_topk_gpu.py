@@ -171,6 +171,37 @@ def test_sparse_topk_bit_exact(vocab):
     assert np.array_equal(i, ri) and np.array_equal(s, rs)
 
 
+def test_sparse_query_with_a_repeated_term_keeps_the_last_weight():
+    """A query CSR may name a term twice: the LAST weight counts (what a dense scatter of the pairs gives) -- on the
+    single-query kernels, whose dense query vector is scattered on the device since round 6, and on the batched pass's
+    host-built weight table alike.  Unsorted terms inside a query row are fine too (the document's term order is what counts)."""
+    from verbatim_rag_amd.vector_stores import SparseShard
+
+    vocab = 30522
+    rng = np.random.default_rng(5)
+    indptr, idx, val, _qp, _qi, _qv = _sparse_corpus(rng, 20000, vocab, 64, 1, 8)
+    hot = np.bincount(idx, minlength=vocab).argsort()[-6:][::-1].astype(np.int32)     # frequent terms: many documents score
+    # query 0: term hot[0] three times (weights 9, 0.25, 2 -> 2 counts), hot[1] once, hot[2] twice (-> 0.5); query 1: ordinary
+    q0_t = np.asarray([hot[0], hot[1], hot[0], hot[2], hot[0], hot[2]], np.int32)
+    q0_w = np.asarray([9.0, 1.5, 0.25, 3.0, 2.0, 0.5], np.float32)
+    q1_t, q1_w = hot[3:6].copy(), np.asarray([1.0, 0.75, 2.5], np.float32)
+    d0_t, d0_w = np.asarray([hot[0], hot[1], hot[2]], np.int32), np.asarray([2.0, 1.5, 0.5], np.float32)   # the de-duplicated query 0
+    sh = SparseShard(vocab, indptr, idx, val)
+    try:
+        one = lambda t, w: (np.asarray([0, len(t)], np.int64), t, w)
+        order0, order1 = np.argsort(d0_t), np.argsort(q1_t)
+        r0 = T.sparse_topk(indptr, idx, val, vocab, *one(d0_t[order0], d0_w[order0]), 7)
+        r1 = T.sparse_topk(indptr, idx, val, vocab, *one(q1_t[order1], q1_w[order1]), 7)
+        s, i = sh.search_csr(*one(q0_t, q0_w), 7)                                   # single-query kernel
+        assert np.array_equal(i, r0[1]) and np.array_equal(s, r0[0])
+        qp = np.asarray([0, len(q0_t), len(q0_t) + len(q1_t)], np.int64)
+        s, i = sh.search_csr(qp, np.concatenate([q0_t, q1_t]), np.concatenate([q0_w, q1_w]), 7)   # batched pass
+        assert np.array_equal(i[0], r0[1][0]) and np.array_equal(s[0], r0[0][0])
+        assert np.array_equal(i[1], r1[1][0]) and np.array_equal(s[1], r1[0][0])
+    finally:
+        sh.close()
+
+
 @pytest.mark.parametrize("vocab", [30522, 50368])
 def test_sparse_batched_hash_path_and_fallbacks_bit_exact(vocab):
     """>= 2 small queries: QB = 8 queries per pass through per-query hash tables in LDS (19 queries = 3 passes, the

@@ -503,6 +503,40 @@ def test_dense_topk_tiled_batched_search_exact(n, dim, nq, k):
     assert np.array_equal(i2, ri[:63]) and np.array_equal(s2, rs[:63])
 
 
+def test_dense_topk_tiled_stage_plan_around_its_boundaries():
+    """The stage plan of the tiled search (csrc/topk.hip dense_tiled_search) branches on the shard size against the tile round
+    (65 536 / 32 768 / 16 384 rows for <= 256 / 512 / 1 024 query columns), on n mod round against the first stage's least size
+    and key budget, on the list length (<= 16: 16x growth, longer: 4x and an 8 192-row first stage at most) and on the batch
+    (widened last stage up to 256 queries): seeded sizes ON and next to those boundaries, every one bit for bit the oracle."""
+    from verbatim_rag_amd.vector_stores import DenseShard
+
+    R = 65536
+    cases = [(R, 64, 10), (R + 1, 64, 10), (R - 1, 33, 3), (R + 4095, 64, 10), (R + 4096, 64, 16), (R + 4097, 40, 17),
+             (2 * R, 128, 10), (2 * R + 5000, 200, 10), (2 * R + 5000, 256, 16), (3 * R // 2, 257, 10), (R + 4500, 300, 20),
+             (32768 + 4096, 512, 5), (16384 * 3 + 100, 1000, 10), (8192 + 4200, 70, 64), (40_000, 520, 33), (4097, 64, 10)]
+    for n, nq, k in cases:
+        rng = np.random.default_rng(n * 7 + nq)
+        X, Q = _dyadic(rng, (n, 64), lim=8), _dyadic(rng, (nq, 64))
+        X[n - 1] = X[0]                         # a tie across the whole shard
+        sh = DenseShard(64, n, "bf16")
+        sh.add(X)
+        s, i = sh.search(Q, k)
+        sh.close()
+        rs, ri = T.dense_topk(X, Q, k, blocked=True)
+        assert np.array_equal(i, ri) and np.array_equal(s, rs), (n, nq, k)
+    # fp32 rows behind the bf16 image: the collect form's prefix (min(n, 65 536) rows) as one direct stage or 4 096 + the rest,
+    # the 64-candidate route above 256 queries -- arbitrary data, the exact fmaf chain's bits
+    for n, nq, k in [(R - 7, 5, 10), (R, 33, 10), (R + 4100, 64, 16), (R + 4100, 100, 10), (2 * R + 300, 256, 5), (R + 9000, 300, 10)]:
+        rng = np.random.default_rng(n + nq)
+        X, Q = rng.standard_normal((n, 64), dtype=np.float32), rng.standard_normal((nq, 64), dtype=np.float32)
+        sh = DenseShard(64, n, "f32")
+        sh.add(X)
+        s, i = sh.search(Q, k)
+        sh.close()
+        rs, ri = T.dense_topk(X, Q, k, blocked=True)
+        assert np.array_equal(i, ri) and np.array_equal(s, rs), ("f32", n, nq, k)
+
+
 def test_dense_topk_tiled_fp32_queries_ride_as_column_pairs():
     """Queries that are not bf16 numbers: (value, remainder) column pairs in the tiled search too -- the ranking equals the
     fp32-query oracle's up to fp32 summation noise, exactly like the 16-queries-per-pass route."""

@@ -495,7 +495,7 @@ def test_dense_topk_tiled_batched_search_exact(n, dim, nq, k):
     sh = DenseShard(dim, n, "bf16")
     sh.add(X)
     s, i = sh.search(Q, k)
-    s2, i2 = sh.search(Q[:63], k)          # the 32-queries-per-pass route on the same shard
+    s2, i2 = sh.search(Q[:63], k)          # 64 query columns: the 256 x 64 tile form (the 32-queries-per-pass route under VRAG_TOPK_NO_TILED)
     sh.close()
     rs, ri = T.dense_topk(X, Q, k, blocked=n * nq > 5_000_000)
     assert np.array_equal(i, ri), (n, dim, nq, k)
@@ -535,6 +535,25 @@ def test_dense_topk_tiled_stage_plan_around_its_boundaries():
         sh.close()
         rs, ri = T.dense_topk(X, Q, k, blocked=True)
         assert np.array_equal(i, ri) and np.array_equal(s, rs), ("f32", n, nq, k)
+
+
+def test_dense_pass_kernels_in_a_child_process():
+    """Since late round 6 a bf16 shard of >= 4 096 rows with dim % 64 == 0 answers every batch of two or more queries through the
+    tiled search; the 4- / 32-queries-per-pass kernels (scalar and matrix-core, one- and two-pass plans) keep the other shards
+    and `VRAG_TOPK_NO_TILED` (read once per process).  A child process runs this module's dense tests under it, so the pass
+    kernels stay pinned to the oracle at the full range of shapes."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("VRAG_TOPK_NO_TILED"):
+        pytest.skip("already inside the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_topk_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+         "batched_mfma_path or exact_on_dyadic_grid or random_data_ranking or fuzz_shapes or tiled_batched_search_exact or fp32_queries_ride or dense_paged"],
+        env={**os.environ, "VRAG_TOPK_NO_TILED": "1"}, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_dense_topk_tiled_fp32_queries_ride_as_column_pairs():

@@ -1740,9 +1740,12 @@ __global__ void prefilter_combine_kernel(u64* __restrict__ pf, const u64* __rest
 // Smallest batch that takes the tiled search (round 6; profiles/r06_dense_midbatch_probe.txt, 1.25 M x 768 rows):
 //  * the bf16 image of an fp32 index: 3 -- every batch the one-pass route (1-2 queries) does not take.  The 32-queries-per-pass
 //    exact scan costs 0.93-1.02 ms per pass (3-32 queries; 1.96-2.1 ms for 33-63), the image route 0.65-0.81 (0.88-0.95);
-//  * bf16 rows: one pass of the 32-query kernel is 0.44-0.49 ms, the tiled search 0.58 ms for up to 128 query columns -- so a
-//    batch that would need TWO passes (more than 32 queries, or more than 16 when fp32 queries ride as column pairs) is tiled.
-constexpr int kTiledMinImage = 3, kTiledMinBf16 = 33, kTiledMinBf16Pairs = 17;
+//  * bf16 rows: 2 (late round 6).  One pass of the 32-query kernel is 0.43-0.48 ms (two queries ran as two single-query passes:
+//    0.95 ms); with its first stage a whole round of one-key-per-row writes the tiled search takes 0.37-0.41 ms for anything
+//    up to 64 query columns -- 2-32 exact-bf16 queries 0.38-0.40, 2-32 generic fp32 queries (column pairs) 0.37-0.40
+//    (tools/probes/bf16_small_batch_route.py, profiles/r06_search_timeline.txt).  The pass kernels keep the shards the tiled
+//    search does not take (fewer than 4 096 rows, dim not a multiple of 64) and VRAG_TOPK_NO_TILED.
+constexpr int kTiledMinImage = 3, kTiledMinBf16 = 2, kTiledMinBf16Pairs = 2;
 static bool dense_use_tiled(int dtype, int dim, int nq, int k, long long size, int min_nq = kTiledMinBf16) {
   static const bool off = getenv("VRAG_TOPK_NO_TILED") != nullptr;   // A/B against the 32-query passes
   return !off && dtype == 0 && dim % 64 == 0 && nq >= min_nq && k <= KMAX && size >= 4096;

@@ -581,7 +581,8 @@ def test_dense_topk_tiled_fp32_queries_ride_as_column_pairs():
 
 def test_dense_topk_tiled_candidate_overflow_is_rescued():
     """Rows sorted by similarity to a query: every row of a stage beats the threshold the stage started with, the
-    query's candidate buffer (2 048 slots) overflows, and the rescue pass re-answers that query from the whole shard.
+    query's candidate buffer (2 048 slots) overflows, and the query is re-answered from the whole shard -- by the pass kernels behind
+    the flags the host call reads back, by the sliced rescue pass where the lists stay on the device.
     Query 0 scores row r as x0 + x1 / 256 with (x0, x1) ascending in r -- 16 641 distinct, strictly increasing scores;
     query 1 sees them descending; the other queries are ordinary."""
     from verbatim_rag_amd.vector_stores import DenseShard
@@ -596,13 +597,22 @@ def test_dense_topk_tiled_candidate_overflow_is_rescued():
     Q[0] = 0
     Q[0, 0], Q[0, 1] = 1.0, 1.0 / 256
     Q[1] = -Q[0]
+    import torch
+
     sh = DenseShard(dim, n, "bf16")
     sh.add(X)
-    s, i = sh.search(Q, k)
+    s, i = sh.search(Q, k)                     # the host call: flags read back with the lists, flagged queries through the pass kernels
+    d_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    d_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    sh.search_device(Q, k, d_s.data_ptr(), d_i.data_ptr(), stream=None)     # no host round trip: the device rescue pass (sliced walk + merge)
+    s2, i2 = sh.search(Q[:2], k)               # the two flagged queries alone (64 query columns)
+    torch.cuda.synchronize()
     sh.close()
     rs, ri = T.dense_topk(X, Q, k)
     assert np.array_equal(i[0], np.arange(n - 1, n - 1 - k, -1)) and np.array_equal(i[1], np.arange(k))
     assert np.array_equal(i, ri) and np.array_equal(s, rs)
+    assert np.array_equal(d_i.cpu().numpy(), ri) and np.array_equal(d_s.cpu().numpy(), rs)
+    assert np.array_equal(i2, ri[:2]) and np.array_equal(s2, rs[:2])
 
 
 def test_dense_f32_prefilter_falls_back_when_scores_bunch():

@@ -1259,12 +1259,20 @@ __global__ __launch_bounds__(TSEL_NT) void tiled_select_direct_kernel(const u64*
 // Queries whose candidate buffer overflowed: one workgroup per query walks the whole shard (16 rows in flight, one per
 // 16-lane group, fp32 query in LDS) and rewrites out[q].  Launched with one workgroup per query after every tiled search;
 // all of them leave at once unless a flag is set.
+constexpr int TRESCUE_SLICES = 64;   // workgroups per flagged query (at most: gridDim.y = max(8, min(64, 8192 / queries)) -- thousands of queries launch fewer empty workgroups)
 __global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
-                                                                  const float* __restrict__ queries, int k,
-                                                                  const unsigned* __restrict__ ovf, u64* __restrict__ out) {
-  const int q = blockIdx.x;
+                                                                  const float* __restrict__ queries, int nq, int k,
+                                                                  const unsigned* __restrict__ ovf, u64* __restrict__ part,
+                                                                  unsigned* __restrict__ done, u64* __restrict__ out) {
+  // grid (queries, TRESCUE_SLICES).  Late round 6: the flagged query's shard walk is cut into slices -- one workgroup per slice,
+  // four rows per 16-lane group in flight -- and the slice that finishes last (a counter per query) merges the slices' lists.  One
+  // workgroup per query with one dependent row load per group and step took ~150 ms over 1.25 M x 768 rows: since every batch
+  // of two or more queries over bf16 rows takes the tiled search, a topic-ordered corpus (a query's few thousand relevant rows
+  // in one run, beyond the first stage) must not fall off that cliff.  The per-row arithmetic is unchanged.
+  const int q = blockIdx.x, sl = blockIdx.y;
   if (!ovf[q]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ bool last;
   float* sq = reinterpret_cast<float*>(smem);
   u64* lists = reinterpret_cast<u64*>(smem + (size_t)dim * sizeof(float));   // [16 groups][k]
   const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
@@ -1272,36 +1280,61 @@ __global__ __launch_bounds__(256) void dense_tiled_rescue_kernel(const bf16_t* _
   for (int i = tid; i < 16 * k; i += 256) lists[i] = 0ull;
   __syncthreads();
   u64* mylist = lists + (size_t)grp * k;
-  for (long long r = grp; r < n_rows; r += 16) {
-    const bf16_t* row = rows + (size_t)r * dim;
-    float acc = 0.f;
+  const int n_sl = (int)gridDim.y;
+  const long long per = ((n_rows + n_sl - 1) / n_sl + 63) / 64 * 64;
+  const long long lo = (long long)sl * per, hi = lo + per < n_rows ? lo + per : n_rows;
+  for (long long r0 = lo + grp; r0 < hi; r0 += 64) {   // rows r0, r0 + 16, r0 + 32, r0 + 48 of this group in flight together
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = gl * 8; c < dim; c += 128) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
+      bf16x8 v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc = fmaf((float)v[j], sq[c + j], acc);
+      for (int u = 0; u < 4; ++u) {
+        const long long r = r0 + 16 * u < hi ? r0 + 16 * u : r0;
+        v[u] = *reinterpret_cast<const bf16x8*>(rows + (size_t)r * dim + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) acc[u] = fmaf((float)v[u][j2], sq[c + j2], acc[u]);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (gl == 0) insert_key(mylist, k, make_key(acc, (unsigned)r));
+    for (int u = 0; u < 4; ++u) {
+      float a = acc[u];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (gl == 0 && r0 + 16 * u < hi) insert_key(mylist, k, make_key(a, (unsigned)(r0 + 16 * u)));
+    }
   }
   __syncthreads();
-  if (tid == 0) {
-    int head[16];
-    for (int g = 0; g < 16; ++g) head[g] = 0;
+  auto merge_lists = [&](const u64* src, int n_lists, size_t stride, u64* dst) {   // n_lists sorted lists of k -> the best k (thread 0)
+    int head[TRESCUE_SLICES];
+    for (int g = 0; g < n_lists; ++g) head[g] = 0;
     for (int i = 0; i < k; ++i) {
       u64 best = 0ull;
       int bg = -1;
-      for (int g = 0; g < 16; ++g)
+      for (int g = 0; g < n_lists; ++g)
         if (head[g] < k) {
-          const u64 v = lists[(size_t)g * k + head[g]];
+          const u64 v = src[(size_t)g * stride + head[g]];
           if (v > best) {
             best = v;
             bg = g;
           }
         }
-      out[(size_t)q * k + i] = best;
+      dst[i] = best;
       if (bg >= 0) ++head[bg];
     }
+  };
+  u64* mine = part + ((size_t)sl * nq + q) * k;
+  if (tid == 0) {
+    merge_lists(lists, 16, (size_t)k, mine);
+    __threadfence();
+    last = atomicAdd(done + q, 1u) == (unsigned)(n_sl - 1);
+  }
+  __syncthreads();
+  if (last && tid == 0) {
+    __threadfence();
+    merge_lists(part + (size_t)q * k, n_sl, (size_t)nq * k, out + (size_t)q * k);
+    done[q] = 0u;   // ready for the next search
   }
 }
 
@@ -2200,6 +2233,8 @@ struct vrag_dense_index {
   // tiled batched search (batches over bf16 rows: kTiledMin*): W operand of the score GEMM, candidate buffers, thresholds, flags
   bf16_t* d_tw = nullptr;
   u64 *d_tbuf = nullptr, *d_tthr = nullptr, *d_tdir = nullptr;   // d_tdir: [nq][rows of the first stage] one key per row
+  u64* d_tres = nullptr;   // [TRESCUE_SLICES][nq][k] per-slice lists of the rescue pass
+  size_t d_tres_elems = 0;
   float* d_tthrs = nullptr;
   unsigned* d_tcnt = nullptr;   // [nq] counters followed by [nq] overflow flags
   size_t d_tw_elems = 0, d_tbuf_elems = 0, d_tthr_elems = 0, d_tthrs_elems = 0, d_tcnt_elems = 0, d_tdir_elems = 0;
@@ -2341,6 +2376,7 @@ __global__ void tiled_init_kernel(int nq, u64* __restrict__ thr_key, float* __re
   thr_score[q] = -INFINITY;
   cnt_ovf[q] = 0u;
   cnt_ovf[nq + q] = 0u;
+  cnt_ovf[2 * nq + q] = 0u;   // the rescue pass's slice counter
 }
 
 // Collect form of the tiled search (round 6; the prefilter image of an fp32 index, <= 64 queries): instead of ranking the image for
@@ -2368,7 +2404,8 @@ __global__ void tiled_tau_kernel(int nq, u64* __restrict__ thr_key, float* __res
 }
 
 // The tiled batched search on the resident queries (ix->d_q, fp32): leaves the [nq, k] keys in ix->d_out.  Kernels only.
-int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, const void* rows_bf16 = nullptr, const TiledCollect* col = nullptr) {
+int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, const void* rows_bf16 = nullptr, const TiledCollect* col = nullptr,
+                       bool device_rescue = true) {
   const int dim = ix->dim, pairs = ix->resident_split;
   if (!rows_bf16) rows_bf16 = ix->rows;
   const int n_cols = pairs ? 2 * nq : nq;
@@ -2384,7 +2421,9 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   if ((rc = grow(&ix->d_tbuf, &ix->d_tbuf_elems, (size_t)nq * TCAP))) return rc;
   if ((rc = grow(&ix->d_tthr, &ix->d_tthr_elems, (size_t)nq))) return rc;
   if ((rc = grow(&ix->d_tthrs, &ix->d_tthrs_elems, (size_t)nq))) return rc;
-  if ((rc = grow(&ix->d_tcnt, &ix->d_tcnt_elems, (size_t)2 * nq))) return rc;
+  if ((rc = grow(&ix->d_tcnt, &ix->d_tcnt_elems, (size_t)3 * nq))) return rc;   // counters, overflow flags, the rescue's slice counters
+  const int res_slices = std::max(8, std::min(TRESCUE_SLICES, 8192 / nq));
+  if (!col && (rc = grow(&ix->d_tres, &ix->d_tres_elems, (size_t)res_slices * nq * k))) return rc;
   unsigned* ovf = ix->d_tcnt + nq;
   hipLaunchKernelGGL(tiled_queries_kernel, dim3(n_pad), dim3(256), 0, st, ix->d_q, nq, dim, pairs, n_pad, ix->d_tw);
   hipLaunchKernelGGL(tiled_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, nq, ix->d_tthr, ix->d_tthrs, ix->d_tcnt);
@@ -2486,9 +2525,10 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     HIP_TRY(launch_gemm(EPI_TOPK, g, st));
     return VRAG_OK;   // the caller re-scores and selects; overflow = its flag
   }
+  if (!device_rescue) return VRAG_OK;   // the host call reads the overflow flags back with the lists and re-answers flagged queries through the pass kernels
   const size_t lds = (size_t)dim * sizeof(float) + (size_t)16 * k * sizeof(u64);
-  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n_all, dim,
-                     ix->d_q, k, ovf, ix->d_out);
+  hipLaunchKernelGGL(dense_tiled_rescue_kernel, dim3(nq, res_slices), dim3(256), lds, st, reinterpret_cast<const bf16_t*>(rows_bf16), n_all, dim,
+                     ix->d_q, nq, k, ovf, ix->d_tres, ix->d_tcnt + 2 * (size_t)nq, ix->d_out);
   HIP_TRY(hipGetLastError());
   return VRAG_OK;
 }
@@ -2496,7 +2536,10 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
 // One device pass (k <= KMAX) of a dense search: uploads the queries, runs phase 1 + the per-query merge and leaves the
 // [nq, k] keys in ix->d_out.  Returns once the query upload has been consumed (the caller's buffer may be reused); the
 // kernels are only enqueued.  Caller holds ix->mu and has set the device.
-int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, int image = 0, const TiledCollect* col = nullptr) {
+int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int k, hipStream_t st, int image = 0, const TiledCollect* col = nullptr,
+                         bool* host_rescue = nullptr) {
+  // host_rescue (non-null: the caller reads results back anyway): set when the tiled search ran WITHOUT its device rescue pass -- the
+  // caller copies the overflow flags (ix->d_tcnt + nq) with the lists and re-answers flagged queries itself
   // image: rank the bf16 prefilter image of an fp32 index instead of its rows (the approximate pass of the prefilter route);
   // 2 = with the queries rounded to bf16 instead of riding as (value, remainder) column pairs -- half the GEMM columns, the
   // rounding is part of the caller's error bound
@@ -2530,7 +2573,8 @@ int dense_search_enqueue(vrag_dense_index* ix, const float* queries, int nq, int
   if (ix->size == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_out, 0, (size_t)nq * k * sizeof(u64), st));
   } else if (dense_use_tiled(dtype, ix->dim, nq, k, (long long)ix->size, image ? kTiledMinImage : (ix->resident_split ? kTiledMinBf16Pairs : kTiledMinBf16))) {
-    if ((rc = dense_tiled_search(ix, nq, k, st, image ? rows : nullptr, col))) return rc;
+    if ((rc = dense_tiled_search(ix, nq, k, st, image ? rows : nullptr, col, host_rescue == nullptr))) return rc;
+    if (host_rescue) *host_rescue = true;
   } else {
     HIP_TRY(dense_launch_all(dtype, rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
                              ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
@@ -2597,7 +2641,7 @@ void vrag_dense_index_destroy(vrag_dense_index* ix) {
   if (ix->d_cand) (void)hipFree(ix->d_cand);
   if (ix->d_out) (void)hipFree(ix->d_out);
   if (ix->d_bound) (void)hipFree(ix->d_bound);
-  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tdir, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, (void*)ix->d_pfb, ix->rows16, (void*)ix->d_norm2,
+  for (void* p : {(void*)ix->d_tw, (void*)ix->d_tbuf, (void*)ix->d_tdir, (void*)ix->d_tres, (void*)ix->d_tthr, (void*)ix->d_tthrs, (void*)ix->d_tcnt, (void*)ix->d_pfb, ix->rows16, (void*)ix->d_norm2,
                   (void*)ix->d_pf_eps, (void*)ix->d_pf_out, (void*)ix->d_pf_flag, (void*)ix->d_pf_cand, (void*)ix->d_pf_keys, (void*)ix->d_pf_cnt,
                   (void*)ix->d_pf_thr})
     if (p) (void)hipFree(p);
@@ -2970,9 +3014,33 @@ int vrag_dense_index_search(vrag_dense_index* ix, const float* queries, int32_t 
     }
     ++ix->pf_fallbacks;   // scores bunched within the image's error bound: the full fp32 scan answers
   }
-  if ((rc = dense_search_enqueue(ix, queries, nq, k, st))) return rc;
+  bool host_rescue = false;
+  if ((rc = dense_search_enqueue(ix, queries, nq, k, st, 0, nullptr, &host_rescue))) return rc;
   HIP_TRY(hipMemcpyAsync(keys.data(), ix->d_out, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+  std::vector<unsigned> ovf;
+  if (host_rescue) {
+    ovf.resize((size_t)nq);
+    HIP_TRY(hipMemcpyAsync(ovf.data(), ix->d_tcnt + nq, (size_t)nq * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(hipStreamSynchronize(st));
+  bool flagged = false;
+  for (unsigned f : ovf) flagged = flagged || f != 0u;
+  if (flagged) {
+    // A candidate buffer of the tiled search overflowed (rows in topic order: a query's few thousand relevant rows in one run
+    // beyond the first stage).  The flags are on the host anyway: the batch goes through the pass kernels -- per-workgroup lists,
+    // nothing to overflow, 0.45 ms per 32 queries -- and the flagged queries take their lists from there (the device rescue pass
+    // of the resident / sharded search walks the shard per flagged query: 2 ms for one, 8 ms for 64 of 64).
+    const int n_wg = dense_n_wg(ix->dtype, ix->dim, nq, k, ix->size);
+    HIP_TRY(dense_launch_all(ix->dtype, ix->rows, (long long)ix->size, ix->dim, ix->d_q, nq, k, ix->d_cand, n_wg, st,
+                             ix->d_out + (size_t)nq * k, ix->d_out, nullptr, ix->resident_split));
+    HIP_TRY(launch_topk_merge(ix->d_cand, n_wg, nq, k, ix->d_out, st));
+    HIP_TRY(hipGetLastError());
+    std::vector<u64> again((size_t)nq * k);
+    HIP_TRY(hipMemcpyAsync(again.data(), ix->d_out, again.size() * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < nq; ++q)
+      if (ovf[q]) std::copy(again.begin() + (size_t)q * k, again.begin() + (size_t)(q + 1) * k, keys.begin() + (size_t)q * k);
+  }
   decode_keys(keys, nq, k, 0, nullptr, scores, ids);
   return VRAG_OK;
 }

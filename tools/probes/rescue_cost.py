@@ -8,7 +8,7 @@ import verbatim_rag_amd
 from verbatim_rag_amd.vector_stores import DenseShard
 n, dim, k = 1_250_000, 768, 10
 rng = np.random.default_rng(0)
-sh = DenseShard(dim, n, "bf16")
+sh = DenseShard(dim, n, os.environ.get("ROWS", "bf16"))
 topic = (rng.integers(-64, 65, size=dim) / 64.0).astype(np.float32)
 for b in range(n // 125_000):
     x = (rng.integers(-64, 65, size=(125_000, dim)) / 64.0).astype(np.float32)

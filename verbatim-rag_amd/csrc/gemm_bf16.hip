@@ -760,12 +760,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           if (query >= p.topk_nq) continue;
           unsigned long long* slot = p.topk_buf + (size_t)query * p.topk_cap + (mw + l15);
           asm volatile("" : "+v"(slot));
+          // sampled stage: the key carries the corpus row, rows of launch tile t sit (stride - 1) * 256 * t further on
+          const unsigned row_bias = p.topk_tile_stride > 1 ? (unsigned)(mw >> 8) * (unsigned)(p.topk_tile_stride - 1) * 256u : 0u;
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt) {
             const int row = mw + rt * 16 + l15;
             if (row >= p.M) continue;   // padding rows of the last tile hold whatever the allocation does
             const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][r + 1] : acc[nj][rt][r];
-            slot[rt * 16] = sc >= thr[nj][r] ? make_key(sc, p.topk_row_base + (unsigned)row) : 0ull;
+            slot[rt * 16] = sc >= thr[nj][r] ? make_key(sc, p.topk_row_base + row_bias + (unsigned)row) : 0ull;
           }
         }
     } else if (any) {
@@ -891,6 +893,9 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, KCH ? 1 : 2) void gemm_bf16_ke
   const int b = range_lo + tix;
   const int m0 = (b / nbn) * BM, n0 = (b % nbn) * BN;
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
+  if constexpr (EPI == EPI_TOPK && BM == 256) {   // sampled first stage: tile t of the launch = corpus tile t * stride
+    if (p.topk_tile_stride > 1) Ab = p.A + (size_t)(b / nbn) * p.topk_tile_stride * BM * K;
+  }
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 
   // LDS-DMA staging: instruction i of this wave fills tile rows wave*RPI*INSTR + i*RPI .. +RPI.

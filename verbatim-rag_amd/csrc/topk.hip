@@ -1185,7 +1185,7 @@ constexpr int TSEL_NT = 1024;   // threads of the first stage's selection: its w
 __global__ __launch_bounds__(TSEL_NT) void tiled_select_direct_kernel(const u64* __restrict__ src, int src_stride, int n, u64* __restrict__ buf,
                                                                    unsigned* __restrict__ cnt, int cap, int k, u64* __restrict__ thr_key,
                                                                    float* __restrict__ thr_score, u64* __restrict__ out,
-                                                                   unsigned* __restrict__ ovf) {
+                                                                   unsigned* __restrict__ ovf, int drop_carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned n_surv;
   u64* sk = reinterpret_cast<u64*>(smem);   // cap keys
@@ -1249,9 +1249,11 @@ __global__ __launch_bounds__(TSEL_NT) void tiled_select_direct_kernel(const u64*
     if (out) out[(size_t)q * k + i] = v;
   }
   if (tid == 0) {
-    const bool full = n >= k;
-    cnt[q] = (unsigned)min(n, k);
-    thr_key[q] = full ? sk[k - 1] : 0ull;
+    // drop_carry (the stage ran on a SAMPLE of the shard's tiles and the appending stages will meet these rows again): no key is kept,
+    // only the threshold -- inclusive, so that the k-th key itself is appended again (keys are unique: key > kth - 1 <=> key >= kth)
+    const bool full = n >= k && sk[k - 1] != 0ull;
+    cnt[q] = drop_carry ? 0u : (unsigned)min(n, k);
+    thr_key[q] = full ? sk[k - 1] - (drop_carry ? 1ull : 0ull) : 0ull;
     thr_score[q] = full ? unorderable((unsigned)(sk[k - 1] >> 32)) : -INFINITY;
   }
 }
@@ -2465,16 +2467,31 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   if (n <= c0max) s0 = n;
   else if (R && c0max >= R) s0 = R;   // the key budget holds a whole round: up to 256 queries no appending stage below the last one at all
   else if (R && n % R >= s0min && n % R <= c0max) s0 = n % R;
-  std::vector<long long> b = {0, s0};
-  while (b.back() < n) {
-    long long hi = b.back() * ratio;
-    if (nq <= 256 && hi * 2 >= n) hi = n;
-    if (R && hi < n) hi = b.back() + std::max(R, (hi - b.back()) / R * R);   // whole rounds
-    b.push_back(std::min<long long>(n, hi));
+  // A whole-round first stage takes its 256 tiles as a SAMPLE of the shard -- every (tiles / 256)-th 256-row tile -- instead of the
+  // first 65 536 rows: an entry threshold from a prefix is as good as the prefix is representative, and a corpus in topic order
+  // (a query's few thousand relevant rows in one run somewhere beyond the prefix) overflowed the candidate buffer of the last stage
+  // and fell back to the rescue / the gated full scan (1.5-3 ms instead of 0.4-0.6: profiles/r06_search_timeline.txt).  A run
+  // longer than one sampling period (~4 900 rows at 1.25 M) has a tile in the sample; shorter runs fit the buffer.  The collect
+  // form only needs the threshold, so the sample costs it nothing; the ranking form drops the sample's keys after the selection
+  // (entry threshold = their k-th, inclusive) and its appending stages cover ALL rows, the sampled ones again: one more round.
+  const long long tiles_full = n_all / 256;
+  const int sample_stride = (R == 65536 && s0 == R && tiles_full >= 4 * 256) ? (int)(tiles_full / 256) : 1;
+  const bool sampled = sample_stride > 1;
+  std::vector<long long> b = {0, sampled && !col ? 0 : s0};   // stage i >= 1 covers rows [b[i], b[i + 1])
+  {
+    long long reach = s0;   // rows the thresholds have seen
+    while (b.back() < n) {
+      long long hi = std::max(reach, b.back()) * ratio;
+      if (nq <= 256 && hi * 2 >= n) hi = n;
+      if (R && hi < n) hi = b.back() + std::max(R, (hi - b.back()) / R * R);   // whole rounds
+      b.push_back(std::min<long long>(n, hi));
+      reach = b.back();
+    }
   }
   if ((rc = grow(&ix->d_tdir, &ix->d_tdir_elems, (size_t)nq * (size_t)std::max(c0max, s0)))) return rc;   // the batch size's maximum, not this shard size's: no re-allocation on a later search of a grown shard
   for (size_t stage = 0; stage + 1 < b.size(); ++stage) {
-    const long long lo = b[stage], hi = b[stage + 1];
+    const bool first = stage == 0;
+    const long long lo = first ? 0 : b[stage], hi = first ? s0 : b[stage + 1];
     GemmParams g{};
     g.op_dtype = kOpBf16;
     g.A = reinterpret_cast<const bf16_t*>(rows_bf16) + (size_t)lo * dim;
@@ -2485,19 +2502,20 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     g.topk_thr_score = ix->d_tthrs;
     g.topk_thr_key = ix->d_tthr;
     g.topk_cnt = ix->d_tcnt;
-    g.topk_buf = stage == 0 ? ix->d_tdir : ix->d_tbuf;
-    g.topk_cap = stage == 0 ? (int)s0 : TCAP;
+    g.topk_buf = first ? ix->d_tdir : ix->d_tbuf;
+    g.topk_cap = first ? (int)s0 : TCAP;
     g.topk_nq = nq;
     g.topk_pairs = pairs;
-    g.topk_direct = stage == 0;
+    g.topk_direct = first;
     g.topk_row_base = (unsigned)lo;
     g.topk_tile = tile;
+    g.topk_tile_stride = first ? sample_stride : 1;
     HIP_TRY(launch_gemm(EPI_TOPK, g, st));
-    const bool last = hi >= n;
+    const bool last = !(first && sampled && !col) && hi >= n;
     u64* const sel_out = (last && !col) ? ix->d_out : (u64*)nullptr;
-    if (stage == 0)
+    if (first)
       hipLaunchKernelGGL(tiled_select_direct_kernel, dim3(nq), dim3(TSEL_NT), (size_t)TCAP * sizeof(u64), st, ix->d_tdir, (int)s0, (int)s0, ix->d_tbuf,
-                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf);
+                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf, sampled && !col ? 1 : 0);
     else
       hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
                          ix->d_tthr, ix->d_tthrs, sel_out, ovf, 0);

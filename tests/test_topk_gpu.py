@@ -513,11 +513,19 @@ def test_dense_topk_tiled_stage_plan_around_its_boundaries():
     R = 65536
     cases = [(R, 64, 10), (R + 1, 64, 10), (R - 1, 33, 3), (R + 4095, 64, 10), (R + 4096, 64, 16), (R + 4097, 40, 17),
              (2 * R, 128, 10), (2 * R + 5000, 200, 10), (2 * R + 5000, 256, 16), (3 * R // 2, 257, 10), (R + 4500, 300, 20),
-             (32768 + 4096, 512, 5), (16384 * 3 + 100, 1000, 10), (8192 + 4200, 70, 64), (40_000, 520, 33), (4097, 64, 10)]
+             (32768 + 4096, 512, 5), (16384 * 3 + 100, 1000, 10), (8192 + 4200, 70, 64), (40_000, 520, 33), (4097, 64, 10),
+             # >= 4 rounds of rows and <= 256 query columns: the first stage is a SAMPLE of the shard's tiles (every (tiles / 256)-th),
+             # its keys are dropped after the selection and the appending stages cover all rows -- at the switch, off a tile multiple,
+             # with a sampling period of 2, and (the last case, see below) with the rows in topic order
+             (4 * R - 256, 64, 10), (4 * R, 64, 10), (4 * R + 300, 200, 16), (8 * R + 77, 40, 10), (6 * R + 5, 2, 10)]
     for n, nq, k in cases:
         rng = np.random.default_rng(n * 7 + nq)
         X, Q = _dyadic(rng, (n, 64), lim=8), _dyadic(rng, (nq, 64))
         X[n - 1] = X[0]                         # a tie across the whole shard
+        if n == 6 * R + 5:                      # topic order: 5 000 consecutive rows far better for query 0 than the rest
+            X[200_000:205_000, :8] = 4.0 + rng.integers(0, 8, size=(5_000, 8)).astype(np.float32) / 8     # bf16-exact
+            Q[0] = 0
+            Q[0, :8] = 1.0
         sh = DenseShard(64, n, "bf16")
         sh.add(X)
         s, i = sh.search(Q, k)

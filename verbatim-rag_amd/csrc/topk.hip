@@ -1615,7 +1615,8 @@ constexpr int PFBEST = 2;     // keys kept per workgroup
 template <int DIMC>
 __global__ __launch_bounds__(256) void prefilter_prefix_kernel(const bf16_t* __restrict__ rows, long long n_rows, int dim,
                                                                 const float* __restrict__ query, u64* __restrict__ best,
-                                                                unsigned* __restrict__ cnt, unsigned* __restrict__ flag, int best_stride) {
+                                                                unsigned* __restrict__ cnt, unsigned* __restrict__ flag, int best_stride,
+                                                                long long block_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);
   u64* keys = reinterpret_cast<u64*>(smem + (size_t)dim * sizeof(float));   // [PFROWS]
@@ -1637,7 +1638,9 @@ __global__ __launch_bounds__(256) void prefilter_prefix_kernel(const bf16_t* __r
 #pragma unroll
       for (int j = 0; j < 8; ++j) qreg[i * 8 + j] = sq[gl * 8 + i * 128 + j];
   }
-  const long long r_begin = (long long)blockIdx.x * PFROWS;
+  // block_stride = PFROWS: a prefix; larger: the workgroups' 128-row blocks are a SAMPLE spread over the shard (any subset of rows gives a
+  // valid threshold; a sample gives one that does not depend on the order of the rows -- see dense_tiled_search)
+  const long long r_begin = (long long)blockIdx.x * block_stride;
   for (int it = 0; it < PFROWS / 32; ++it) {
     const long long r = r_begin + grp + 32 * it;
     const bool has0 = r < n_rows, has1 = r + 16 < n_rows;
@@ -2865,6 +2868,10 @@ static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const
   }
   const long long prefix = std::min<long long>(PFPREFIX, (long long)ix->size);
   const int n_wg0 = (int)((prefix + PFROWS - 1) / PFROWS);
+  // shards of at least four prefixes: the threshold rows are a sample -- one 128-row block every size / 256 rows -- not the first 32 768
+  const bool pf_sampled = (long long)ix->size >= 4 * PFPREFIX;
+  const long long pf_block_stride = pf_sampled ? (long long)ix->size / n_wg0 / PFROWS * PFROWS : PFROWS;
+  const long long pf_rows = pf_sampled ? (long long)ix->size : prefix;
   const int per = dense_rows_per_wg((long long)ix->size);
   const int wgs = (int)(((long long)ix->size + per - 1) / per);
   const int dimc = dim % 128 == 0 ? dim / 128 : 0;
@@ -2877,8 +2884,8 @@ static int prefilter_single_enqueue(vrag_dense_index* ix, const float* dq, const
   u64* kth0 = ix->d_pf_thr + 2 * PFQ;
   float* kth_score0 = reinterpret_cast<float*>(ix->d_pf_thr + 3 * PFQ);
 #define VRAG_PF_PREFIX(DC_, Q0_, NQ_) hipLaunchKernelGGL((prefilter_prefix_kernel<DC_>), dim3(n_wg0, NQ_), dim3(256), lds_q + PFROWS * sizeof(u64), st, img, \
-                                                         prefix, dim, dq + (size_t)(Q0_) * dim, ix->d_pf_keys + (size_t)(Q0_) * PFCAP, ix->d_pf_cnt + (Q0_),  \
-                                                         out_flags + (Q0_), PFCAP)
+                                                         pf_rows, dim, dq + (size_t)(Q0_) * dim, ix->d_pf_keys + (size_t)(Q0_) * PFCAP, ix->d_pf_cnt + (Q0_),  \
+                                                         out_flags + (Q0_), PFCAP, pf_block_stride)
   auto prefix_launch = [&](int q0, int n) {
     if (dimc == 6) VRAG_PF_PREFIX(6, q0, n);
     else if (dimc == 3) VRAG_PF_PREFIX(3, q0, n);

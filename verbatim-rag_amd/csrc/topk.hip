@@ -7,15 +7,26 @@
 //
 // Total order everywhere: (score desc, id asc).  A candidate is one u64 key
 //   [ orderable(score) : 32 | 0xFFFFFFFF - local_row : 32 ]      (max key == best hit)
-// Phase 1 streams the shard once per query tile and leaves per-workgroup top-k keys;
-// phase 2 merges them per query.  Both are HBM-bound integer/byte work -- no MFMA.
 //
-// Dense: rows are bf16 (or fp32) row-major; one 16-lane group per row, 16-byte coalesced loads,
-//   fp32 accumulate, 4 queries per pass held in registers.
-// Sparse: SELL-64 ("sliced ELLPACK"): documents sorted by nnz, 64 per slice, column-major inside
-//   the slice, so lane l walks document l with fully coalesced loads and accumulates
-//   fmaf(value, q[term], acc) in the document's term order -- bit-identical to the sequential
-//   CPU restatement.  The query is a dense fp32 vector in LDS (vocab <= 40000) or in L2.
+// Routes as of the end of round 6 (every one pinned to oracle/topk_ref.c by tests/test_topk_gpu.py, test_full_size_gpu.py):
+//   dense, bf16 rows
+//     1 query                      dense_topk_kernel: one 16-lane group per row, 16-byte loads, per-workgroup lists + merge (HBM-bound)
+//     >= 2 queries                 the TILED search (shards >= 4 096 rows, dim % 64 == 0): scores = rows x queries^T on the encoder's GEMM
+//                                  kernel (csrc/gemm_bf16.hip, EPI_TOPK: the epilogue keeps only keys above the query's entry threshold);
+//                                  first stage = one key per row over a SAMPLE of the shard's 256-row tiles (a whole tile round when its
+//                                  keys fit 128 MB) picked over by tiled_select_direct_kernel, later stages whole rounds that append;
+//                                  an overflowing candidate buffer flags its query: pass kernels behind the flags (host call) or the
+//                                  sliced rescue pass (device-resident / sharded search)
+//     other shards, VRAG_TOPK_NO_TILED   4 / 32 queries per pass: dense_topk_kernel, dense_topk_mfma_kernel, dense_topk_mfma2_kernel
+//   dense, fp32 rows (the store's default; scores = the oracle's sequential fmaf chain, bit for bit)
+//     with the bf16 prefilter image (index dtype 2): candidates from the image with a proven error bound, exact re-score --
+//       1-4 queries ONE streaming pass (prefilter_collect[_multi]_kernel), >= 5 the tiled search over the image (collect form up to 256
+//       queries, 64-candidate form above), flagged queries re-answered by the gated full scan
+//     full scan: dense_topk_exact[2]_kernel (32 queries per pass on the fp32 matrix instruction, the chain's bits)
+//   sparse (SELL-64 in groups of four terms; fmaf in the document's term order = the oracle's bits)
+//     1 query sparse_topk_kernel (dense query vector in LDS / L2, scattered on the device); >= 2 queries sparse_topk_multi_kernel
+//     (8 / 16 queries per pass: LDS term map + weight table of the pass's term union)
+//   k > 64: exact pages of 64; topk_merge_*: per-query merges, shard merge behind the all-gather (csrc/comm.hip)
 #include "../../include/vrag_amd.h"
 
 #include <algorithm>

@@ -282,9 +282,12 @@ int vrag_encoder_read_profile(vrag_encoder* enc, float* ms /*[VRAG_PROF_COUNT]*/
  * query) and re-scores them exactly -- half the bytes for a small batch, one read of the shard per batch instead of one per 32
  * queries.  Round 6 routes every batch through it: one to four queries share ONE pass over the image that collects every row
  * within twice the bound of an entry threshold (more than 4096 of them = the full scan); 5 .. 256 queries take the same idea
- * on the tiled score GEMM (thresholds from a 65 536-row prefix, one appending pass, exact re-score of the lists); larger
+ * on the tiled score GEMM (thresholds from 65 536 rows -- a sample of the shard's tiles --, one appending pass, exact re-score of the lists); larger
  * batches rank the image for 64 candidates per query with a sufficiency test.  vrag_dense_index_search_device takes the same
  * routes with the full scan enqueued behind per-query flags instead of a host decision.
+ * bf16 rows (dtype 0): one query streams the shard on the scalar kernel; two or more take the tiled score GEMM (shards of >= 4 096
+ * rows, dim % 64 == 0) -- the shard read once per batch -- whose scores are exact on bf16-representable data and otherwise differ
+ * from the fp32 chain by summation order.
  */
 typedef struct vrag_dense_index vrag_dense_index;
 int vrag_dense_index_create(int32_t dim, int64_t capacity, int32_t dtype, int32_t device, vrag_dense_index** out);

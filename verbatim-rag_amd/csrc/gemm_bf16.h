@@ -83,6 +83,9 @@ struct GemmParams {
   unsigned long long* topk_buf;     // [n queries][topk_cap]
   int topk_cap, topk_nq, topk_pairs, topk_direct, topk_tile;   // topk_tile: 1 = 256 x 128 tiles on a three-stage ring (<= 128 query columns), 2 = 256 x 64 tiles on a four-stage ring (<= 64)
   unsigned topk_row_base;
+  int topk_tile_skip, topk_tile0;   // EPI_TOPK, appending stages behind a sampled first stage: the launch walks the corpus tiles the sample did NOT take --
+                                    // launch tile t is tile d = topk_tile0 + t of that sequence = corpus tile d + d / (skip - 1) + 1 (d < 256 (skip - 1)), d + 256 beyond;
+                                    // A = the shard's first row, keys carry the corpus row (0 / 1 = contiguous rows from A)
   int topk_tile_stride;   // EPI_TOPK, first (one-key-per-row) stage only: row tile t of the launch reads corpus rows [t * stride * 256, + 256) -- a SAMPLE of
                           // the shard's 256-row tiles instead of its first rows (0 / 1 = contiguous; the 256-row tile forms only); keys carry the corpus row
   int op_dtype;           // kOpBf16 (0) or kOpF16 (1): what A, W and every 16-bit output hold (pointers stay typed bf16_t*)

@@ -778,6 +778,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       // of its columns, (c) the keys go out; a reserved slot whose key fails the key test (equal score, higher row) is written as "no key".
       unsigned base[16];
       unsigned have = 0u;
+      unsigned skip_bias = 0u;   // appending stage behind a sampled first stage: rows of launch tile t are corpus rows (see GemmParams::topk_tile_skip)
+      if (p.topk_tile_skip > 1) {
+        const int d = p.topk_tile0 + (mw >> 8), s1 = p.topk_tile_skip - 1;
+        skip_bias = (unsigned)((d < 256 * s1 ? d + d / s1 + 1 : d + 256) - (mw >> 8)) * 256u;
+      }
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
@@ -817,7 +822,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             const int row = mw + rt * 16 + l15;
             const float sc = p.topk_pairs ? acc[nj][rt][r] + acc[nj][rt][(r + 1) & 3] : acc[nj][rt][r];
             if (row < p.M && sc >= thr[nj][r]) {
-              const unsigned long long key = make_key(sc, p.topk_row_base + (unsigned)row);
+              const unsigned long long key = make_key(sc, p.topk_row_base + skip_bias + (unsigned)row);
               if (slot < (unsigned)p.topk_cap) p.topk_buf[(size_t)query * p.topk_cap + slot] = key > tk[r] ? key : 0ull;
               ++slot;
             }
@@ -895,6 +900,10 @@ __global__ __launch_bounds__((WM * WN + HW) * 64, KCH ? 1 : 2) void gemm_bf16_ke
   const bf16_t* __restrict__ Ab = p.A + (size_t)m0 * K;
   if constexpr (EPI == EPI_TOPK && BM == 256) {   // sampled first stage: tile t of the launch = corpus tile t * stride
     if (p.topk_tile_stride > 1) Ab = p.A + (size_t)(b / nbn) * p.topk_tile_stride * BM * K;
+    else if (p.topk_tile_skip > 1) {   // the tiles the sample left: dense tile d -> corpus tile
+      const int d = p.topk_tile0 + b / nbn, s1 = p.topk_tile_skip - 1;
+      Ab = p.A + (size_t)(d < 256 * s1 ? d + d / s1 + 1 : d + 256) * BM * K;
+    }
   }
   const bf16_t* __restrict__ Wb = p.W + (size_t)n0 * K;
 

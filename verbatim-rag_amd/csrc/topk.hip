@@ -2486,21 +2486,22 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
   // (a query's few thousand relevant rows in one run somewhere beyond the prefix) overflowed the candidate buffer of the last stage
   // and fell back to the rescue / the gated full scan (1.5-3 ms instead of 0.4-0.6: profiles/r06_search_timeline.txt).  A run
   // longer than one sampling period (~4 900 rows at 1.25 M) has a tile in the sample; shorter runs fit the buffer.  The collect
-  // form only needs the threshold, so the sample costs it nothing; the ranking form drops the sample's keys after the selection
-  // (entry threshold = their k-th, inclusive) and its appending stages cover ALL rows, the sampled ones again: one more round.
+  // form only needs the threshold; the ranking form keeps the sample's best k (their keys carry the corpus rows) and its appending
+  // stages walk the tiles the sample did not take (GemmParams::topk_tile_skip): every row is scored once, as with a prefix.
   const long long tiles_full = n_all / 256;
   const int sample_stride = (R == 65536 && s0 == R && tiles_full >= 4 * 256) ? (int)(tiles_full / 256) : 1;
   const bool sampled = sample_stride > 1;
-  std::vector<long long> b = {0, sampled && !col ? 0 : s0};   // stage i >= 1 covers rows [b[i], b[i + 1])
-  {
-    long long reach = s0;   // rows the thresholds have seen
-    while (b.back() < n) {
-      long long hi = std::max(reach, b.back()) * ratio;
-      if (nq <= 256 && hi * 2 >= n) hi = n;
-      if (R && hi < n) hi = b.back() + std::max(R, (hi - b.back()) / R * R);   // whole rounds
-      b.push_back(std::min<long long>(n, hi));
-      reach = b.back();
-    }
+  // stage i >= 1 covers rows [b[i], b[i + 1]) -- behind a sampled first stage (ranking form) rows of the sequence of tiles the sample did
+  // NOT take: the appending launches walk that sequence through GemmParams::topk_tile_skip, so no row is scored twice
+  const bool skip = sampled && !col;
+  const long long off = skip ? s0 : 0;   // rows the first stage took out of the sequence
+  std::vector<long long> b = {0, s0 - off};
+  while (b.back() < n - off) {
+    long long hi = (b.back() + off) * ratio;          // rows seen so far x ratio
+    if (nq <= 256 && hi * 2 >= n) hi = n;
+    hi -= off;
+    if (R && hi < n - off) hi = b.back() + std::max(R, (hi - b.back()) / R * R);   // whole rounds
+    b.push_back(std::min<long long>(n - off, hi));
   }
   if ((rc = grow(&ix->d_tdir, &ix->d_tdir_elems, (size_t)nq * (size_t)std::max(c0max, s0)))) return rc;   // the batch size's maximum, not this shard size's: no re-allocation on a later search of a grown shard
   for (size_t stage = 0; stage + 1 < b.size(); ++stage) {
@@ -2508,7 +2509,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     const long long lo = first ? 0 : b[stage], hi = first ? s0 : b[stage + 1];
     GemmParams g{};
     g.op_dtype = kOpBf16;
-    g.A = reinterpret_cast<const bf16_t*>(rows_bf16) + (size_t)lo * dim;
+    g.A = reinterpret_cast<const bf16_t*>(rows_bf16) + (size_t)(skip ? 0 : lo) * dim;
     g.W = ix->d_tw;
     g.M = (int)(hi - lo);
     g.N = n_pad;
@@ -2521,15 +2522,17 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     g.topk_nq = nq;
     g.topk_pairs = pairs;
     g.topk_direct = first;
-    g.topk_row_base = (unsigned)lo;
+    g.topk_row_base = skip ? 0u : (unsigned)lo;
     g.topk_tile = tile;
     g.topk_tile_stride = first ? sample_stride : 1;
+    g.topk_tile_skip = (skip && !first) ? sample_stride : 0;
+    g.topk_tile0 = (skip && !first) ? (int)(lo / 256) : 0;
     HIP_TRY(launch_gemm(EPI_TOPK, g, st));
-    const bool last = !(first && sampled && !col) && hi >= n;
+    const bool last = first ? s0 >= n : hi >= n - off;
     u64* const sel_out = (last && !col) ? ix->d_out : (u64*)nullptr;
     if (first)
       hipLaunchKernelGGL(tiled_select_direct_kernel, dim3(nq), dim3(TSEL_NT), (size_t)TCAP * sizeof(u64), st, ix->d_tdir, (int)s0, (int)s0, ix->d_tbuf,
-                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf, sampled && !col ? 1 : 0);
+                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf, 0);
     else
       hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
                          ix->d_tthr, ix->d_tthrs, sel_out, ovf, 0);

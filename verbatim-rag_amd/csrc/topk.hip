@@ -1196,7 +1196,7 @@ constexpr int TSEL_NT = 1024;   // threads of the first stage's selection: its w
 __global__ __launch_bounds__(TSEL_NT) void tiled_select_direct_kernel(const u64* __restrict__ src, int src_stride, int n, u64* __restrict__ buf,
                                                                    unsigned* __restrict__ cnt, int cap, int k, u64* __restrict__ thr_key,
                                                                    float* __restrict__ thr_score, u64* __restrict__ out,
-                                                                   unsigned* __restrict__ ovf, int drop_carry) {
+                                                                   unsigned* __restrict__ ovf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned n_surv;
   u64* sk = reinterpret_cast<u64*>(smem);   // cap keys
@@ -1260,11 +1260,9 @@ __global__ __launch_bounds__(TSEL_NT) void tiled_select_direct_kernel(const u64*
     if (out) out[(size_t)q * k + i] = v;
   }
   if (tid == 0) {
-    // drop_carry (the stage ran on a SAMPLE of the shard's tiles and the appending stages will meet these rows again): no key is kept,
-    // only the threshold -- inclusive, so that the k-th key itself is appended again (keys are unique: key > kth - 1 <=> key >= kth)
-    const bool full = n >= k && sk[k - 1] != 0ull;
-    cnt[q] = drop_carry ? 0u : (unsigned)min(n, k);
-    thr_key[q] = full ? sk[k - 1] - (drop_carry ? 1ull : 0ull) : 0ull;
+    const bool full = n >= k && sk[k - 1] != 0ull;   // fewer than k keys (rows with NaN scores): everything passes the next stage
+    cnt[q] = (unsigned)min(n, k);
+    thr_key[q] = full ? sk[k - 1] : 0ull;
     thr_score[q] = full ? unorderable((unsigned)(sk[k - 1] >> 32)) : -INFINITY;
   }
 }
@@ -2532,7 +2530,7 @@ int dense_tiled_search(vrag_dense_index* ix, int nq, int k, hipStream_t st, cons
     u64* const sel_out = (last && !col) ? ix->d_out : (u64*)nullptr;
     if (first)
       hipLaunchKernelGGL(tiled_select_direct_kernel, dim3(nq), dim3(TSEL_NT), (size_t)TCAP * sizeof(u64), st, ix->d_tdir, (int)s0, (int)s0, ix->d_tbuf,
-                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf, 0);
+                         ix->d_tcnt, TCAP, k, ix->d_tthr, ix->d_tthrs, sel_out, ovf);
     else
       hipLaunchKernelGGL(tiled_select_kernel, dim3(nq), dim3(256), (size_t)TCAP * sizeof(u64), st, ix->d_tbuf, ix->d_tcnt, TCAP, k,
                          ix->d_tthr, ix->d_tthrs, sel_out, ovf, 0);
